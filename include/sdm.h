@@ -1,0 +1,156 @@
+/*
+ * sdm.h -- C-ABI of the MI355X-native cascaded-regression engine (libsdm_hip.so).
+ *
+ * The reference (patrikhuber/superviseddescent v0.4.1) is a header-only C++ template library with
+ * no FFI of its own; its hot path is reached through duck-typed template concepts
+ * (include/superviseddescent/superviseddescent.hpp:85-86,165-166,262-263,323-324).  This header is
+ * the boundary a maintainer binds those concepts to: every entry point below names the reference
+ * code it stands in for.  Plain C, opaque handle, caller-owned host buffers, library-owned device
+ * buffers, one HIP stream per handle, a handle is not thread-safe.
+ *
+ * Conventions
+ *   - all matrices are row-major float32 (CV_32FC1 in the reference), images are single-channel u8
+ *   - a parameter row is [x_0..x_{L-1}, y_0..y_{L-1}]          (include/rcr/helpers.hpp:45-55)
+ *   - a feature row has F = L*C*C*D + 1 floats, the last one the bias 1.0f
+ *                                                              (include/rcr/adaptive_vlhog.hpp:176-183)
+ *   - return value: 0 = ok, negative = error (text from sdm_last_error()); nothing throws
+ *   - there is NO CPU fallback: without a HIP device every compute entry point returns SDM_ERR_NO_DEVICE
+ */
+#ifndef SDM_H_
+#define SDM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDM_OK 0
+#define SDM_ERR_INVALID (-1)       /* bad argument / call order                                      */
+#define SDM_ERR_NO_DEVICE (-2)     /* no HIP device, or the device is not gfx950                       */
+#define SDM_ERR_HIP (-3)           /* a HIP runtime call failed                                        */
+#define SDM_ERR_EMPTY_PATCH (-4)   /* patch_width_half <= 0: cv::resize would throw in the reference   */
+#define SDM_ERR_NOT_SPD (-5)       /* regularised Gram matrix not positive definite                    */
+#define SDM_ERR_COMM (-6)          /* the installed all-reduce callback failed                         */
+
+#define SDM_VARIANT_DALALTRIGGS 0  /* VlHogVariantDalalTriggs, include/rcr/hog.h:72 */
+#define SDM_VARIANT_UOCTTI 1       /* VlHogVariantUoctti */
+
+#define SDM_REG_MANUAL 0           /* Regulariser::RegularisationType::Manual,     regressors.hpp:96 */
+#define SDM_REG_MATRIX_NORM 1      /* Regulariser::RegularisationType::MatrixNorm, regressors.hpp:97 */
+
+/* rcr::HoGParam, include/rcr/adaptive_vlhog.hpp:41-60 (same field order as its cereal serialisation) */
+typedef struct sdm_hog_param {
+    int variant;
+    int num_cells;
+    int cell_size;
+    int num_bins;
+    float relative_patch_size;
+} sdm_hog_param;
+
+typedef struct sdm_ctx sdm_ctx;
+
+/* Timing slots filled when sdm_enable_timing(ctx, 1): accumulated milliseconds and launch counts,
+ * measured with HIP events on the handle's stream.  The solver slots mirror the four stages
+ * VerbosePartialPivLUSolver prints (include/superviseddescent/verbose_solver.hpp:66-97). */
+enum {
+    SDM_T_HOG = 0,      /* hog_batch_kernel                                  */
+    SDM_T_APPLY = 1,    /* apply_partial_kernel + apply_reduce_kernel        */
+    SDM_T_GRAM = 2,     /* "A^T * A" and A^T * b                             */
+    SDM_T_REG = 3,      /* "AtA + Reg"                                       */
+    SDM_T_FACTOR = 4,   /* "Decomposition" + forward substitution            */
+    SDM_T_BACKSOLVE = 5,/* "solve()"                                         */
+    SDM_T_ALLREDUCE = 6,
+    SDM_T_COUNT = 8
+};
+
+const char* sdm_last_error(void);
+int sdm_device_count(void);                       /* number of usable HIP devices (0 on a CPU box) */
+
+/* Lifetime.  sdm_create fails (NULL) without a gfx950 device. */
+sdm_ctx* sdm_create(int device);
+void sdm_destroy(sdm_ctx* ctx);
+/* Run on a caller-provided hipStream_t (e.g. PyTorch's current stream) instead of the handle's own. */
+int sdm_set_stream(sdm_ctx* ctx, void* hip_stream);
+int sdm_synchronize(sdm_ctx* ctx);
+
+/* Model geometry: what rcr::HogTransform's constructor (adaptive_vlhog.hpp:92) and
+ * InterEyeDistanceNormalisation (include/rcr/model.hpp:90) receive, with the string-keyed landmark
+ * ids resolved to 0-based positions.  n_right == 0 && n_left == 0 selects NoNormalisation
+ * (superviseddescent.hpp:60-74) -- only valid for paths that never extract HOG features. */
+int sdm_set_model_geometry(sdm_ctx* ctx, int num_landmarks, const int* right_eye_idx, int n_right,
+                           const int* left_eye_idx, int n_left, int n_levels, const sdm_hog_param* levels);
+int sdm_feature_dim(const sdm_ctx* ctx, int level);          /* F of that level, or negative */
+
+/* Images: the `const std::vector<cv::Mat>& images` of HogTransform (adaptive_vlhog.hpp:92,188),
+ * single channel u8.  Host images are copied to HBM once. */
+int sdm_upload_images_u8(sdm_ctx* ctx, const uint8_t* const* images, const int* width, const int* height,
+                         const int* stride_bytes, int n_images);
+/* Device-resident stack of equally sized images (image i at base + i*height*stride_bytes); not copied. */
+int sdm_set_images_device(sdm_ctx* ctx, const uint8_t* dev_base, int n_images, int width, int height,
+                          int stride_bytes);
+/* `training_index` of HogTransform::operator() (adaptive_vlhog.hpp:109): sample -> image.
+ * idx == NULL means sample i uses image i. */
+int sdm_set_sample_image_index(sdm_ctx* ctx, const int* idx, int n_samples);
+
+/* current_x of the cascade loops (superviseddescent.hpp:169, 266, 327): N x 2L */
+int sdm_set_x(sdm_ctx* ctx, const float* x_host, int n_samples);
+int sdm_get_x(sdm_ctx* ctx, float* x_host);
+int sdm_set_x_device(sdm_ctx* ctx, const float* x_dev, int n_samples);  /* device-to-device copy */
+int sdm_get_x_device(sdm_ctx* ctx, float* x_dev);
+
+/* One cascade level of feature extraction for all N samples: the thread-pool loop
+ * superviseddescent.hpp:173-189 / 269-285 over rcr::HogTransform::operator() (adaptive_vlhog.hpp:109-185).
+ * feat_host may be NULL (features stay in HBM for sdm_apply / sdm_gram_rhs). */
+int sdm_hog_features(sdm_ctx* ctx, int level, float* feat_host /* N x F or NULL */);
+/* Integer decisions of the last sdm_hog_features call: N x (1+2L) ints
+ * [patch_width_half, cvRound(x_i).., cvRound(y_i)..]   (adaptive_vlhog.hpp:123,132-133). */
+int sdm_get_patch_indices(sdm_ctx* ctx, int* idx_host);
+
+/* LinearRegressor::x of one level (regressors.hpp:383), F x M row-major. */
+int sdm_set_regressor(sdm_ctx* ctx, int level, const float* R_host);
+int sdm_get_regressor(sdm_ctx* ctx, int level, float* R_host);
+/* x <- x - (feat * R_level) .* IED(x): LinearRegressor::predict per row + update
+ * (regressors.hpp:377-381, superviseddescent.hpp:209-215 / 294-301 / 337-339). */
+int sdm_apply(sdm_ctx* ctx, int level);
+/* All levels: SupervisedDescentOptimiser::test (superviseddescent.hpp:262-306) with an empty
+ * template, = rcr::detection_model::detect (model.hpp:132-157) for a batch.  x_host may be NULL. */
+int sdm_detect_batch(sdm_ctx* ctx, float* x_host);
+
+/* Training, one level (superviseddescent.hpp:170-218 with templates.empty()):
+ *   sdm_hog_features -> sdm_gram_rhs -> [sdm_allreduce_gram_rhs] -> sdm_solve -> sdm_apply */
+int sdm_set_targets(sdm_ctx* ctx, const float* xstar_host, int n_samples);   /* `parameters`, :165 */
+/* b = (x - x*) .* norm(x) (:199-205);  G = A^T A, B = A^T b  (regressors.hpp:208,225) */
+int sdm_gram_rhs(sdm_ctx* ctx, int level);
+/* Sum {G, B} over data-parallel ranks through the installed callback (no-op when none is installed). */
+typedef int (*sdm_allreduce_fn)(void* dev_ptr, size_t count_f32, void* hip_stream, void* user);
+int sdm_set_allreduce(sdm_ctx* ctx, sdm_allreduce_fn fn, void* user, int world_size);
+int sdm_allreduce_gram_rhs(sdm_ctx* ctx);
+/* Regulariser::get_matrix (regressors.hpp:126-148) with n_train = the GLOBAL sample count, add to the
+ * diagonal (regressors.hpp:215-221), factor and solve (regressors.hpp:224-225; Cholesky instead of
+ * PartialPivLU: the regularised Gram matrix is SPD).  Stores R as the level's regressor; R_host may be NULL. */
+int sdm_solve(sdm_ctx* ctx, int level, int reg_type, float reg_param, int regularise_last_row,
+              long long n_train_global, float* R_host, float* lambda_out);
+/* Convenience: the four calls above + sdm_apply. */
+int sdm_train_level(sdm_ctx* ctx, int level, int reg_type, float reg_param, int regularise_last_row,
+                    long long n_train_global);
+
+/* Device views for collectives / zero-copy interop (valid until the next allocation-changing call). */
+int sdm_gram_device_ptr(sdm_ctx* ctx, void** dev_ptr, size_t* count_f32);
+int sdm_x_device_ptr(sdm_ctx* ctx, void** dev_ptr, size_t* count_f32);
+int sdm_features_device_ptr(sdm_ctx* ctx, void** dev_ptr, long long* ld, int* n_rows);
+
+/* Profiling. */
+int sdm_enable_timing(sdm_ctx* ctx, int on);
+int sdm_get_timing(sdm_ctx* ctx, float* ms /* [SDM_T_COUNT] */, int* launches /* [SDM_T_COUNT] */, int reset);
+
+/* Test hooks (used by tests/ to check intermediate integer/byte results bit-exactly). */
+int sdm_debug_patch(sdm_ctx* ctx, int level, int sample, int landmark, uint8_t* resized_SxS,
+                    uint8_t* bins_SxS, float* hist_2OxCxC, float* desc_P);
+int sdm_debug_gradient_table(sdm_ctx* ctx, int level, float* g_511x511, int* bin_511x511);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDM_H_ */

@@ -1,0 +1,385 @@
+"""CPU ORACLE (test infrastructure, NOT product code).
+
+Python side of the oracle: a ctypes loader for ``oracle/liboracle.so`` (the C restatement of the
+per-sample HOG feature path, see ``sdm_oracle.c``) plus a numpy float32 restatement of the
+reference's regressor / optimiser / model layer:
+
+* ``Regulariser``, ``LinearRegressor``            include/superviseddescent/regressors.hpp:87-169, 318-400
+* ``PartialPivLUSolver`` arithmetic               include/superviseddescent/regressors.hpp:199-234
+  (Eigen is not in the reference tree -- CMakeLists.txt:41, unpinned; normal equations in f32
+  followed by LAPACK sgetrf/sgetrs partial-pivot LU restate its published algorithm)
+* ``SupervisedDescentOptimiser.train/test/predict``  include/superviseddescent/superviseddescent.hpp:165-344
+* ``align_mean``, ``InterEyeDistanceNormalisation``  include/rcr/model.hpp:64-76, 84-116
+* ``perturb``                                      apps/rcr/rcr-train.cpp:130-146
+
+Pinned by the reference's own known-answer tests (tests/test_LinearRegressor1D.cpp,
+tests/test_LinearRegressorND.cpp, tests/test_SupervisedDescentOptimiser.cpp), restated in
+``tests/test_oracle_regressors.py``.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module.  The product package ``superviseddescent_amd`` never does.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_REF = None
+
+VARIANT_DALALTRIGGS = 0  # hog.h:72
+VARIANT_UOCTTI = 1
+
+
+class HogParamC(ctypes.Structure):
+    """Mirror of ``orc_hog_param`` (= rcr::HoGParam, adaptive_vlhog.hpp:41-60)."""
+
+    _fields_ = [
+        ("variant", ctypes.c_int),
+        ("num_cells", ctypes.c_int),
+        ("cell_size", ctypes.c_int),
+        ("num_bins", ctypes.c_int),
+        ("relative_patch_size", ctypes.c_float),
+    ]
+
+
+@dataclass
+class HoGParam:
+    """rcr::HoGParam (adaptive_vlhog.hpp:41-60)."""
+
+    vlhog_variant: int
+    num_cells: int
+    cell_size: int
+    num_bins: int
+    relative_patch_size: float
+
+    def c(self) -> HogParamC:
+        return HogParamC(self.vlhog_variant, self.num_cells, self.cell_size, self.num_bins,
+                         self.relative_patch_size)
+
+    @property
+    def dim(self) -> int:
+        return 3 * self.num_bins + 4 if self.vlhog_variant == VARIANT_UOCTTI else 4 * self.num_bins
+
+    @property
+    def patch_dim(self) -> int:
+        return self.num_cells * self.num_cells * self.dim
+
+
+def build(force: bool = False) -> None:
+    """Compile liboracle.so (and _ref/libref_hog.so when /root/reference is present)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(
+            os.path.join(_HERE, "sdm_oracle.c")):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+    if os.path.exists("/root/reference/include/rcr/hog.c"):
+        ref = os.path.join(_HERE, "_ref", "libref_hog.so")
+        if force or not os.path.exists(ref):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+
+
+def lib() -> ctypes.CDLL:
+    global _LIB
+    if _LIB is None:
+        build()
+        L = ctypes.CDLL(os.path.join(_HERE, "liboracle.so"))
+        L.orc_get_ied.restype = ctypes.c_double
+        L.orc_cv_round.restype = ctypes.c_int
+        L.orc_cv_round.argtypes = [ctypes.c_double]
+        _LIB = L
+    return _LIB
+
+
+def ref_lib() -> Optional[ctypes.CDLL]:
+    """The reference's own hog.c, compiled verbatim (None when it was never built)."""
+    global _REF
+    if _REF is None:
+        p = os.path.join(_HERE, "_ref", "libref_hog.so")
+        if not os.path.exists(p):
+            build()
+        if os.path.exists(p):
+            _REF = ctypes.CDLL(p)
+    return _REF
+
+
+def use_reference_hog(enable: bool) -> bool:
+    """Route the glue's HOG calls to the reference's verbatim hog.c (returns False if absent)."""
+    L = lib()
+    if not enable:
+        L.orc_set_hog_backend(None)
+        return True
+    R = ref_lib()
+    if R is None:
+        return False
+    L.orc_set_hog_backend(ctypes.cast(R.ref_vl_hog, ctypes.c_void_p))
+    return True
+
+
+def _p(a: np.ndarray, t=ctypes.c_float):
+    return a.ctypes.data_as(ctypes.POINTER(t))
+
+
+def _ints(v: Sequence[int]) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(v, dtype=np.int32))
+
+
+# --------------------------------------------------------------------------------------------
+# C oracle wrappers
+# --------------------------------------------------------------------------------------------
+
+def get_ied(x: np.ndarray, right_eye: Sequence[int], left_eye: Sequence[int]) -> float:
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
+    L = x.size // 2
+    re, le = _ints(right_eye), _ints(left_eye)
+    return float(lib().orc_get_ied(_p(x), L, _p(re, ctypes.c_int), re.size, _p(le, ctypes.c_int),
+                                   le.size))
+
+
+def cv_round(v: float) -> int:
+    return int(lib().orc_cv_round(float(v)))
+
+
+def resize_u8_linear(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    sh, sw = src.shape
+    dst = np.empty((dh, dw), np.uint8)
+    lib().orc_resize_u8_linear(_p(src, ctypes.c_uint8), sw, sh, sw, _p(dst, ctypes.c_uint8), dw, dh, dw)
+    return dst
+
+
+def hog(img: np.ndarray, cell: int, O: int, variant: int = VARIANT_UOCTTI, want_hist=False,
+        want_bins=False):
+    """orc_hog on an f32 image; returns feat [D][hh][hw] (+ raw histogram, + per-pixel bins)."""
+    img = np.ascontiguousarray(img, dtype=np.float32)
+    h, w = img.shape
+    hw, hh = (w + cell // 2) // cell, (h + cell // 2) // cell
+    D = 3 * O + 4 if variant == VARIANT_UOCTTI else 4 * O
+    feat = np.zeros((D, hh, hw), np.float32)
+    hist = np.zeros((2 * O, hh, hw), np.float32) if want_hist else None
+    bins = np.zeros((h, w), np.uint8) if want_bins else None
+    rc = lib().orc_hog(_p(img), w, h, cell, O, variant, _p(feat),
+                       _p(hist) if want_hist else None,
+                       _p(bins, ctypes.c_uint8) if want_bins else None)
+    if rc != 0:
+        raise ValueError("orc_hog: invalid geometry")
+    out = [feat]
+    if want_hist:
+        out.append(hist)
+    if want_bins:
+        out.append(bins)
+    return out[0] if len(out) == 1 else tuple(out)
+
+
+def ref_hog(img: np.ndarray, cell: int, O: int, variant: int = VARIANT_UOCTTI) -> np.ndarray:
+    """The reference's verbatim vl_hog_* on an f32 image (requires oracle/_ref)."""
+    R = ref_lib()
+    if R is None:
+        raise RuntimeError("oracle/_ref/libref_hog.so not built")
+    img = np.ascontiguousarray(img, dtype=np.float32)
+    h, w = img.shape
+    hw, hh = (w + cell // 2) // cell, (h + cell // 2) // cell
+    D = 3 * O + 4 if variant == VARIANT_UOCTTI else 4 * O
+    feat = np.zeros((D, hh, hw), np.float32)
+    R.ref_vl_hog(_p(img), w, h, cell, O, variant, _p(feat))
+    return feat
+
+
+def feature_dim(L: int, hp: HoGParam) -> int:
+    return L * hp.patch_dim + 1
+
+
+def hog_features_batch(images: np.ndarray, img_index: Optional[np.ndarray], x: np.ndarray,
+                       right_eye: Sequence[int], left_eye: Sequence[int], hp: HoGParam,
+                       n_threads: int = 1, want_idx: bool = False, out: Optional[np.ndarray] = None):
+    """HogTransform over a batch, task-per-sample on ``n_threads`` workers
+    (superviseddescent.hpp:173-189).  ``images``: (n_img, H, W) uint8 stack."""
+    images = np.ascontiguousarray(images, dtype=np.uint8)
+    n_img, ih, iw = images.shape
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    N, twoL = x.shape
+    L = twoL // 2
+    F = feature_dim(L, hp)
+    feat = out if out is not None else np.empty((N, F), np.float32)
+    assert feat.shape == (N, F) and feat.dtype == np.float32 and feat.flags.c_contiguous
+    idx = np.zeros((N, 1 + 2 * L), np.int32) if want_idx else None
+    ii = None if img_index is None else _ints(img_index)
+    re, le = _ints(right_eye), _ints(left_eye)
+    hpc = hp.c()
+    rc = lib().orc_hog_features_batch_stack(
+        _p(images, ctypes.c_uint8), n_img, iw, ih, iw,
+        _p(ii, ctypes.c_int) if ii is not None else None, _p(x), N, L,
+        _p(re, ctypes.c_int), re.size, _p(le, ctypes.c_int), le.size, ctypes.byref(hpc),
+        _p(feat), ctypes.c_long(F), _p(idx, ctypes.c_int) if want_idx else None, int(n_threads))
+    if rc != 0:
+        raise ValueError(f"orc_hog_transform failed with status {rc} (patch_width_half <= 0?)")
+    return (feat, idx) if want_idx else feat
+
+
+# --------------------------------------------------------------------------------------------
+# numpy restatement of regressors.hpp / superviseddescent.hpp / model.hpp
+# --------------------------------------------------------------------------------------------
+
+class Regulariser:
+    """regressors.hpp:87-169.  ``get_lambda`` is ``get_matrix``'s diagonal value (126-148)."""
+
+    MANUAL = 0       # RegularisationType::Manual
+    MATRIX_NORM = 1  # RegularisationType::MatrixNorm
+
+    def __init__(self, regularisation_type: int = 0, param: float = 0.0,
+                 regularise_last_row: bool = True):
+        self.regularisation_type = regularisation_type
+        self.param = np.float32(param)
+        self.regularise_last_row = regularise_last_row
+
+    def get_lambda(self, AtA: np.ndarray, num_training_elements: int) -> np.float32:
+        if self.regularisation_type == self.MANUAL:
+            return np.float32(self.param)
+        # regressors.hpp:135: lambda * (float)cv::norm(AtA) / (float)N ; cv::norm accumulates in double
+        fro = np.float32(np.sqrt(np.sum(AtA.astype(np.float64) ** 2)))
+        return np.float32(np.float32(self.param * fro) / np.float32(num_training_elements))
+
+
+def partial_piv_lu_solve(data: np.ndarray, labels: np.ndarray, regulariser: Regulariser) -> np.ndarray:
+    """PartialPivLUSolver::solve (regressors.hpp:199-234), all in float32."""
+    from scipy.linalg import lu_factor, lu_solve
+
+    A = np.ascontiguousarray(data, dtype=np.float32)
+    b = np.ascontiguousarray(labels, dtype=np.float32)
+    AtA = (A.T @ A).astype(np.float32)                       # :208
+    lam = regulariser.get_lambda(AtA, A.shape[0])            # :212
+    diag = np.full(AtA.shape[0], lam, np.float32)
+    if not regulariser.regularise_last_row:
+        diag[-1] = 0.0                                       # :143-146
+    AtA[np.diag_indices_from(AtA)] += diag                   # :215-221
+    Atb = (A.T @ b).astype(np.float32)
+    lu, piv = lu_factor(AtA, check_finite=False)             # :224 (sgetrf: partial pivoting)
+    return np.ascontiguousarray(lu_solve((lu, piv), Atb, check_finite=False), dtype=np.float32)  # :225
+
+
+class LinearRegressor:
+    """regressors.hpp:318-400."""
+
+    def __init__(self, regulariser: Optional[Regulariser] = None):
+        self.x: Optional[np.ndarray] = None
+        self.regulariser = regulariser or Regulariser()
+
+    def learn(self, data: np.ndarray, labels: np.ndarray) -> bool:
+        self.x = partial_piv_lu_solve(data, labels, self.regulariser)   # :345-350
+        return True
+
+    def predict(self, values: np.ndarray) -> np.ndarray:
+        return (np.asarray(values, np.float32) @ self.x).astype(np.float32)  # :377-381
+
+    def test(self, data: np.ndarray, labels: np.ndarray) -> float:
+        pred = self.predict(data)                                          # :361-369
+        labels = np.asarray(labels, np.float32)
+        return float(np.linalg.norm((pred - labels).astype(np.float64)) /
+                     np.linalg.norm(labels.astype(np.float64)))
+
+
+class NoNormalisation:
+    """superviseddescent.hpp:60-74."""
+
+    def __call__(self, params: np.ndarray) -> np.ndarray:
+        return np.ones_like(params, dtype=np.float32)
+
+
+class InterEyeDistanceNormalisation:
+    """model.hpp:84-116 with integer eye indices instead of string ids: row of (float)(1/IED)."""
+
+    def __init__(self, right_eye: Sequence[int], left_eye: Sequence[int]):
+        self.right_eye, self.left_eye = list(right_eye), list(left_eye)
+
+    def __call__(self, params: np.ndarray) -> np.ndarray:
+        params = np.atleast_2d(np.asarray(params, np.float32))
+        out = np.empty_like(params)
+        for i in range(params.shape[0]):
+            out[i, :] = np.float32(1.0 / get_ied(params[i], self.right_eye, self.left_eye))
+        return out
+
+
+class SupervisedDescentOptimiser:
+    """superviseddescent.hpp:85-361.  ``projection(current_x[N x P], level) -> N x F`` is the
+    batched form of the reference's per-sample ``projection(row, level, index)``."""
+
+    def __init__(self, regressors: List[LinearRegressor], normalisation=None):
+        self.regressors = regressors
+        self.normalisation = normalisation or NoNormalisation()
+
+    def _inv_norm(self, x: np.ndarray) -> np.ndarray:
+        n = self.normalisation(x)
+        return (np.float32(1.0) / n).astype(np.float32)            # `1 / normalisation(x)` :213
+
+    def train(self, parameters, initialisations, templates, projection, callback=None):
+        x = np.asarray(initialisations, np.float32).copy()
+        params = np.asarray(parameters, np.float32)
+        for level, reg in enumerate(self.regressors):
+            feats = np.asarray(projection(x, level), np.float32)                    # :173-189
+            obs = feats if templates is None else (feats - np.asarray(templates, np.float32))  # :191-197
+            b = ((x - params) * self.normalisation(x)).astype(np.float32)          # :199-205
+            reg.learn(obs, b)                                                      # :207
+            upd = reg.predict(obs) * self._inv_norm(x)                             # :209-215
+            x = (x - upd).astype(np.float32)
+            if callback is not None:
+                callback(x)                                                        # :217
+        return x
+
+    def test(self, initialisations, templates, projection, callback=None):
+        x = np.asarray(initialisations, np.float32).copy()
+        for level, reg in enumerate(self.regressors):
+            feats = np.asarray(projection(x, level), np.float32)                    # :269-285
+            obs = feats if templates is None else (feats - np.asarray(templates, np.float32))
+            upd = reg.predict(obs) * self._inv_norm(x)                             # :294-301
+            x = (x - upd).astype(np.float32)
+            if callback is not None:
+                callback(x)
+        return x
+
+    def predict(self, initialisation, templates, projection):
+        return self.test(np.atleast_2d(initialisation), templates, projection)     # :323-344
+
+
+class HogTransform:
+    """rcr::HogTransform (adaptive_vlhog.hpp:70-195), batched over samples."""
+
+    def __init__(self, images: np.ndarray, hog_params: List[HoGParam], right_eye, left_eye,
+                 img_index: Optional[np.ndarray] = None, n_threads: int = 1):
+        self.images, self.hog_params = images, hog_params
+        self.right_eye, self.left_eye = list(right_eye), list(left_eye)
+        self.img_index, self.n_threads = img_index, n_threads
+
+    def __call__(self, x: np.ndarray, level: int) -> np.ndarray:
+        x = np.atleast_2d(np.asarray(x, np.float32))
+        return hog_features_batch(self.images, self.img_index, x, self.right_eye, self.left_eye,
+                                  self.hog_params[level], self.n_threads)
+
+
+def align_mean(mean: np.ndarray, box, scaling_x=1.0, scaling_y=1.0, translation_x=0.0,
+               translation_y=0.0) -> np.ndarray:
+    """model.hpp:64-76; box = (x, y, w, h) ints.  f32 evaluation of the MatExpr."""
+    mean = np.asarray(mean, np.float32).reshape(-1)
+    L = mean.size // 2
+    bx, by, bw, bh = box
+    out = np.empty_like(mean)
+    out[:L] = (mean[:L] * np.float32(scaling_x) + np.float32(0.5) + np.float32(translation_x)) \
+        * np.float32(bw) + np.float32(bx)
+    out[L:] = (mean[L:] * np.float32(scaling_y) + np.float32(0.5) + np.float32(translation_y)) \
+        * np.float32(bh) + np.float32(by)
+    return out.astype(np.float32)
+
+
+def perturb(box, tx: float, ty: float, s: float = 1.0):
+    """apps/rcr/rcr-train.cpp:130-146 (float arithmetic, truncation into cv::Rect ints)."""
+    x, y, w, h = box
+    f = np.float32
+    tx_pixel, ty_pixel = f(tx) * f(w), f(ty) * f(h)
+    pw, ph = f(w) * f(s), f(h) * f(s)
+    nx = f(x) + (f(w) - pw) / f(2.0) + tx_pixel
+    ny = f(y) + (f(h) - ph) / f(2.0) + ty_pixel
+    return (int(nx), int(ny), int(pw), int(ph))

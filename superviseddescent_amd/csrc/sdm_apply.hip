@@ -1,0 +1,213 @@
+// sdm_apply.hip -- batched regressor apply + cascade update for gfx950 (MI355X).
+//
+// Replaces the reference's serial per-sample loop (include/superviseddescent/superviseddescent.hpp:
+// 209-215, 294-301, 337-339):
+//     update = regressors[l].predict(row)                 -> `values * x`, include/superviseddescent/regressors.hpp:377-381
+//     update = update.mul(1 / normalisation(current_x))   -> * IED(current_x), include/rcr/model.hpp:94-98
+//     x_next = current_x - update
+// by one skinny f32 GEMM  U[N x M] = feat[N x F] * R[F x M]  (M = 2L = 44 | 136) on the matrix cores
+// (v_mfma_f32_16x16x4_f32: exact f32 products, k-ordered f32 accumulation) with the IED-scaled update
+// fused into the split-K reduction.
+//
+// Operand layout: both operands are K-contiguous.  feat rows are the HOG kernel's output; the regressor
+// is held transposed Rt[Mp][ldr] (row j = column j of R, zero padded to Mp = 16*ceil(M/16) rows and to
+// ldr = ldf columns).  A lane (i = l&15, q = l>>4) loads one float4 feat[row0+i][k0+4q..4q+3] and one
+// float4 Rt[col0+i][k0+4q..4q+3]; element e of both feeds MFMA e of the 16-wide k-group, so sixteen k's
+// cost four MFMAs per 16x16 output tile and no LDS traffic at all on the operand path.
+//
+// Work split: a workgroup of 4 waves owns 16*RT rows x all Mp columns x one K-split; its waves take
+// interleaved 16-wide k-groups, their accumulators are summed through LDS in wave order 0..3 and written
+// to partial[split][N][Mp]; apply_reduce_kernel sums the splits in order and applies the update.  The
+// result is therefore run-to-run deterministic.
+//
+// Roofline: 2*N*F*M flops over N*F*4 feature bytes = M/2 flop/B (22 | 68): HBM-bound for RCR-22,
+// MFMA-bound for RCR-68.
+#include "sdm_kernels.h"
+
+#pragma clang fp contract(off)  // update = u*scale, then x - update: two roundings as in the reference
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ inline double device_ied_rows(const float* __restrict__ xr, int L, const EyeIdxDev& e)
+{
+    // get_ied, include/rcr/helpers.hpp:136-160 (same arithmetic as sdm_hog.hip::device_ied)
+    float rx = 0.0f, ry = 0.0f, lx = 0.0f, ly = 0.0f;
+    for (int i = 0; i < e.nre; ++i) { rx += xr[e.re[i]]; ry += xr[e.re[i] + L]; }
+    rx /= (float)e.nre; ry /= (float)e.nre;
+    for (int i = 0; i < e.nle; ++i) { lx += xr[e.le[i]]; ly += xr[e.le[i] + L]; }
+    lx /= (float)e.nle; ly /= (float)e.nle;
+    float dxf = rx - lx, dyf = ry - ly;
+    double dx = dxf, dy = dyf;
+    return sqrt(dx * dx + dy * dy);
+}
+
+#define APPLY_WAVES 4
+
+// RT = 16-row tiles per wave, NT = 16-column tiles (Mp/16)
+template <int RT, int NT>
+__global__ void __launch_bounds__(APPLY_WAVES * 64)
+apply_partial_kernel(const float* __restrict__ feat, long long ldf, int N, int kgroups,
+                     const float* __restrict__ Rt, long long ldr, float* __restrict__ partial, int splits)
+{
+    __shared__ float red[APPLY_WAVES - 1][RT * NT][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int row0 = blockIdx.x * (16 * RT);
+    const int split = blockIdx.y;
+    // k-groups (16 wide) of this split: [g0, g1)
+    const int g0 = (int)(((long long)kgroups * split) / splits);
+    const int g1 = (int)(((long long)kgroups * (split + 1)) / splits);
+
+    f32x4 acc[RT][NT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const float* arow[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        int row = row0 + 16 * r + li;
+        if (row > N - 1) row = N - 1;  // clamp: duplicates are never stored
+        arow[r] = feat + (long long)row * ldf + 4 * lq;
+    }
+    const float* brow[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) brow[c] = Rt + (long long)(16 * c + li) * ldr + 4 * lq;
+
+    for (int g = g0 + wave; g < g1; g += APPLY_WAVES) {
+        const long long k0 = (long long)g * 16;
+        f32x4 a[RT], b[NT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) a[r] = *(const f32x4*)(arow[r] + k0);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) b[c] = *(const f32x4*)(brow[c] + k0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int c = 0; c < NT; ++c)
+                    acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][e], b[c][e], acc[r][c], 0, 0, 0);
+    }
+
+    // cross-wave reduction in wave order (deterministic)
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int c = 0; c < NT; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) red[wave - 1][r * NT + c][e][lane] = acc[r][c][e];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int Mp = NT * 16;
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int c = 0; c < NT; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[r][c][e];
+                    for (int w = 0; w < APPLY_WAVES - 1; ++w) v += red[w][r * NT + c][e][lane];
+                    // C/D layout of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + e
+                    const int row = row0 + 16 * r + lq * 4 + e;
+                    const int col = 16 * c + li;
+                    if (row < N) partial[((long long)split * N + row) * Mp + col] = v;
+                }
+    }
+}
+
+__global__ void apply_reduce_kernel(const float* __restrict__ partial, int splits, int N, int Mp, int M,
+                                    const float* __restrict__ x_in, float* __restrict__ x_out, int L,
+                                    EyeIdxDev eyes)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)N * M) return;
+    const int row = (int)(t / M), col = (int)(t - (long long)row * M);
+    float u = 0.0f;
+    for (int s = 0; s < splits; ++s) u += partial[((long long)s * N + row) * Mp + col];
+    const float* xr = x_in + (long long)row * M;
+    float scale = 1.0f;
+    if (eyes.nre > 0) {
+        // normalisation(x) = ones / ied -> (float)(1.0/ied)  (model.hpp:97);  update.mul(1 / norm)
+        const float n = (float)(1.0 / device_ied_rows(xr, L, eyes));
+        scale = 1.0f / n;
+    }
+    x_out[t] = xr[col] - u * scale;
+}
+
+__global__ void targets_kernel(const float* __restrict__ x, const float* __restrict__ xstar, int N, int L,
+                               EyeIdxDev eyes, float* __restrict__ feat, long long ldf, int bcol0)
+{
+    // b = (x - x*) .* normalisation(x), superviseddescent.hpp:199-205
+    const int M = 2 * L;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)N * M) return;
+    const int row = (int)(t / M), col = (int)(t - (long long)row * M);
+    const float* xr = x + (long long)row * M;
+    float n = 1.0f;
+    if (eyes.nre > 0) n = (float)(1.0 / device_ied_rows(xr, L, eyes));
+    feat[(long long)row * ldf + bcol0 + col] = (xr[col] - xstar[t]) * n;
+}
+
+}  // namespace
+
+int sdm_apply_splits(int N, int F)
+{
+    // enough workgroups to cover 256 CUs a few times over, but at least 4 k-groups per wave
+    const int row_blocks = (N + 31) / 32;
+    int splits = (1024 + row_blocks - 1) / row_blocks;
+    const int kgroups = (F + 15) / 16;
+    int max_splits = kgroups / (4 * APPLY_WAVES);
+    if (max_splits < 1) max_splits = 1;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    if (splits > 64) splits = 64;
+    return splits;
+}
+
+template <int RT, int NT>
+static void launch_partial(const float* feat, long long ldf, int N, int kgroups, const float* Rt,
+                           long long ldr, float* partial, int splits, hipStream_t stream)
+{
+    dim3 grid((N + 16 * RT - 1) / (16 * RT), splits);
+    hipLaunchKernelGGL((apply_partial_kernel<RT, NT>), grid, dim3(APPLY_WAVES * 64), 0, stream, feat, ldf, N,
+                       kgroups, Rt, ldr, partial, splits);
+}
+
+void sdm_launch_apply(const float* feat, long long ldf, int N, int F, const float* Rt, long long ldr,
+                      int M, const float* x_in, float* x_out, int L, const EyeIdxDev& eyes,
+                      float* partial, int splits, hipStream_t stream)
+{
+    if (N <= 0) return;
+    const int kgroups = (F + 15) / 16;   // feat/Rt are zero padded to a multiple of 16 columns
+    const int NT = (M + 15) / 16;
+    switch (NT) {
+        case 1: launch_partial<2, 1>(feat, ldf, N, kgroups, Rt, ldr, partial, splits, stream); break;
+        case 2: launch_partial<2, 2>(feat, ldf, N, kgroups, Rt, ldr, partial, splits, stream); break;
+        case 3: launch_partial<2, 3>(feat, ldf, N, kgroups, Rt, ldr, partial, splits, stream); break;
+        case 4: launch_partial<2, 4>(feat, ldf, N, kgroups, Rt, ldr, partial, splits, stream); break;
+        case 5: launch_partial<2, 5>(feat, ldf, N, kgroups, Rt, ldr, partial, splits, stream); break;
+        case 6: launch_partial<2, 6>(feat, ldf, N, kgroups, Rt, ldr, partial, splits, stream); break;
+        case 7: launch_partial<2, 7>(feat, ldf, N, kgroups, Rt, ldr, partial, splits, stream); break;
+        case 8: launch_partial<2, 8>(feat, ldf, N, kgroups, Rt, ldr, partial, splits, stream); break;
+        case 9: launch_partial<2, 9>(feat, ldf, N, kgroups, Rt, ldr, partial, splits, stream); break;
+        default: return;  // M > 144 rejected by the C-ABI before reaching here
+    }
+    const long long total = (long long)N * M;
+    hipLaunchKernelGGL(apply_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                       partial, splits, N, NT * 16, M, x_in, x_out, L, eyes);
+}
+
+void sdm_launch_targets(const float* x, const float* xstar, int N, int L, const EyeIdxDev& eyes,
+                        float* feat, long long ldf, int bcol0, hipStream_t stream)
+{
+    const long long total = (long long)N * 2 * L;
+    if (total <= 0) return;
+    hipLaunchKernelGGL(targets_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, xstar,
+                       N, L, eyes, feat, ldf, bcol0);
+}

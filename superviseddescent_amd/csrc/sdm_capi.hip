@@ -1,0 +1,724 @@
+// sdm_capi.hip -- implementation of the C-ABI declared in include/sdm.h.
+// Host-side bookkeeping only: device buffers, stream, kernel launch sequencing.  All arithmetic of the
+// hot path runs in the gfx950 kernels (sdm_hog.hip, sdm_apply.hip, sdm_solve.hip); there is no CPU
+// fallback -- without a device sdm_create() fails.
+#include "../../include/sdm.h"
+#include "sdm_kernels.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(SDM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;   // elements
+    int ensure(size_t n, bool zero = false, hipStream_t s = nullptr)
+    {
+        if (n <= cap) return SDM_OK;
+        if (p) { hipError_t e = hipFree(p); (void)e; p = nullptr; cap = 0; }
+        hipError_t e = hipMalloc((void**)&p, n * sizeof(T));
+        if (e != hipSuccess) return fail(SDM_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+        cap = n;
+        if (zero) {
+            e = hipMemsetAsync(p, 0, n * sizeof(T), s);
+            if (e != hipSuccess) return fail(SDM_ERR_HIP, std::string("hipMemset: ") + hipGetErrorString(e));
+        }
+        return SDM_OK;
+    }
+    void release()
+    {
+        if (p) { hipError_t e = hipFree(p); (void)e; }
+        p = nullptr; cap = 0;
+    }
+};
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+struct sdm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    // geometry
+    int L = 0, M = 0;
+    EyeIdxDev eyes{};
+    std::vector<HogLevelDev> levels;
+    std::vector<sdm_hog_param> params;
+    int Fmax = 0;
+    long long ldf = 0;      // feature row stride: round_up(Fmax,128) + 128 (tail tile = training targets)
+
+    // images
+    DevBuf<uint8_t> img_owned;
+    const uint8_t* img_base = nullptr;
+    DevBuf<long long> img_off;
+    DevBuf<int> img_w, img_h, img_stride;
+    int n_images = 0;
+    DevBuf<int> img_idx;
+    bool idx_identity = true;
+
+    // samples
+    int N = 0;
+    DevBuf<float> x[2];
+    int cur = 0;
+    DevBuf<float> xstar;
+    bool have_targets = false;
+    DevBuf<float> feat;
+    int feat_level = -1;
+    DevBuf<int> patch_idx;
+    DevBuf<int> status;
+    DevBuf<float> partial;
+
+    // regressors, transposed + padded: [Mp][ldf]
+    std::vector<DevBuf<float>> Rt;
+    std::vector<bool> have_R;
+
+    // normal equations
+    DevBuf<float> G;       // [ncols][ncols]
+    int g_ncols = 0;
+    int g_level = -1;
+    DevBuf<double> fro;
+    DevBuf<float> Rsol;    // [Fp][Mp_ld]
+    DevBuf<float> lambda_dev;
+
+    sdm_allreduce_fn allreduce = nullptr;
+    void* allreduce_user = nullptr;
+    int world_size = 1;
+
+    // timing
+    bool timing = false;
+    float t_ms[SDM_T_COUNT] = {0};
+    int t_n[SDM_T_COUNT] = {0};
+    struct Pending { int slot; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+};
+
+namespace {
+
+int Mp_of(int M) { return round_up(M, 16); }
+
+struct Timer {
+    sdm_ctx* c; int slot; hipEvent_t a = nullptr, b = nullptr;
+    Timer(sdm_ctx* ctx, int s) : c(ctx), slot(s)
+    {
+        if (!c->timing) return;
+        a = take(); b = take();
+        hipError_t e = hipEventRecord(a, c->stream); (void)e;
+    }
+    hipEvent_t take()
+    {
+        if (!c->pool.empty()) { hipEvent_t ev = c->pool.back(); c->pool.pop_back(); return ev; }
+        hipEvent_t ev; hipError_t e = hipEventCreate(&ev); (void)e; return ev;
+    }
+    ~Timer()
+    {
+        if (!c->timing) return;
+        hipError_t e = hipEventRecord(b, c->stream); (void)e;
+        c->pending.push_back({slot, a, b});
+    }
+};
+
+void drain_timing(sdm_ctx* c)
+{
+    for (auto& p : c->pending) {
+        hipError_t e = hipEventSynchronize(p.b); (void)e;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { c->t_ms[p.slot] += ms; c->t_n[p.slot] += 1; }
+        c->pool.push_back(p.a); c->pool.push_back(p.b);
+    }
+    c->pending.clear();
+}
+
+int check_status(sdm_ctx* c)
+{
+    int st = 0;
+    HIP_TRY(hipMemcpyAsync(&st, c->status.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (st) {
+        HIP_TRY(hipMemsetAsync(c->status.p, 0, sizeof(int), c->stream));
+        if (st & SDM_DEV_ERR_EMPTY_PATCH)
+            return fail(SDM_ERR_EMPTY_PATCH, "patch_width_half <= 0 for at least one sample (inter-eye distance too small)");
+        if (st & 2) return fail(SDM_ERR_NOT_SPD, "regularised Gram matrix is not positive definite; increase lambda");
+    }
+    return SDM_OK;
+}
+
+int level_F(const sdm_ctx* c, int level) { return c->L * c->levels[level].P + 1; }
+
+ImageSetDev image_set(const sdm_ctx* c)
+{
+    ImageSetDev s;
+    s.base = c->img_base; s.offset = c->img_off.p; s.w = c->img_w.p; s.h = c->img_h.p;
+    s.stride = c->img_stride.p; s.n_images = c->n_images;
+    return s;
+}
+
+int ensure_sample_buffers(sdm_ctx* c, int N)
+{
+    int rc;
+    const size_t nx = (size_t)N * c->M;
+    if ((rc = c->x[0].ensure(nx))) return rc;
+    if ((rc = c->x[1].ensure(nx))) return rc;
+    const size_t nf = (size_t)N * (size_t)c->ldf;
+    if (nf > c->feat.cap) {
+        // zero once: the padding columns must stay exactly 0 for the GEMMs that read full tiles
+        if ((rc = c->feat.ensure(nf, true, c->stream))) return rc;
+        c->feat_level = -1;
+    }
+    if ((rc = c->patch_idx.ensure((size_t)N * (1 + 2 * c->L)))) return rc;
+    return SDM_OK;
+}
+
+int do_hog(sdm_ctx* c, int level)
+{
+    if (!c->img_base) return fail(SDM_ERR_INVALID, "no images set");
+    if (c->N <= 0) return fail(SDM_ERR_INVALID, "no samples set (sdm_set_x)");
+    if (c->eyes.nre <= 0 || c->eyes.nle <= 0)
+        return fail(SDM_ERR_INVALID, "HOG features need eye landmark indices (IED-adaptive patch size)");
+    if (c->idx_identity && c->N > c->n_images)
+        return fail(SDM_ERR_INVALID, "more samples than images and no sample->image index set");
+    if (c->feat_level >= 0 && level_F(c, c->feat_level) != level_F(c, level)) {
+        // a different level geometry leaves stale columns beyond its own F: clear the rows once
+        HIP_TRY(hipMemsetAsync(c->feat.p, 0, (size_t)c->N * c->ldf * sizeof(float), c->stream));
+    }
+    {
+        Timer t(c, SDM_T_HOG);
+        sdm_launch_hog(image_set(c), c->idx_identity ? nullptr : c->img_idx.p, c->x[c->cur].p, c->N, c->L,
+                       c->eyes, c->levels[level], c->feat.p, c->ldf, c->patch_idx.p, c->status.p, c->stream);
+    }
+    HIP_TRY(hipGetLastError());
+    c->feat_level = level;
+    return SDM_OK;
+}
+
+int do_apply(sdm_ctx* c, int level)
+{
+    if (c->feat_level != level) return fail(SDM_ERR_INVALID, "sdm_apply: features of this level not extracted");
+    if (!c->have_R[level]) return fail(SDM_ERR_INVALID, "sdm_apply: no regressor set for this level");
+    const int F = level_F(c, level);
+    const int splits = sdm_apply_splits(c->N, F);
+    int rc = c->partial.ensure((size_t)splits * c->N * Mp_of(c->M));
+    if (rc) return rc;
+    {
+        Timer t(c, SDM_T_APPLY);
+        sdm_launch_apply(c->feat.p, c->ldf, c->N, F, c->Rt[level].p, c->ldf, c->M, c->x[c->cur].p,
+                         c->x[c->cur ^ 1].p, c->L, c->eyes, c->partial.p, splits, c->stream);
+    }
+    HIP_TRY(hipGetLastError());
+    c->cur ^= 1;
+    return SDM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* sdm_last_error(void) { return g_err.c_str(); }
+
+int sdm_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+sdm_ctx* sdm_create(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        fail(SDM_ERR_NO_DEVICE, "no HIP device available: this engine has no CPU fallback");
+        return nullptr;
+    }
+    if (device < 0 || device >= n) { fail(SDM_ERR_INVALID, "device index out of range"); return nullptr; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { fail(SDM_ERR_HIP, "hipGetDeviceProperties failed"); return nullptr; }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fail(SDM_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) { fail(SDM_ERR_HIP, "hipSetDevice failed"); return nullptr; }
+    sdm_ctx* c = new sdm_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        fail(SDM_ERR_HIP, "hipStreamCreate failed"); delete c; return nullptr;
+    }
+    c->own_stream = true;
+    if (c->status.ensure(1, true, c->stream) || c->lambda_dev.ensure(1, true, c->stream)) { delete c; return nullptr; }
+    return c;
+}
+
+void sdm_destroy(sdm_ctx* c)
+{
+    if (!c) return;
+    hipError_t e = hipSetDevice(c->device); (void)e;
+    e = hipStreamSynchronize(c->stream);
+    drain_timing(c);
+    for (auto ev : c->pool) { e = hipEventDestroy(ev); }
+    c->img_owned.release(); c->img_off.release(); c->img_w.release(); c->img_h.release();
+    c->img_stride.release(); c->img_idx.release(); c->x[0].release(); c->x[1].release();
+    c->xstar.release(); c->feat.release(); c->patch_idx.release(); c->status.release();
+    c->partial.release(); c->G.release(); c->fro.release(); c->Rsol.release(); c->lambda_dev.release();
+    for (auto& r : c->Rt) r.release();
+    if (c->own_stream) e = hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int sdm_set_stream(sdm_ctx* c, void* hip_stream)
+{
+    if (!c) return fail(SDM_ERR_INVALID, "null context");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->own_stream) { HIP_TRY(hipStreamDestroy(c->stream)); c->own_stream = false; }
+    c->stream = (hipStream_t)hip_stream;
+    return SDM_OK;
+}
+
+int sdm_synchronize(sdm_ctx* c)
+{
+    if (!c) return fail(SDM_ERR_INVALID, "null context");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    drain_timing(c);
+    return SDM_OK;
+}
+
+int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int* le, int nle, int n_levels,
+                           const sdm_hog_param* levels)
+{
+    if (!c) return fail(SDM_ERR_INVALID, "null context");
+    if (L <= 0 || n_levels <= 0 || !levels) return fail(SDM_ERR_INVALID, "bad geometry");
+    if (nre < 0 || nle < 0 || nre > SDM_MAX_EYE || nle > SDM_MAX_EYE || ((nre == 0) != (nle == 0)))
+        return fail(SDM_ERR_INVALID, "eye index lists must both be empty or hold 1..4 entries each");
+    if (2 * L > 144) return fail(SDM_ERR_INVALID, "at most 72 landmarks (2L <= 144) supported");
+    for (int i = 0; i < nre; ++i) if (re[i] < 0 || re[i] >= L) return fail(SDM_ERR_INVALID, "right eye index out of range");
+    for (int i = 0; i < nle; ++i) if (le[i] < 0 || le[i] >= L) return fail(SDM_ERR_INVALID, "left eye index out of range");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->L = L; c->M = 2 * L;
+    c->eyes.nre = nre; c->eyes.nle = nle;
+    for (int i = 0; i < nre; ++i) c->eyes.re[i] = re[i];
+    for (int i = 0; i < nle; ++i) c->eyes.le[i] = le[i];
+    c->levels.clear(); c->params.clear();
+    c->Fmax = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        const sdm_hog_param& p = levels[l];
+        if (p.variant != SDM_VARIANT_DALALTRIGGS && p.variant != SDM_VARIANT_UOCTTI)
+            return fail(SDM_ERR_INVALID, "unknown HOG variant");
+        if (p.num_cells < 1 || p.cell_size < 1 || p.num_bins < 1 || p.num_bins > SDM_MAX_ORIENT)
+            return fail(SDM_ERR_INVALID, "HOG parameters out of range (num_bins <= 16)");
+        if (p.num_cells * p.cell_size <= 3) return fail(SDM_ERR_INVALID, "resized ROI must exceed 3 px (hog.c:545-546)");
+        if (!(p.relative_patch_size > 0.0f)) return fail(SDM_ERR_INVALID, "relative_patch_size must be positive");
+        HogLevelDev lv;
+        memset(&lv, 0, sizeof(lv));
+        lv.variant = p.variant; lv.C = p.num_cells; lv.cell = p.cell_size; lv.O = p.num_bins;
+        lv.S = lv.C * lv.cell;
+        lv.D = p.variant == SDM_VARIANT_UOCTTI ? 3 * lv.O + 4 : 4 * lv.O;   // hog.c:212-219
+        lv.P = lv.C * lv.C * lv.D;
+        lv.rel = p.relative_patch_size;
+        for (int k = 0; k < lv.O; ++k) {            // hog.c:195-199, evaluated with the host libm
+            const double angle = k * 3.141592653589793 / lv.O;
+            lv.ox[k] = (float)cos(angle);
+            lv.oy[k] = (float)sin(angle);
+        }
+        if (sdm_hog_lds_bytes(lv, 4) > 160 * 1024) return fail(SDM_ERR_INVALID, "HOG geometry exceeds the LDS budget");
+        c->levels.push_back(lv); c->params.push_back(p);
+        const int F = L * lv.P + 1;
+        if (F > c->Fmax) c->Fmax = F;
+    }
+    c->ldf = (long long)round_up(c->Fmax, 128) + 128;
+    for (auto& r : c->Rt) r.release();
+    c->Rt.assign(n_levels, DevBuf<float>());
+    c->have_R.assign(n_levels, false);
+    c->feat.release(); c->feat_level = -1;
+    c->N = 0; c->have_targets = false; c->g_level = -1;
+    return SDM_OK;
+}
+
+int sdm_feature_dim(const sdm_ctx* c, int level)
+{
+    if (!c || level < 0 || level >= (int)c->levels.size()) return fail(SDM_ERR_INVALID, "bad level");
+    return level_F(c, level);
+}
+
+int sdm_upload_images_u8(sdm_ctx* c, const uint8_t* const* images, const int* w, const int* h,
+                         const int* stride, int n)
+{
+    if (!c || !images || n <= 0) return fail(SDM_ERR_INVALID, "bad image list");
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<long long> off(n);
+    long long total = 0;
+    for (int i = 0; i < n; ++i) {
+        if (w[i] <= 0 || h[i] <= 0 || stride[i] < w[i]) return fail(SDM_ERR_INVALID, "bad image size");
+        off[i] = total;
+        total += (long long)w[i] * h[i];   // stored densely (stride = width) in HBM
+    }
+    int rc;
+    if ((rc = c->img_owned.ensure((size_t)total))) return rc;
+    if ((rc = c->img_off.ensure(n)) || (rc = c->img_w.ensure(n)) || (rc = c->img_h.ensure(n)) || (rc = c->img_stride.ensure(n)))
+        return rc;
+    for (int i = 0; i < n; ++i)
+        HIP_TRY(hipMemcpy2DAsync(c->img_owned.p + off[i], w[i], images[i], stride[i], w[i], h[i],
+                                 hipMemcpyHostToDevice, c->stream));
+    std::vector<int> dense(w, w + n);
+    HIP_TRY(hipMemcpyAsync(c->img_off.p, off.data(), n * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->img_w.p, w, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->img_h.p, h, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->img_stride.p, dense.data(), n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->img_base = c->img_owned.p;
+    c->n_images = n;
+    return SDM_OK;
+}
+
+int sdm_set_images_device(sdm_ctx* c, const uint8_t* dev_base, int n, int w, int h, int stride)
+{
+    if (!c || !dev_base || n <= 0 || w <= 0 || h <= 0 || stride < w) return fail(SDM_ERR_INVALID, "bad device image stack");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    if ((rc = c->img_off.ensure(n)) || (rc = c->img_w.ensure(n)) || (rc = c->img_h.ensure(n)) || (rc = c->img_stride.ensure(n)))
+        return rc;
+    std::vector<long long> off(n);
+    std::vector<int> vw(n, w), vh(n, h), vs(n, stride);
+    for (int i = 0; i < n; ++i) off[i] = (long long)i * h * stride;
+    HIP_TRY(hipMemcpyAsync(c->img_off.p, off.data(), n * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->img_w.p, vw.data(), n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->img_h.p, vh.data(), n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->img_stride.p, vs.data(), n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->img_base = dev_base;
+    c->n_images = n;
+    return SDM_OK;
+}
+
+int sdm_set_sample_image_index(sdm_ctx* c, const int* idx, int n)
+{
+    if (!c) return fail(SDM_ERR_INVALID, "null context");
+    if (!idx) { c->idx_identity = true; return SDM_OK; }
+    if (n <= 0) return fail(SDM_ERR_INVALID, "bad sample count");
+    for (int i = 0; i < n; ++i)
+        if (idx[i] < 0 || (c->n_images > 0 && idx[i] >= c->n_images)) return fail(SDM_ERR_INVALID, "image index out of range");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = c->img_idx.ensure(n);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->img_idx.p, idx, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->idx_identity = false;
+    return SDM_OK;
+}
+
+static int set_x_common(sdm_ctx* c, const float* x, int N, hipMemcpyKind kind)
+{
+    if (!c || !x || N <= 0) return fail(SDM_ERR_INVALID, "bad x");
+    if (c->L <= 0) return fail(SDM_ERR_INVALID, "geometry not set");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_sample_buffers(c, N);
+    if (rc) return rc;
+    if (N != c->N) { c->have_targets = false; c->feat_level = -1; }
+    c->N = N; c->cur = 0;
+    HIP_TRY(hipMemcpyAsync(c->x[0].p, x, (size_t)N * c->M * sizeof(float), kind, c->stream));
+    if (kind == hipMemcpyHostToDevice) HIP_TRY(hipStreamSynchronize(c->stream));
+    return SDM_OK;
+}
+
+int sdm_set_x(sdm_ctx* c, const float* x, int N) { return set_x_common(c, x, N, hipMemcpyHostToDevice); }
+int sdm_set_x_device(sdm_ctx* c, const float* x, int N) { return set_x_common(c, x, N, hipMemcpyDeviceToDevice); }
+
+int sdm_get_x(sdm_ctx* c, float* x)
+{
+    if (!c || !x || c->N <= 0) return fail(SDM_ERR_INVALID, "no x to get");
+    HIP_TRY(hipMemcpyAsync(x, c->x[c->cur].p, (size_t)c->N * c->M * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return check_status(c);
+}
+
+int sdm_get_x_device(sdm_ctx* c, float* x)
+{
+    if (!c || !x || c->N <= 0) return fail(SDM_ERR_INVALID, "no x to get");
+    HIP_TRY(hipMemcpyAsync(x, c->x[c->cur].p, (size_t)c->N * c->M * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    return SDM_OK;
+}
+
+int sdm_hog_features(sdm_ctx* c, int level, float* feat_host)
+{
+    if (!c || level < 0 || level >= (int)c->levels.size()) return fail(SDM_ERR_INVALID, "bad level");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = do_hog(c, level);
+    if (rc) return rc;
+    if (feat_host) {
+        const int F = level_F(c, level);
+        HIP_TRY(hipMemcpy2DAsync(feat_host, (size_t)F * sizeof(float), c->feat.p, (size_t)c->ldf * sizeof(float),
+                                 (size_t)F * sizeof(float), c->N, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return check_status(c);
+    }
+    return SDM_OK;
+}
+
+int sdm_get_patch_indices(sdm_ctx* c, int* idx)
+{
+    if (!c || !idx || c->N <= 0 || c->feat_level < 0) return fail(SDM_ERR_INVALID, "no HOG call to report");
+    HIP_TRY(hipMemcpyAsync(idx, c->patch_idx.p, (size_t)c->N * (1 + 2 * c->L) * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SDM_OK;
+}
+
+int sdm_set_regressor(sdm_ctx* c, int level, const float* R)
+{
+    if (!c || !R || level < 0 || level >= (int)c->levels.size()) return fail(SDM_ERR_INVALID, "bad regressor");
+    HIP_TRY(hipSetDevice(c->device));
+    const int F = level_F(c, level), M = c->M, Mp = Mp_of(M);
+    int rc = c->Rt[level].ensure((size_t)Mp * c->ldf);
+    if (rc) return rc;
+    std::vector<float> t((size_t)Mp * c->ldf, 0.0f);
+    for (int k = 0; k < F; ++k)
+        for (int j = 0; j < M; ++j) t[(size_t)j * c->ldf + k] = R[(size_t)k * M + j];
+    HIP_TRY(hipMemcpyAsync(c->Rt[level].p, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_R[level] = true;
+    return SDM_OK;
+}
+
+int sdm_get_regressor(sdm_ctx* c, int level, float* R)
+{
+    if (!c || !R || level < 0 || level >= (int)c->levels.size() || !c->have_R[level]) return fail(SDM_ERR_INVALID, "no regressor");
+    const int F = level_F(c, level), M = c->M, Mp = Mp_of(M);
+    std::vector<float> t((size_t)Mp * c->ldf);
+    HIP_TRY(hipMemcpyAsync(t.data(), c->Rt[level].p, t.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < F; ++k)
+        for (int j = 0; j < M; ++j) R[(size_t)k * M + j] = t[(size_t)j * c->ldf + k];
+    return SDM_OK;
+}
+
+int sdm_apply(sdm_ctx* c, int level)
+{
+    if (!c || level < 0 || level >= (int)c->levels.size()) return fail(SDM_ERR_INVALID, "bad level");
+    HIP_TRY(hipSetDevice(c->device));
+    return do_apply(c, level);
+}
+
+int sdm_detect_batch(sdm_ctx* c, float* x_host)
+{
+    if (!c) return fail(SDM_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    for (int l = 0; l < (int)c->levels.size(); ++l) {
+        int rc = do_hog(c, l);
+        if (rc) return rc;
+        if ((rc = do_apply(c, l))) return rc;
+    }
+    if (x_host) return sdm_get_x(c, x_host);
+    return SDM_OK;
+}
+
+int sdm_set_targets(sdm_ctx* c, const float* xstar, int N)
+{
+    if (!c || !xstar || N <= 0 || N != c->N) return fail(SDM_ERR_INVALID, "targets must match the sample count of sdm_set_x");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = c->xstar.ensure((size_t)N * c->M);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->xstar.p, xstar, (size_t)N * c->M * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_targets = true;
+    return SDM_OK;
+}
+
+int sdm_gram_rhs(sdm_ctx* c, int level)
+{
+    if (!c || level < 0 || level >= (int)c->levels.size()) return fail(SDM_ERR_INVALID, "bad level");
+    if (c->feat_level != level) return fail(SDM_ERR_INVALID, "sdm_gram_rhs: features of this level not extracted");
+    if (!c->have_targets) return fail(SDM_ERR_INVALID, "sdm_gram_rhs: no targets set");
+    HIP_TRY(hipSetDevice(c->device));
+    const int F = level_F(c, level);
+    const int Fp = round_up(F, 128), ncols = Fp + 128;
+    int rc = c->G.ensure((size_t)ncols * ncols);
+    if (rc) return rc;
+    Timer t(c, SDM_T_GRAM);
+    // the tail tile of every feature row holds b; clear it first (columns beyond 2L must be 0)
+    HIP_TRY(hipMemset2DAsync(c->feat.p + Fp, (size_t)c->ldf * sizeof(float), 0, 128 * sizeof(float), c->N, c->stream));
+    sdm_launch_targets(c->x[c->cur].p, c->xstar.p, c->N, c->L, c->eyes, c->feat.p, c->ldf, Fp, c->stream);
+    sdm_launch_syrk_tn(c->feat.p, c->ldf, c->N, ncols, c->G.p, ncols, 1.0f, 0, 0, c->stream);
+    HIP_TRY(hipGetLastError());
+    c->g_ncols = ncols; c->g_level = level;
+    return SDM_OK;
+}
+
+int sdm_set_allreduce(sdm_ctx* c, sdm_allreduce_fn fn, void* user, int world_size)
+{
+    if (!c || world_size < 1) return fail(SDM_ERR_INVALID, "bad all-reduce registration");
+    c->allreduce = fn; c->allreduce_user = user; c->world_size = world_size;
+    return SDM_OK;
+}
+
+int sdm_allreduce_gram_rhs(sdm_ctx* c)
+{
+    if (!c || c->g_level < 0) return fail(SDM_ERR_INVALID, "no Gram matrix to reduce");
+    if (!c->allreduce || c->world_size == 1) return SDM_OK;
+    Timer t(c, SDM_T_ALLREDUCE);
+    // rows [0, Fp) hold every tile the solve reads (Gram upper tiles + RHS tile column)
+    const size_t count = (size_t)(c->g_ncols - 128) * c->g_ncols;
+    if (c->allreduce(c->G.p, count, (void*)c->stream, c->allreduce_user) != 0)
+        return fail(SDM_ERR_COMM, "all-reduce callback reported failure");
+    return SDM_OK;
+}
+
+int sdm_solve(sdm_ctx* c, int level, int reg_type, float reg_param, int regularise_last_row,
+              long long n_train_global, float* R_host, float* lambda_out)
+{
+    if (!c || level < 0 || level >= (int)c->levels.size()) return fail(SDM_ERR_INVALID, "bad level");
+    if (c->g_level != level) return fail(SDM_ERR_INVALID, "sdm_solve: no Gram matrix for this level");
+    if (reg_type != SDM_REG_MANUAL && reg_type != SDM_REG_MATRIX_NORM) return fail(SDM_ERR_INVALID, "bad regulariser type");
+    HIP_TRY(hipSetDevice(c->device));
+    const int F = level_F(c, level), M = c->M, Mp = Mp_of(M);
+    const int Fp = round_up(F, 128), ncols = c->g_ncols;
+    int rc;
+    if ((rc = c->fro.ensure((size_t)F + 1))) return rc;
+    if ((rc = c->Rsol.ensure((size_t)Fp * Mp))) return rc;
+    if ((rc = c->Rt[level].ensure((size_t)Mp * c->ldf))) return rc;
+    {
+        Timer t(c, SDM_T_REG);
+        if (reg_type == SDM_REG_MATRIX_NORM) sdm_launch_fro2_upper(c->G.p, ncols, F, c->fro.p, c->stream);
+        sdm_launch_add_diag(c->G.p, ncols, F, c->fro.p + F, reg_type, reg_param,
+                            (int)(n_train_global > 0 ? n_train_global : c->N), regularise_last_row,
+                            c->lambda_dev.p, c->stream);
+    }
+    {
+        Timer t(c, SDM_T_FACTOR);
+        // factor + forward substitution (the back substitution is part of the same launcher)
+        sdm_launch_cholesky_solve(c->G.p, ncols, F, Fp, Mp, c->Rsol.p, Mp, nullptr, c->status.p, c->stream);
+    }
+    HIP_TRY(hipGetLastError());
+    // R (Fp x Mp) -> Rt (Mp x ldf), zero padded
+    HIP_TRY(hipMemsetAsync(c->Rt[level].p, 0, (size_t)Mp * c->ldf * sizeof(float), c->stream));
+    std::vector<float> r((size_t)Fp * Mp);
+    HIP_TRY(hipMemcpyAsync(r.data(), c->Rsol.p, r.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((rc = check_status(c))) return rc;
+    std::vector<float> t((size_t)Mp * c->ldf, 0.0f);
+    for (int k = 0; k < F; ++k)
+        for (int j = 0; j < M; ++j) t[(size_t)j * c->ldf + k] = r[(size_t)k * Mp + j];
+    HIP_TRY(hipMemcpyAsync(c->Rt[level].p, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_R[level] = true;
+    c->g_level = -1;   // G now holds the factor
+    if (R_host)
+        for (int k = 0; k < F; ++k)
+            for (int j = 0; j < M; ++j) R_host[(size_t)k * M + j] = r[(size_t)k * Mp + j];
+    if (lambda_out) {
+        HIP_TRY(hipMemcpy(lambda_out, c->lambda_dev.p, sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return SDM_OK;
+}
+
+int sdm_train_level(sdm_ctx* c, int level, int reg_type, float reg_param, int regularise_last_row,
+                    long long n_train_global)
+{
+    int rc;
+    if ((rc = sdm_hog_features(c, level, nullptr))) return rc;
+    if ((rc = sdm_gram_rhs(c, level))) return rc;
+    if ((rc = sdm_allreduce_gram_rhs(c))) return rc;
+    if ((rc = sdm_solve(c, level, reg_type, reg_param, regularise_last_row, n_train_global, nullptr, nullptr))) return rc;
+    return sdm_apply(c, level);
+}
+
+int sdm_gram_device_ptr(sdm_ctx* c, void** p, size_t* count)
+{
+    if (!c || c->g_level < 0) return fail(SDM_ERR_INVALID, "no Gram matrix");
+    *p = c->G.p; *count = (size_t)(c->g_ncols - 128) * c->g_ncols;
+    return SDM_OK;
+}
+
+int sdm_x_device_ptr(sdm_ctx* c, void** p, size_t* count)
+{
+    if (!c || c->N <= 0) return fail(SDM_ERR_INVALID, "no x");
+    *p = c->x[c->cur].p; *count = (size_t)c->N * c->M;
+    return SDM_OK;
+}
+
+int sdm_features_device_ptr(sdm_ctx* c, void** p, long long* ld, int* n_rows)
+{
+    if (!c || c->feat_level < 0) return fail(SDM_ERR_INVALID, "no features");
+    *p = c->feat.p; *ld = c->ldf; *n_rows = c->N;
+    return SDM_OK;
+}
+
+int sdm_enable_timing(sdm_ctx* c, int on)
+{
+    if (!c) return fail(SDM_ERR_INVALID, "null context");
+    c->timing = on != 0;
+    return SDM_OK;
+}
+
+int sdm_get_timing(sdm_ctx* c, float* ms, int* launches, int reset)
+{
+    if (!c) return fail(SDM_ERR_INVALID, "null context");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    drain_timing(c);
+    for (int i = 0; i < SDM_T_COUNT; ++i) {
+        if (ms) ms[i] = c->t_ms[i];
+        if (launches) launches[i] = c->t_n[i];
+        if (reset) { c->t_ms[i] = 0.f; c->t_n[i] = 0; }
+    }
+    return SDM_OK;
+}
+
+int sdm_debug_patch(sdm_ctx* c, int level, int sample, int landmark, uint8_t* rsz, uint8_t* bins, float* hist, float* desc)
+{
+    if (!c || level < 0 || level >= (int)c->levels.size()) return fail(SDM_ERR_INVALID, "bad level");
+    if (sample < 0 || sample >= c->N || landmark < 0 || landmark >= c->L) return fail(SDM_ERR_INVALID, "bad patch");
+    if (!c->img_base) return fail(SDM_ERR_INVALID, "no images set");
+    HIP_TRY(hipSetDevice(c->device));
+    const HogLevelDev& lv = c->levels[level];
+    const size_t nS = (size_t)lv.S * lv.S, nH = (size_t)2 * lv.O * lv.C * lv.C, nP = lv.P;
+    DevBuf<uint8_t> d_r, d_b; DevBuf<float> d_h, d_d;
+    int rc;
+    if ((rc = d_r.ensure(nS)) || (rc = d_b.ensure(nS)) || (rc = d_h.ensure(nH)) || (rc = d_d.ensure(nP))) return rc;
+    sdm_launch_hog_debug(image_set(c), c->idx_identity ? nullptr : c->img_idx.p, c->x[c->cur].p, c->N, c->L,
+                         c->eyes, lv, sample, landmark, d_r.p, d_b.p, d_h.p, d_d.p, c->status.p, c->stream);
+    HIP_TRY(hipGetLastError());
+    if (rsz) HIP_TRY(hipMemcpyAsync(rsz, d_r.p, nS, hipMemcpyDeviceToHost, c->stream));
+    if (bins) HIP_TRY(hipMemcpyAsync(bins, d_b.p, nS, hipMemcpyDeviceToHost, c->stream));
+    if (hist) HIP_TRY(hipMemcpyAsync(hist, d_h.p, nH * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (desc) HIP_TRY(hipMemcpyAsync(desc, d_d.p, nP * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    d_r.release(); d_b.release(); d_h.release(); d_d.release();
+    return SDM_OK;
+}
+
+int sdm_debug_gradient_table(sdm_ctx* c, int level, float* g, int* bin)
+{
+    if (!c || level < 0 || level >= (int)c->levels.size() || !g || !bin) return fail(SDM_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n = 511 * 511;
+    DevBuf<float> d_g; DevBuf<int> d_b;
+    int rc;
+    if ((rc = d_g.ensure(n)) || (rc = d_b.ensure(n))) return rc;
+    sdm_launch_gradient_table(c->levels[level], d_g.p, d_b.p, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(g, d_g.p, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(bin, d_b.p, n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    d_g.release(); d_b.release();
+    return SDM_OK;
+}
+
+}  // extern "C"

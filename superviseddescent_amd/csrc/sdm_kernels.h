@@ -1,0 +1,92 @@
+// sdm_kernels.h -- internal launch interface between the C-ABI (sdm_capi.hip) and the gfx950 kernels.
+// Not part of the public boundary (that is include/sdm.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SDM_MAX_ORIENT 16  // max undirected orientations (num_bins) a level may ask for
+#define SDM_MAX_EYE 4      // max landmarks averaged per eye centre
+
+// Geometry of one cascade level's HOG, resolved on the host (doubles evaluated with glibc so that
+// they are bit-identical to the reference's CPU evaluation: include/rcr/hog.c:195-199).
+struct HogLevelDev {
+    int variant;      // 0 DalalTriggs, 1 UoCTTI           (include/rcr/hog.h:72)
+    int C;            // num_cells                          (include/rcr/adaptive_vlhog.hpp:44)
+    int cell;         // cell_size
+    int O;            // num_bins = undirected orientations
+    int S;            // C*cell, the fixed resized ROI edge  (adaptive_vlhog.hpp:154)
+    int D;            // per-cell dimension 3O+4 | 4O        (hog.c:212-219)
+    int P;            // C*C*D floats per landmark
+    float rel;        // relative_patch_size
+    float ox[SDM_MAX_ORIENT];  // (float)cos(k*pi/O)
+    float oy[SDM_MAX_ORIENT];  // (float)sin(k*pi/O)
+};
+
+struct EyeIdxDev {
+    int nre, nle;
+    int re[SDM_MAX_EYE];
+    int le[SDM_MAX_EYE];
+};
+
+// Image set: a stack of single-channel u8 images addressed through per-image descriptors.
+struct ImageSetDev {
+    const uint8_t* base;       // device pointer
+    const long long* offset;   // [n_images] byte offset of image i from base
+    const int* w;              // [n_images]
+    const int* h;
+    const int* stride;         // bytes per row
+    int n_images;
+};
+
+// status bits written by kernels into the context's device status word
+#define SDM_DEV_ERR_EMPTY_PATCH 1  // patch_width_half <= 0 (cv::resize would throw in the reference)
+
+size_t sdm_hog_lds_bytes(const HogLevelDev& lv, int waves_per_block);
+
+// HOG features for every (sample, landmark) of one cascade level.
+//  x        [N][2L] f32 current landmark estimates
+//  img_idx  [N] sample -> image (nullptr = identity)
+//  feat     [N][ldf] f32 output rows: L*P descriptor floats then the bias 1.0f
+//  idx_out  nullable [N][1+2L] ints: patch_width_half, cx_i.., cy_i..   (integer decisions)
+void sdm_launch_hog(const ImageSetDev& imgs, const int* img_idx, const float* x, int N, int L,
+                    const EyeIdxDev& eyes, const HogLevelDev& lv, float* feat, long long ldf,
+                    int* idx_out, int* status, hipStream_t stream);
+
+// Single-patch debug variant that also returns the resized ROI, per-pixel bins and raw histogram.
+void sdm_launch_hog_debug(const ImageSetDev& imgs, const int* img_idx, const float* x, int N, int L,
+                          const EyeIdxDev& eyes, const HogLevelDev& lv, int sample, int landmark,
+                          uint8_t* rsz_out, uint8_t* bins_out, float* hist_out, float* desc_out,
+                          int* status, hipStream_t stream);
+
+// (g, directed bin) for every integer gradient (gx, gy) in [-255,255]^2 : exhaustive arithmetic check.
+void sdm_launch_gradient_table(const HogLevelDev& lv, float* g_out, int* bin_out, hipStream_t stream);
+
+// ---- regressor apply: u = feat[N x F] * R[F x M]; x_out = x - u * IED(x) ----------------------
+// Rt is the regressor transposed and padded: [Mp][ldr] f32 (row j = column j of R), Mp = 16*ceil(M/16)
+int sdm_apply_splits(int N, int F);
+void sdm_launch_apply(const float* feat, long long ldf, int N, int F, const float* Rt, long long ldr,
+                      int M, const float* x_in, float* x_out, int L, const EyeIdxDev& eyes,
+                      float* partial, int splits, hipStream_t stream);
+
+// ---- training -----------------------------------------------------------------------------------
+// b = (x - xstar) * (float)(1/IED(x)) written into feat[:, bcol0 : bcol0+2L]
+void sdm_launch_targets(const float* x, const float* xstar, int N, int L, const EyeIdxDev& eyes,
+                        float* feat, long long ldf, int bcol0, hipStream_t stream);
+
+// C[i][j] (+)= alpha * sum_n A[n][i]*A[n][j] for the upper-triangular 128x128 tiles of the
+// ncols x ncols matrix (i-tile <= j-tile); A is [rows][lda], C is [ncols][ldc]. ncols % 128 == 0.
+// tile_i0 / tile_j0 restrict the update to tiles with i-tile >= tile_i0 (used by the Cholesky).
+void sdm_launch_syrk_tn(const float* A, long long lda, int rows, int ncols, float* C, long long ldc,
+                        float alpha, int accumulate, int tile_i0, hipStream_t stream);
+
+// Frobenius norm^2 (double) of the symmetric matrix whose upper triangle (incl. diagonal) of the
+// leading F x F block is stored in G; result accumulated into *out (must be zeroed).
+void sdm_launch_fro2_upper(const float* G, long long ldg, int F, double* out, hipStream_t stream);
+void sdm_launch_add_diag(float* G, long long ldg, int F, const double* fro2, int reg_type, float param,
+                         int n_train, int regularise_last_row, float* lambda_out, hipStream_t stream);
+
+// Blocked Cholesky G = U^T U on the upper triangle of the leading F x F block, with the
+// forward substitution fused into the panel updates for the extra columns [rhs0, rhs0+nrhs),
+// then back substitution; R_out [F][ldr].  work: >= 2*NB*NB floats.
+void sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs, float* R_out,
+                               long long ldr, float* work, int* status, hipStream_t stream);

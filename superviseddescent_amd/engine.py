@@ -1,0 +1,417 @@
+"""Python host side of the engine: the reference's operator surface for the RCR hot path, bound to the
+C-ABI (``include/sdm.h``) through ctypes.
+
+Class and method names follow the reference so that the parity tests read like its own:
+
+=============================================  =====================================================
+``HoGParam``                                   rcr::HoGParam                 include/rcr/adaptive_vlhog.hpp:41-60
+``HogTransform``                               rcr::HogTransform             include/rcr/adaptive_vlhog.hpp:70-195
+``InterEyeDistanceNormalisation``              include/rcr/model.hpp:84-116
+``Regulariser`` / ``LinearRegressor``          include/superviseddescent/regressors.hpp:87-169, 318-400
+``SupervisedDescentOptimiser.train/test/predict``  include/superviseddescent/superviseddescent.hpp:165-344
+``detection_model.detect``                     include/rcr/model.hpp:122-183
+=============================================  =====================================================
+
+Everything numeric happens on the MI355X: HOG extraction, regressor apply, Gram/RHS build and the
+Cholesky solve are HIP kernels behind the C-ABI.  Nothing here falls back to the CPU -- without the
+built library or without a gfx950 device the constructors raise.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import SdmError, SdmHogParam, check
+
+
+@dataclass
+class HoGParam:
+    """rcr::HoGParam (include/rcr/adaptive_vlhog.hpp:41-60)."""
+
+    vlhog_variant: int
+    num_cells: int
+    cell_size: int
+    num_bins: int
+    relative_patch_size: float
+
+    @property
+    def dim(self) -> int:
+        return 3 * self.num_bins + 4 if self.vlhog_variant == 1 else 4 * self.num_bins  # hog.c:212-219
+
+    @property
+    def patch_dim(self) -> int:
+        return self.num_cells * self.num_cells * self.dim
+
+
+def _fp(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def _ip(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+
+
+class Context:
+    """Owner of one ``sdm_ctx`` (one GPU, one stream).  Thin, 1:1 with the C-ABI."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self._lib = _lib.lib()
+        self._h = self._lib.sdm_create(int(device))
+        if not self._h:
+            raise SdmError(_lib.SDM_ERR_NO_DEVICE, self._lib.sdm_last_error().decode())
+        self.device = device
+        self._keep = []  # keeps ctypes callbacks alive
+        if stream is not None:
+            check(self._lib.sdm_set_stream(self._h, ctypes.c_void_p(stream)))
+        self.L = 0
+        self.n_levels = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sdm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- geometry / inputs ---------------------------------------------------------------------
+    def set_model_geometry(self, num_landmarks: int, right_eye_idx: Sequence[int],
+                           left_eye_idx: Sequence[int], hog_params: Sequence[HoGParam]):
+        re = np.ascontiguousarray(right_eye_idx, np.int32)
+        le = np.ascontiguousarray(left_eye_idx, np.int32)
+        arr = (SdmHogParam * len(hog_params))(*[
+            SdmHogParam(p.vlhog_variant, p.num_cells, p.cell_size, p.num_bins, p.relative_patch_size)
+            for p in hog_params])
+        check(self._lib.sdm_set_model_geometry(self._h, num_landmarks, _ip(re), re.size, _ip(le), le.size,
+                                               len(hog_params), arr))
+        self.L, self.n_levels = num_landmarks, len(hog_params)
+
+    def feature_dim(self, level: int) -> int:
+        return check(self._lib.sdm_feature_dim(self._h, level))
+
+    def upload_images(self, images):
+        """``images``: list of 2-D uint8 arrays (or one [n,H,W] stack)."""
+        imgs = [np.ascontiguousarray(im, np.uint8) for im in images]
+        for im in imgs:
+            if im.ndim != 2:
+                raise ValueError("images must be single-channel (H x W) uint8")
+        n = len(imgs)
+        ptrs = (ctypes.c_void_p * n)(*[im.ctypes.data for im in imgs])
+        w = np.array([im.shape[1] for im in imgs], np.int32)
+        h = np.array([im.shape[0] for im in imgs], np.int32)
+        s = np.array([im.strides[0] for im in imgs], np.int32)
+        check(self._lib.sdm_upload_images_u8(self._h, ptrs, _ip(w), _ip(h), _ip(s), n))
+
+    def set_images_device(self, dev_ptr: int, n_images: int, width: int, height: int, stride: int):
+        check(self._lib.sdm_set_images_device(self._h, ctypes.c_void_p(dev_ptr), n_images, width, height, stride))
+
+    def set_sample_image_index(self, idx: Optional[np.ndarray]):
+        if idx is None:
+            check(self._lib.sdm_set_sample_image_index(self._h, None, 0))
+        else:
+            a = np.ascontiguousarray(idx, np.int32)
+            check(self._lib.sdm_set_sample_image_index(self._h, _ip(a), a.size))
+
+    def set_x(self, x: np.ndarray):
+        x = np.ascontiguousarray(x, np.float32)
+        if x.ndim != 2 or x.shape[1] != 2 * self.L:
+            raise ValueError("x must be N x 2L")
+        check(self._lib.sdm_set_x(self._h, _fp(x), x.shape[0]))
+        self.N = x.shape[0]
+
+    def set_x_device(self, dev_ptr: int, n: int):
+        check(self._lib.sdm_set_x_device(self._h, ctypes.c_void_p(dev_ptr), n))
+        self.N = n
+
+    def get_x(self) -> np.ndarray:
+        out = np.empty((self.N, 2 * self.L), np.float32)
+        check(self._lib.sdm_get_x(self._h, _fp(out)))
+        return out
+
+    # -- cascade steps ---------------------------------------------------------------------------
+    def hog_features(self, level: int, fetch: bool = False) -> Optional[np.ndarray]:
+        if fetch:
+            out = np.empty((self.N, self.feature_dim(level)), np.float32)
+            check(self._lib.sdm_hog_features(self._h, level, _fp(out)))
+            return out
+        check(self._lib.sdm_hog_features(self._h, level, None))
+        return None
+
+    def patch_indices(self) -> np.ndarray:
+        out = np.empty((self.N, 1 + 2 * self.L), np.int32)
+        check(self._lib.sdm_get_patch_indices(self._h, _ip(out)))
+        return out
+
+    def set_regressor(self, level: int, R: np.ndarray):
+        R = np.ascontiguousarray(R, np.float32)
+        if R.shape != (self.feature_dim(level), 2 * self.L):
+            raise ValueError(f"regressor must be {self.feature_dim(level)} x {2 * self.L}")
+        check(self._lib.sdm_set_regressor(self._h, level, _fp(R)))
+
+    def get_regressor(self, level: int) -> np.ndarray:
+        out = np.empty((self.feature_dim(level), 2 * self.L), np.float32)
+        check(self._lib.sdm_get_regressor(self._h, level, _fp(out)))
+        return out
+
+    def apply(self, level: int):
+        check(self._lib.sdm_apply(self._h, level))
+
+    def detect_batch(self, fetch: bool = True) -> Optional[np.ndarray]:
+        if fetch:
+            out = np.empty((self.N, 2 * self.L), np.float32)
+            check(self._lib.sdm_detect_batch(self._h, _fp(out)))
+            return out
+        check(self._lib.sdm_detect_batch(self._h, None))
+        return None
+
+    # -- training ----------------------------------------------------------------------------------
+    def set_targets(self, xstar: np.ndarray):
+        xs = np.ascontiguousarray(xstar, np.float32)
+        check(self._lib.sdm_set_targets(self._h, _fp(xs), xs.shape[0]))
+
+    def gram_rhs(self, level: int):
+        check(self._lib.sdm_gram_rhs(self._h, level))
+
+    def set_allreduce(self, fn: Optional[Callable[[int, int, int], int]], world_size: int):
+        """``fn(dev_ptr, count_f32, hip_stream) -> 0`` sums the buffer over all ranks in place."""
+        if fn is None:
+            cb = _lib.ALLREDUCE_FN()
+        else:
+            def tramp(ptr, count, stream, _user):
+                try:
+                    return int(fn(ptr, count, stream) or 0)
+                except Exception:  # never let an exception cross the C boundary
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            cb = _lib.ALLREDUCE_FN(tramp)
+        self._keep.append(cb)
+        check(self._lib.sdm_set_allreduce(self._h, cb, None, world_size))
+
+    def allreduce_gram_rhs(self):
+        check(self._lib.sdm_allreduce_gram_rhs(self._h))
+
+    def solve(self, level: int, reg_type: int, reg_param: float, regularise_last_row: bool,
+              n_train_global: int = 0, fetch: bool = True):
+        lam = ctypes.c_float(0.0)
+        R = np.empty((self.feature_dim(level), 2 * self.L), np.float32) if fetch else None
+        check(self._lib.sdm_solve(self._h, level, reg_type, reg_param, int(regularise_last_row),
+                                  n_train_global, _fp(R) if fetch else None, ctypes.byref(lam)))
+        return R, lam.value
+
+    def train_level(self, level: int, reg_type: int, reg_param: float, regularise_last_row: bool,
+                    n_train_global: int = 0):
+        check(self._lib.sdm_train_level(self._h, level, reg_type, reg_param, int(regularise_last_row),
+                                        n_train_global))
+
+    # -- misc ------------------------------------------------------------------------------------------
+    def synchronize(self):
+        check(self._lib.sdm_synchronize(self._h))
+
+    def enable_timing(self, on: bool = True):
+        check(self._lib.sdm_enable_timing(self._h, int(on)))
+
+    def get_timing(self, reset: bool = False):
+        ms = (ctypes.c_float * _lib.SDM_T_COUNT)()
+        n = (ctypes.c_int * _lib.SDM_T_COUNT)()
+        check(self._lib.sdm_get_timing(self._h, ms, n, int(reset)))
+        return {_lib.TIMING_NAMES[i]: (float(ms[i]), int(n[i])) for i in range(_lib.SDM_T_COUNT - 1)}
+
+    def gram_device_ptr(self):
+        p, c = ctypes.c_void_p(), ctypes.c_size_t()
+        check(self._lib.sdm_gram_device_ptr(self._h, ctypes.byref(p), ctypes.byref(c)))
+        return p.value, c.value
+
+    def x_device_ptr(self):
+        p, c = ctypes.c_void_p(), ctypes.c_size_t()
+        check(self._lib.sdm_x_device_ptr(self._h, ctypes.byref(p), ctypes.byref(c)))
+        return p.value, c.value
+
+    def debug_patch(self, level: int, sample: int, landmark: int, hp: HoGParam):
+        S, C, O = hp.num_cells * hp.cell_size, hp.num_cells, hp.num_bins
+        rsz = np.empty((S, S), np.uint8)
+        bins = np.empty((S, S), np.uint8)
+        hist = np.empty((2 * O, C, C), np.float32)
+        desc = np.empty(hp.patch_dim, np.float32)
+        u8 = ctypes.POINTER(ctypes.c_uint8)
+        check(self._lib.sdm_debug_patch(self._h, level, sample, landmark, rsz.ctypes.data_as(u8),
+                                        bins.ctypes.data_as(u8), _fp(hist), _fp(desc)))
+        return rsz, bins, hist, desc
+
+    def debug_gradient_table(self, level: int):
+        g = np.empty((511, 511), np.float32)
+        b = np.empty((511, 511), np.int32)
+        check(self._lib.sdm_debug_gradient_table(self._h, level, _fp(g), _ip(b)))
+        return g, b
+
+
+# --------------------------------------------------------------------------------------------------
+# Reference-shaped operator surface
+# --------------------------------------------------------------------------------------------------
+
+class Regulariser:
+    """regressors.hpp:87-169."""
+
+    class RegularisationType:
+        Manual = 0
+        MatrixNorm = 1
+
+    def __init__(self, regularisation_type: int = 0, param: float = 0.0, regularise_last_row: bool = True):
+        self.regularisation_type = regularisation_type
+        self.param = float(param)
+        self.regularise_last_row = bool(regularise_last_row)
+
+
+class LinearRegressor:
+    """regressors.hpp:318-400.  ``x`` is the learned F x M matrix (public, as in the reference)."""
+
+    def __init__(self, regulariser: Optional[Regulariser] = None):
+        self.x: Optional[np.ndarray] = None
+        self.regulariser = regulariser or Regulariser()
+        self.last_lambda: Optional[float] = None
+
+
+class InterEyeDistanceNormalisation:
+    """model.hpp:84-116 (string ids resolved to positions once instead of per call)."""
+
+    def __init__(self, model_landmarks: Sequence[str], right_eye_ids: Sequence[str], left_eye_ids: Sequence[str]):
+        ids = list(model_landmarks)
+        try:
+            self.right_eye = [ids.index(i) for i in right_eye_ids]
+            self.left_eye = [ids.index(i) for i in left_eye_ids]
+        except ValueError as e:  # helpers.hpp:143-145, 152-154
+            raise RuntimeError("one of given eye identifiers not present in lms") from e
+        self.model_landmarks = ids
+
+
+class HogTransform:
+    """rcr::HogTransform (adaptive_vlhog.hpp:70-195): holds the images and per-level HoG parameters.
+
+    ``images`` is a list / stack of single-channel uint8 images; ``img_index`` maps a sample row to its
+    image (the reference's ``training_index``; perturbed copies share an image)."""
+
+    def __init__(self, images, hog_params: Sequence[HoGParam], model_landmarks: Sequence[str],
+                 right_eye_ids: Sequence[str], left_eye_ids: Sequence[str],
+                 img_index: Optional[np.ndarray] = None):
+        self.images = images
+        self.hog_params = list(hog_params)
+        self.model_landmarks = list(model_landmarks)
+        self.norm = InterEyeDistanceNormalisation(model_landmarks, right_eye_ids, left_eye_ids)
+        self.img_index = img_index
+
+
+class SupervisedDescentOptimiser:
+    """superviseddescent.hpp:85-361 for RegressorType = LinearRegressor and ProjectionFunction =
+    HogTransform: the per-level work runs as batched HIP kernels.
+
+    ``allreduce`` (optional) is ``fn(dev_ptr, count_f32, hip_stream)``; with it ``train`` is the
+    data-parallel variant: every rank holds a shard of the rows, {A^T A, A^T b} are summed over ranks
+    once per level and every rank solves the identical system (see parallel.py)."""
+
+    def __init__(self, regressors: List[LinearRegressor], normalisation: Optional[InterEyeDistanceNormalisation] = None,
+                 device: int = 0, stream: Optional[int] = None):
+        self.regressors = regressors
+        self.normalisation = normalisation
+        self.ctx = Context(device, stream)
+        self._bound = None
+
+    def _bind(self, projection: HogTransform):
+        if not isinstance(projection, HogTransform):
+            raise TypeError("the HIP engine accelerates HogTransform projections; generic projection "
+                            "functors are served by the C++ header layer (superviseddescent.hpp)")
+        if len(projection.hog_params) != len(self.regressors):
+            raise ValueError("one HoGParam per regressor level expected")  # rcr-train.cpp:448
+        norm = self.normalisation or projection.norm
+        key = (id(projection.images), tuple(projection.model_landmarks))
+        self.ctx.set_model_geometry(len(projection.model_landmarks), norm.right_eye, norm.left_eye,
+                                    projection.hog_params)
+        if self._bound != key:
+            self.ctx.upload_images(projection.images)
+            self._bound = key
+        self.ctx.set_sample_image_index(projection.img_index)
+
+    def train(self, parameters, initialisations, templates, projection: HogTransform,
+              on_training_epoch_callback: Optional[Callable[[np.ndarray], None]] = None,
+              allreduce=None, world_size: int = 1, n_train_global: int = 0):
+        if templates is not None and np.size(templates) != 0:
+            raise NotImplementedError("known-template training is served by the C++ header layer")
+        self._bind(projection)
+        c = self.ctx
+        c.set_x(np.asarray(initialisations, np.float32))
+        c.set_targets(np.asarray(parameters, np.float32))
+        c.set_allreduce(allreduce, world_size)
+        n_glob = n_train_global or c.N
+        for level, reg in enumerate(self.regressors):
+            c.hog_features(level)                                            # superviseddescent.hpp:173-189
+            c.gram_rhs(level)                                                # :199-205 + regressors.hpp:208,225
+            c.allreduce_gram_rhs()
+            r = reg.regulariser
+            reg.x, reg.last_lambda = c.solve(level, r.regularisation_type, r.param, r.regularise_last_row,
+                                             n_glob)                         # :207
+            c.apply(level)                                                   # :209-216
+            if on_training_epoch_callback is not None:
+                on_training_epoch_callback(c.get_x())                        # :217
+        return c.get_x()
+
+    def _load_regressors(self):
+        for level, reg in enumerate(self.regressors):
+            if reg.x is None:
+                raise RuntimeError("regressor level %d has not been learned" % level)
+            self.ctx.set_regressor(level, reg.x)
+
+    def test(self, initialisations, templates, projection: HogTransform,
+             on_regressor_iteration_callback: Optional[Callable[[np.ndarray], None]] = None) -> np.ndarray:
+        if templates is not None and np.size(templates) != 0:
+            raise NotImplementedError("known-template testing is served by the C++ header layer")
+        self._bind(projection)
+        self._load_regressors()
+        c = self.ctx
+        c.set_x(np.atleast_2d(np.asarray(initialisations, np.float32)))
+        if on_regressor_iteration_callback is None:
+            return c.detect_batch()                                           # :262-306
+        for level in range(len(self.regressors)):
+            c.hog_features(level)
+            c.apply(level)
+            on_regressor_iteration_callback(c.get_x())                        # :303
+        return c.get_x()
+
+    def predict(self, initialisation, templates, projection: HogTransform) -> np.ndarray:
+        return self.test(np.atleast_2d(initialisation), templates, projection)  # :323-344
+
+
+class detection_model:
+    """rcr::detection_model (model.hpp:122-183)."""
+
+    def __init__(self, optimised_model: SupervisedDescentOptimiser, mean: np.ndarray, landmark_ids: Sequence[str],
+                 hog_params: Sequence[HoGParam], right_eye_ids: Sequence[str], left_eye_ids: Sequence[str]):
+        self.optimised_model = optimised_model
+        self.mean = np.asarray(mean, np.float32).reshape(-1)
+        self.landmark_ids = list(landmark_ids)
+        self.hog_params = list(hog_params)
+        self.right_eye_ids, self.left_eye_ids = list(right_eye_ids), list(left_eye_ids)
+
+    def detect(self, image: np.ndarray, facebox_or_init) -> np.ndarray:
+        """model.hpp:132-157: one image, from a face box (x, y, w, h) or from an initial landmark row."""
+        from .synth import align_mean
+        a = np.asarray(facebox_or_init)
+        init = align_mean(self.mean, tuple(int(v) for v in a)) if a.size == 4 else a.astype(np.float32).reshape(1, -1)
+        hog = HogTransform([image], self.hog_params, self.landmark_ids, self.right_eye_ids, self.left_eye_ids)
+        return self.optimised_model.predict(np.atleast_2d(init), None, hog)[0]
+
+    def detect_batch(self, images, faceboxes: np.ndarray, img_index: Optional[np.ndarray] = None) -> np.ndarray:
+        """Batched ``detect``: row i starts from align_mean(mean, faceboxes[i]) on image img_index[i]."""
+        from .synth import align_mean
+        init = np.stack([align_mean(self.mean, tuple(int(v) for v in b)) for b in np.asarray(faceboxes)])
+        hog = HogTransform(images, self.hog_params, self.landmark_ids, self.right_eye_ids, self.left_eye_ids,
+                           img_index)
+        return self.optimised_model.test(init, None, hog)
+
+    def get_mean(self) -> np.ndarray:
+        return self.mean
