@@ -178,6 +178,44 @@ void orc_resize_u8_linear(const uint8_t *src, int sw, int sh, int sstride,
     }
 }
 
+/* One pixel: gradient (gx, gy) -> magnitude and hard-assigned directed orientation bin
+ * (hog.c:637-672 for a single channel; bin = -1 when no orientation scores > 0). */
+static void orc_gradient_bin(float gx, float gy, int O, const float *ox, const float *oy,
+                             float *g_out, int *bin_out)
+{
+    float g2 = gx * gx + gy * gy;
+    float g, best = 0.0f;
+    int bin = -1, k;
+    double den;
+    if (!(g2 > 0.0f)) { gx = 0.0f; gy = 0.0f; g2 = 0.0f; } /* hog.c:638-642 */
+    g = sqrtf(g2);                         /* hog.c:645 */
+    den = (double)g > 1e-10 ? (double)g : 1e-10;
+    gx = (float)((double)gx / den);        /* hog.c:646-647: float /= double */
+    gy = (float)((double)gy / den);
+    for (k = 0; k < O; ++k) {              /* hog.c:656-672 */
+        float s = gx * ox[k] + gy * oy[k];
+        int b = k;
+        if (s < 0) { s = -s; b += O; }
+        if (s > best) { best = s; bin = b; }
+    }
+    *g_out = g;
+    *bin_out = bin;
+}
+
+/* (g, bin) for every integer gradient in [-255,255]^2, row = gy+255, col = gx+255 */
+void orc_gradient_table(int O, float *g_out, int *bin_out)
+{
+    float ox[64], oy[64];
+    int k, i;
+    for (k = 0; k < O; ++k) {
+        double angle = k * ORC_PI / O;
+        ox[k] = (float)cos(angle);
+        oy[k] = (float)sin(angle);
+    }
+    for (i = 0; i < 511 * 511; ++i)
+        orc_gradient_bin((float)(i % 511 - 255), (float)(i / 511 - 255), O, ox, oy, &g_out[i], &bin_out[i]);
+}
+
 /* ------------------------------------------------------------------------------------
  * VLFeat HOG restated: put_image (hog.c:595-728) + extract (hog.c:857-1062),
  * single channel, non-transposed, hard orientation assignment (hog.c:185, 679-682).
@@ -215,25 +253,12 @@ int orc_hog(const float *img, int width, int height, int cell, int O, int varian
             const float *p = img + (size_t)y * width + x;
             float gx = p[1] - p[-1];               /* hog.c:635-636 */
             float gy = p[width] - p[-width];
-            float g2 = gx * gx + gy * gy;
-            float g, best = 0.0f;
-            int bin = -1;
+            float g;
+            int bin;
             float hx, hy, wx1, wx2, wy1, wy2;
             long bx, by;
-            double den;
 
-            if (!(g2 > 0.0f)) { gx = 0.0f; gy = 0.0f; g2 = 0.0f; } /* hog.c:638-642 */
-            g = sqrtf(g2);                         /* hog.c:645 */
-            den = (double)g > 1e-10 ? (double)g : 1e-10;
-            gx = (float)((double)gx / den);        /* hog.c:646-647: float /= double */
-            gy = (float)((double)gy / den);
-
-            for (k = 0; k < O; ++k) {              /* hog.c:656-672 */
-                float s = gx * ox[k] + gy * oy[k];
-                int b = k;
-                if (s < 0) { s = -s; b += O; }
-                if (s > best) { best = s; bin = b; }
-            }
+            orc_gradient_bin(gx, gy, O, ox, oy, &g, &bin);
             if (bin < 0) continue;                 /* hog.c:694: no orientation selected */
             if (bins_out) bins_out[(size_t)y * width + x] = (uint8_t)bin;
 

@@ -190,6 +190,14 @@ def ref_hog(img: np.ndarray, cell: int, O: int, variant: int = VARIANT_UOCTTI) -
     return feat
 
 
+def gradient_table(O: int):
+    """(g, bin) of every integer gradient (gx, gy) in [-255,255]^2 ([gy+255][gx+255]), hog.c:637-672."""
+    g = np.empty((511, 511), np.float32)
+    b = np.empty((511, 511), np.int32)
+    lib().orc_gradient_table(int(O), _p(g), _p(b, ctypes.c_int))
+    return g, b
+
+
 def feature_dim(L: int, hp: HoGParam) -> int:
     return L * hp.patch_dim + 1
 
@@ -258,8 +266,37 @@ def partial_piv_lu_solve(data: np.ndarray, labels: np.ndarray, regulariser: Regu
         diag[-1] = 0.0                                       # :143-146
     AtA[np.diag_indices_from(AtA)] += diag                   # :215-221
     Atb = (A.T @ b).astype(np.float32)
+    if AtA.shape[0] <= 32:
+        return _unblocked_lu_solve_f32(AtA, Atb)             # :224-225, Eigen's small-matrix path
     lu, piv = lu_factor(AtA, check_finite=False)             # :224 (sgetrf: partial pivoting)
     return np.ascontiguousarray(lu_solve((lu, piv), Atb, check_finite=False), dtype=np.float32)  # :225
+
+
+def _unblocked_lu_solve_f32(A: np.ndarray, B: np.ndarray) -> np.ndarray:
+    """Eigen::PartialPivLU's unblocked kernel restated in strict float32: per column pick the largest
+    |pivot|, swap rows, scale the sub-column, rank-1 update the trailing block; then unit-lower forward
+    and upper backward substitution.  (For the tiny systems of the reference's gtest goldens LAPACK's
+    blocked/recursive sgetrf rounds differently in the last digit.)"""
+    f32 = np.float32
+    A = A.astype(f32).copy()
+    B = B.astype(f32).copy()
+    n = A.shape[0]
+    for k in range(n):
+        p = k + int(np.argmax(np.abs(A[k:, k])))
+        if p != k:
+            A[[k, p]] = A[[p, k]]
+            B[[k, p]] = B[[p, k]]
+        if k < n - 1:
+            A[k + 1:, k] = (A[k + 1:, k] / A[k, k]).astype(f32)
+            A[k + 1:, k + 1:] = (A[k + 1:, k + 1:] - np.outer(A[k + 1:, k], A[k, k + 1:]).astype(f32)).astype(f32)
+    for i in range(n):
+        for j in range(i):
+            B[i] = (B[i] - (A[i, j] * B[j]).astype(f32)).astype(f32)
+    for i in range(n - 1, -1, -1):
+        for j in range(i + 1, n):
+            B[i] = (B[i] - (A[i, j] * B[j]).astype(f32)).astype(f32)
+        B[i] = (B[i] / A[i, i]).astype(f32)
+    return np.ascontiguousarray(B, dtype=f32)
 
 
 class LinearRegressor:

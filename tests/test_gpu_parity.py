@@ -1,0 +1,330 @@
+"""Parity tests proper: the HIP path (through the C-ABI) against the CPU oracle on identical inputs.
+Integer / byte results (patch geometry, resized ROI bytes, orientation bins) and the HOG features are
+compared BIT-EXACTLY; the MFMA GEMM results (apply, Gram, solve) within the stated tolerances; the
+free-running landmark predictions within 1e-4 relative L2 (BASELINE.json north_star)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import sdm_oracle as orc
+from superviseddescent_amd import (Context, HoGParam, HogTransform, LinearRegressor, Regulariser, SdmError,
+                                   SupervisedDescentOptimiser, detection_model, ibug, synth)
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "hog_ref_vectors.npz"))
+IDS = ibug.RCR22_IDS
+RE, LE = ibug.eye_indices(IDS)
+SHIPPED = [HoGParam(*p) for p in ibug.SHIPPED_HOG_PARAMS]
+O_SHIPPED = [orc.HoGParam(*p) for p in ibug.SHIPPED_HOG_PARAMS]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def rel_l2(a, b):
+    return float(np.linalg.norm((a - b).astype(np.float64)) / np.linalg.norm(b.astype(np.float64)))
+
+
+@pytest.fixture(scope="module")
+def faces():
+    images, boxes, gt = synth.make_faces(192, seed=2024)
+    x_star, x0, idx = synth.make_samples(boxes, gt, IDS, n_perturb=0, seed=2025)
+    return images, boxes, gt, x_star, x0
+
+
+# ------------------------------------------------------------------------------------------ HOG
+@pytest.mark.parametrize("level", [0, 1, 2, 3])
+def test_gradient_table_exhaustive(gpu_ctx, level):
+    """sqrt / divide / orientation arg-max for every possible u8 central difference pair."""
+    p = [HoGParam(1, 5, 6, 4, 1.0), HoGParam(1, 5, 6, 9, 1.0), HoGParam(0, 5, 6, 6, 1.0), HoGParam(1, 5, 6, 16, 1.0)]
+    gpu_ctx.set_model_geometry(22, RE, LE, p)
+    g, b = gpu_ctx.debug_gradient_table(level)
+    og, ob = orc.gradient_table(p[level].num_bins)
+    assert np.array_equal(bits(g), bits(og))
+    assert np.array_equal(b, ob)
+
+
+def test_golden_rows_bitwise(gpu_ctx):
+    """Committed vectors (reference hog.c + documented glue): Dalal-Triggs, 9 orientations, the exact-2x
+    area path, patches poking outside the image, cvRound ties."""
+    re, le = [int(GOLD["tr_eyes"][0])], [int(GOLD["tr_eyes"][1])]
+    params = [HoGParam(int(v), int(C), int(c), int(O), float(r))
+              for (v, C, c, O), r in zip(GOLD["tr_params"], GOLD["tr_rel"])]
+    gpu_ctx.set_model_geometry(5, re, le, params)
+    gpu_ctx.upload_images(GOLD["tr_images"])
+    gpu_ctx.set_sample_image_index(None)
+    gpu_ctx.set_x(GOLD["tr_x"])
+    for li in range(len(params)):
+        feat = gpu_ctx.hog_features(li, fetch=True)
+        assert np.array_equal(gpu_ctx.patch_indices(), GOLD[f"tr_idx_{li}"])
+        assert np.array_equal(bits(feat), bits(GOLD[f"tr_feat_{li}"])), li
+
+
+def test_patch_intermediates_bitwise(gpu_ctx, faces):
+    images, _, _, _, x0 = faces
+    gpu_ctx.set_model_geometry(len(IDS), RE, LE, SHIPPED)
+    gpu_ctx.upload_images(images)
+    gpu_ctx.set_sample_image_index(None)
+    gpu_ctx.set_x(x0)
+    L = len(IDS)
+    for (lvl, s, lm) in [(0, 0, 0), (0, 5, 21), (1, 17, 9), (2, 33, 4), (3, 100, 13), (0, 191, 7)]:
+        hp = SHIPPED[lvl]
+        rsz, dbins, hist, desc = gpu_ctx.debug_patch(lvl, s, lm, hp)
+        ied = orc.get_ied(x0[s], RE, LE)
+        h = int(np.floor(np.float64(np.float32(hp.relative_patch_size)) * ied / 2 + 0.5))
+        cx, cy = orc.cv_round(x0[s, lm]), orc.cv_round(x0[s, lm + L])
+        roi = np.zeros((2 * h, 2 * h), np.uint8)
+        ys, xs = np.mgrid[cy - h:cy + h, cx - h:cx + h]
+        ok = (ys >= 0) & (ys < 256) & (xs >= 0) & (xs < 256)
+        roi[ok] = images[s][ys[ok], xs[ok]]
+        S = hp.num_cells * hp.cell_size
+        orsz = orc.resize_u8_linear(roi, S, S)
+        ofeat, ohist, obins = orc.hog(orsz.astype(np.float32), hp.cell_size, hp.num_bins, hp.vlhog_variant, True, True)
+        assert np.array_equal(rsz, orsz)                       # bytes
+        assert np.array_equal(dbins, obins)                    # orientation bin indices
+        assert np.array_equal(bits(hist), bits(ohist))         # accumulation order = raster order
+        assert np.array_equal(bits(desc), bits(ofeat.transpose(0, 2, 1).reshape(-1)))
+
+
+@pytest.mark.parametrize("level", [0, 1, 2, 3])
+def test_rcr22_features_bitwise(gpu_ctx, faces, level):
+    images, _, _, _, x0 = faces
+    gpu_ctx.set_model_geometry(len(IDS), RE, LE, SHIPPED)
+    gpu_ctx.upload_images(images)
+    gpu_ctx.set_sample_image_index(None)
+    gpu_ctx.set_x(x0)
+    feat = gpu_ctx.hog_features(level, fetch=True)
+    ofeat, oidx = orc.hog_features_batch(images, None, x0, RE, LE, O_SHIPPED[level], n_threads=os.cpu_count() or 1,
+                                         want_idx=True)
+    assert np.array_equal(gpu_ctx.patch_indices(), oidx)
+    assert np.array_equal(bits(feat), bits(ofeat))
+
+
+def test_baseline31_variant_and_image_index(gpu_ctx, faces):
+    """'31-bin VlHog' (9 orientations) + perturbed rows sharing images + ragged batch size."""
+    images, boxes, gt, _, _ = faces
+    x_star, x0, idx = synth.make_samples(boxes[:37], gt[:37], IDS, n_perturb=2, seed=77)   # N = 111
+    params = [HoGParam(*p) for p in ibug.BASELINE31_HOG_PARAMS]
+    gpu_ctx.set_model_geometry(len(IDS), RE, LE, params)
+    gpu_ctx.upload_images(images[:37])
+    gpu_ctx.set_sample_image_index(idx)
+    gpu_ctx.set_x(x0)
+    for level in (0, 4):
+        feat = gpu_ctx.hog_features(level, fetch=True)
+        ofeat = orc.hog_features_batch(images[:37], idx, x0, RE, LE, orc.HoGParam(*ibug.BASELINE31_HOG_PARAMS[level]),
+                                       n_threads=os.cpu_count() or 1)
+        assert feat.shape[1] == 22 * 25 * 31 + 1
+        assert np.array_equal(bits(feat), bits(ofeat))
+
+
+def test_ragged_images(gpu_ctx):
+    rng = np.random.default_rng(9)
+    imgs = [rng.integers(0, 256, (h, w)).astype(np.uint8) for (h, w) in [(120, 90), (64, 200), (181, 181)]]
+    x = np.array([[30, 50, 60, 45, 40, 42, 70, 60], [20, 90, 150, 100, 30, 28, 50, 40], [60, 100, 140, 100, 80, 82, 120, 150]],
+                 np.float32)   # L = 4, eyes 0 and 2
+    p = HoGParam(1, 4, 5, 4, 0.8)
+    gpu_ctx.set_model_geometry(4, [0], [2], [p])
+    gpu_ctx.upload_images(imgs)
+    gpu_ctx.set_sample_image_index(None)
+    gpu_ctx.set_x(x)
+    feat = gpu_ctx.hog_features(0, fetch=True)
+    L = orc.lib()
+    for i in range(3):
+        of = orc.hog_features_batch(imgs[i][None], None, x[i:i + 1], [0], [2], orc.HoGParam(1, 4, 5, 4, 0.8))
+        assert np.array_equal(bits(feat[i:i + 1]), bits(of))
+
+
+def test_empty_patch_reports_error(gpu_ctx, faces):
+    images, _, _, _, x0 = faces
+    gpu_ctx.set_model_geometry(len(IDS), RE, LE, [HoGParam(1, 5, 6, 4, 0.001)])
+    gpu_ctx.upload_images(images[:8])
+    gpu_ctx.set_sample_image_index(None)
+    gpu_ctx.set_x(x0[:8])
+    with pytest.raises(SdmError) as e:
+        gpu_ctx.hog_features(0, fetch=True)
+    assert e.value.code == -4
+
+
+# ------------------------------------------------------------------------------------------ apply
+@pytest.mark.parametrize("n", [1, 33, 192])
+def test_apply_update(gpu_ctx, faces, n):
+    images, _, _, _, x0 = faces
+    gpu_ctx.set_model_geometry(len(IDS), RE, LE, SHIPPED)
+    gpu_ctx.upload_images(images)
+    gpu_ctx.set_sample_image_index(None)
+    gpu_ctx.set_x(x0[:n])
+    feat = gpu_ctx.hog_features(0, fetch=True)
+    rng = np.random.default_rng(n)
+    R = (rng.standard_normal((feat.shape[1], 44)) * 0.01).astype(np.float32)
+    gpu_ctx.set_regressor(0, R)
+    assert np.array_equal(gpu_ctx.get_regressor(0), R)
+    gpu_ctx.apply(0)
+    x1 = gpu_ctx.get_x()
+    u = (feat.astype(np.float64) @ R.astype(np.float64)).astype(np.float32)
+    norm = orc.InterEyeDistanceNormalisation(RE, LE)(x0[:n])
+    ref = (x0[:n] - u * (np.float32(1.0) / norm)).astype(np.float32)
+    assert rel_l2(x1, ref) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------ train / detect
+def small_params():
+    # RCR-22 landmarks with 3x3 cells: F = 22*9*16+1 = 3169, so that the oracle's LAPACK LU stays cheap
+    return [(1, 3, 12, 4, 0.9), (1, 3, 9, 4, 0.6), (1, 3, 7, 4, 0.35)]
+
+
+def run_oracle_train(images, idx, x_star, x0, params, reg):
+    ohog = orc.HogTransform(images, [orc.HoGParam(*p) for p in params], RE, LE, idx, n_threads=os.cpu_count() or 1)
+    osdo = orc.SupervisedDescentOptimiser([orc.LinearRegressor(orc.Regulariser(*reg)) for _ in params],
+                                          orc.InterEyeDistanceNormalisation(RE, LE))
+    per_level = []
+    x = osdo.train(x_star, x0, None, ohog, callback=lambda cur: per_level.append(cur.copy()))
+    return osdo, ohog, x, per_level
+
+
+@pytest.mark.parametrize("reg", [(1, 1.5, False), (0, 1.0, True), (1, 0.5, True)])
+def test_train_cascade_matches_oracle(faces, reg):
+    """SupervisedDescentOptimiser::train on the GPU vs the oracle (LU): per-level landmarks and the
+    learned regressors' predictions."""
+    images, boxes, gt, _, _ = faces
+    x_star, x0, idx = synth.make_samples(boxes[:160], gt[:160], IDS, n_perturb=3, seed=5)   # N = 640
+    params = small_params()
+    sdo = SupervisedDescentOptimiser([LinearRegressor(Regulariser(*reg)) for _ in params])
+    hog = HogTransform(images[:160], [HoGParam(*p) for p in params], IDS, ibug.RIGHT_EYE_IDS, ibug.LEFT_EYE_IDS, idx)
+    seen = []
+    x_gpu = sdo.train(x_star, x0, None, hog, on_training_epoch_callback=lambda cur: seen.append(cur.copy()))
+    osdo, ohog, x_orc, oseen = run_oracle_train(images[:160], idx, x_star, x0, params, reg)
+    assert len(seen) == len(params)
+    for lvl in range(len(params)):
+        assert rel_l2(seen[lvl], oseen[lvl]) < 1e-4, lvl
+    assert rel_l2(x_gpu, x_orc) < 1e-4
+    if reg[0] == 1:   # MatrixNorm lambda from ||A^T A||_F of the first level
+        A = ohog(x0, 0)
+        lam = orc.Regulariser(*reg).get_lambda((A.T @ A).astype(np.float32), A.shape[0])
+        assert sdo.regressors[0].last_lambda == pytest.approx(float(lam), rel=2e-5)
+    # the cascade must actually reduce the error on the training set
+    e0, e1 = rel_l2(x0, x_star), rel_l2(x_gpu, x_star)
+    assert e1 < 0.7 * e0
+    # held-out detection with the GPU-trained model: GPU vs oracle running the same regressors
+    xs2, x02, idx2 = synth.make_samples(boxes[160:], gt[160:], IDS, n_perturb=1, seed=6)
+    hog2 = HogTransform(images[160:], [HoGParam(*p) for p in params], IDS, ibug.RIGHT_EYE_IDS, ibug.LEFT_EYE_IDS, idx2)
+    pred = sdo.test(x02, None, hog2)
+    for lvl, r in enumerate(sdo.regressors):
+        osdo.regressors[lvl].x = r.x
+    ohog2 = orc.HogTransform(images[160:], [orc.HoGParam(*p) for p in params], RE, LE, idx2, n_threads=os.cpu_count() or 1)
+    opred = osdo.test(x02, None, ohog2)
+    assert rel_l2(pred, opred) < 1e-4
+
+
+def test_detect_rcr22_free_running_and_teacher_forced(gpu_ctx, faces):
+    """Config 'RCR-22 detect' with an oracle-supplied model: free-running landmarks within 1e-4, and with
+    the oracle's x_k fed to level k (teacher forcing) the integer patch decisions are identical."""
+    images, boxes, gt, x_star, x0 = faces
+    rng = np.random.default_rng(42)
+    F = 22 * 400 + 1
+    Rs = [(rng.standard_normal((F, 44)) * (0.004 / (l + 1))).astype(np.float32) for l in range(4)]
+    gpu_ctx.set_model_geometry(len(IDS), RE, LE, SHIPPED)
+    gpu_ctx.upload_images(images)
+    gpu_ctx.set_sample_image_index(None)
+    for l in range(4):
+        gpu_ctx.set_regressor(l, Rs[l])
+    gpu_ctx.set_x(x0)
+    x_gpu = gpu_ctx.detect_batch()
+    ohog = orc.HogTransform(images, O_SHIPPED, RE, LE, None, n_threads=os.cpu_count() or 1)
+    regs = []
+    for l in range(4):
+        r = orc.LinearRegressor(); r.x = Rs[l]; regs.append(r)
+    osdo = orc.SupervisedDescentOptimiser(regs, orc.InterEyeDistanceNormalisation(RE, LE))
+    xs = [x0.copy()]
+    x_orc = osdo.test(x0, None, ohog, callback=lambda cur: xs.append(cur.copy()))
+    assert rel_l2(x_gpu, x_orc) < 1e-4
+    for l in range(4):   # teacher forced
+        gpu_ctx.set_x(xs[l])
+        gpu_ctx.hog_features(l)
+        _, oidx = orc.hog_features_batch(images, None, xs[l], RE, LE, O_SHIPPED[l], n_threads=os.cpu_count() or 1, want_idx=True)
+        assert np.array_equal(gpu_ctx.patch_indices(), oidx)
+        gpu_ctx.apply(l)
+        assert rel_l2(gpu_ctx.get_x(), xs[l + 1]) < 1e-5
+
+
+def test_detection_model_detect_single_image(faces):
+    """rcr::detection_model::detect(image, facebox): the single-sample path goes through the same kernels."""
+    images, boxes, gt, _, _ = faces
+    rng = np.random.default_rng(1)
+    params = [HoGParam(*p) for p in ibug.SHIPPED_HOG_PARAMS[:2]]
+    regs = []
+    for l in range(2):
+        r = LinearRegressor(); r.x = (rng.standard_normal((8801, 44)) * 0.003).astype(np.float32); regs.append(r)
+    model = detection_model(SupervisedDescentOptimiser(regs), ibug.select_mean(IDS), IDS, params,
+                            ibug.RIGHT_EYE_IDS, ibug.LEFT_EYE_IDS)
+    lm = model.detect(images[3], boxes[3])
+    oregs = []
+    for l in range(2):
+        r = orc.LinearRegressor(); r.x = regs[l].x; oregs.append(r)
+    osdo = orc.SupervisedDescentOptimiser(oregs, orc.InterEyeDistanceNormalisation(RE, LE))
+    ohog = orc.HogTransform(images[3:4], O_SHIPPED[:2], RE, LE)
+    ref = osdo.predict(orc.align_mean(ibug.select_mean(IDS), boxes[3]), None, ohog)[0]
+    assert rel_l2(lm, ref) < 1e-4
+    both = model.detect_batch(images[:6], boxes[:6])
+    assert rel_l2(both[3], ref) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------ properties at full size
+def test_full_batch_properties():
+    """BASELINE batch (4096 faces): determinism, sample-order invariance, bias column, NaN-free."""
+    n = 4096
+    images, boxes, gt = synth.make_faces(n, seed=31337)
+    _, x0, _ = synth.make_samples(boxes, gt, IDS, 0, seed=31338)
+    ctx = Context(0)
+    ctx.set_model_geometry(len(IDS), RE, LE, SHIPPED)
+    ctx.upload_images(images)
+    rng = np.random.default_rng(0)
+    for l in range(4):
+        ctx.set_regressor(l, (rng.standard_normal((8801, 44)) * 0.002).astype(np.float32))
+    ctx.set_sample_image_index(None)
+    ctx.set_x(x0)
+    a = ctx.detect_batch()
+    ctx.set_x(x0)
+    b = ctx.detect_batch()
+    assert np.array_equal(bits(a), bits(b))                      # run-to-run deterministic
+    assert np.isfinite(a).all()
+    perm = rng.permutation(n).astype(np.int32)
+    ctx.set_sample_image_index(perm)
+    ctx.set_x(x0[perm])
+    c = ctx.detect_batch()
+    assert np.array_equal(bits(c), bits(a[perm]))                # independent of the row order
+    ctx.set_sample_image_index(None)
+    ctx.set_x(x0)
+    f = ctx.hog_features(3, fetch=True)
+    assert np.all(f[:, -1] == 1.0) and np.isfinite(f).all() and f.min() >= 0.0
+    # spot-check 64 random rows of the big batch against the oracle, bit for bit
+    rows = np.sort(rng.choice(n, 64, replace=False))
+    of = orc.hog_features_batch(images, rows.astype(np.int32), x0[rows], RE, LE, O_SHIPPED[3], n_threads=os.cpu_count() or 1)
+    assert np.array_equal(bits(f[rows]), bits(of))
+    ctx.close()
+
+
+def test_rcr68_shapes(faces):
+    """RCR-68 geometry (M = 136, F = 27201): features bit-exact, apply + Gram tile paths for 9 column tiles."""
+    images, boxes, gt, _, _ = faces
+    ids = ibug.IBUG68_IDS
+    re, le = ibug.eye_indices(ids)
+    xs, x0, idx = synth.make_samples(boxes[:24], gt[:24], ids, 0, seed=8)
+    ctx = Context(0)
+    ctx.set_model_geometry(68, re, le, SHIPPED[2:4])
+    ctx.upload_images(images[:24])
+    ctx.set_sample_image_index(None)
+    ctx.set_x(x0)
+    f = ctx.hog_features(0, fetch=True)
+    of = orc.hog_features_batch(images[:24], None, x0, re, le, O_SHIPPED[2], n_threads=os.cpu_count() or 1)
+    assert f.shape == (24, 27201) and np.array_equal(bits(f), bits(of))
+    rng = np.random.default_rng(3)
+    R = (rng.standard_normal((27201, 136)) * 0.002).astype(np.float32)
+    ctx.set_regressor(0, R)
+    ctx.apply(0)
+    u = (f.astype(np.float64) @ R.astype(np.float64)).astype(np.float32)
+    ref = (x0 - u * (np.float32(1.0) / orc.InterEyeDistanceNormalisation(re, le)(x0))).astype(np.float32)
+    assert rel_l2(ctx.get_x(), ref) < 1e-6
+    ctx.close()
