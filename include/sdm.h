@@ -83,6 +83,20 @@ int sdm_set_model_geometry(sdm_ctx* ctx, int num_landmarks, const int* right_eye
                            const int* left_eye_idx, int n_left, int n_levels, const sdm_hog_param* levels);
 int sdm_feature_dim(const sdm_ctx* ctx, int level);          /* F of that level, or negative */
 
+/* HOG accumulation mode.  Both modes take identical integer decisions (ROI geometry, resized bytes,
+ * orientation bins) as the reference; they differ only in how the f32 contributions of one histogram cell
+ * are summed:
+ *   SDM_HOG_EXACT_ORDER  in the reference's raster order (hog.c:616-617,713-724) -> features bit-identical
+ *                        to the reference's CPU path; slow (LDS float atomics retire one lane per 3 cycles)
+ *   SDM_HOG_FAST         (default) exact fixed-point sum, rounded to f32 once -> order independent,
+ *                        deterministic, within a few ulp of the reference's sequentially rounded sum */
+#define SDM_HOG_EXACT_ORDER 0
+#define SDM_HOG_FAST 1
+int sdm_set_hog_mode(sdm_ctx* ctx, int mode);
+/* Which kernel a level runs: *fast_kernel = 1 when the fused S<=64 kernel is used, *fast_bins = 1 when the
+ * un-normalised orientation arg-max was verified exhaustively (511x511 gradients) for that level. */
+int sdm_get_hog_info(sdm_ctx* ctx, int level, int* fast_kernel, int* fast_bins);
+
 /* Images: the `const std::vector<cv::Mat>& images` of HogTransform (adaptive_vlhog.hpp:92,188),
  * single channel u8.  Host images are copied to HBM once. */
 int sdm_upload_images_u8(sdm_ctx* ctx, const uint8_t* const* images, const int* width, const int* height,
@@ -148,6 +162,9 @@ int sdm_get_timing(sdm_ctx* ctx, float* ms /* [SDM_T_COUNT] */, int* launches /*
 /* Test hooks (used by tests/ to check intermediate integer/byte results bit-exactly). */
 int sdm_debug_patch(sdm_ctx* ctx, int level, int sample, int landmark, uint8_t* resized_SxS,
                     uint8_t* bins_SxS, float* hist_2OxCxC, float* desc_P);
+/* Instrumented HOG launch (O=4, C=5 geometry only): per-phase shader cycles summed over all waves:
+ * [0] geometry/tables [1] histogram clear [2] row loop [3] barrier [4] normalisation [5] output stores, [7] waves. */
+int sdm_debug_hog_profile(sdm_ctx* ctx, int level, unsigned long long* out8);
 int sdm_debug_gradient_table(sdm_ctx* ctx, int level, float* g_511x511, int* bin_511x511);
 
 #ifdef __cplusplus

@@ -16,17 +16,18 @@ SDM_ERR_INVALID, SDM_ERR_NO_DEVICE, SDM_ERR_HIP, SDM_ERR_EMPTY_PATCH, SDM_ERR_NO
     -1, -2, -3, -4, -5, -6
 SDM_T_HOG, SDM_T_APPLY, SDM_T_GRAM, SDM_T_REG, SDM_T_FACTOR, SDM_T_BACKSOLVE, SDM_T_ALLREDUCE = range(7)
 SDM_T_COUNT = 8
+SDM_HOG_EXACT_ORDER, SDM_HOG_FAST = 0, 1
 TIMING_NAMES = ["hog", "apply", "gram", "reg", "factor_solve", "backsolve", "allreduce", "_"]
 
 # every symbol include/sdm.h declares (checked by tests/test_capi_symbols.py without a GPU)
 EXPORTED = [
     "sdm_last_error", "sdm_device_count", "sdm_create", "sdm_destroy", "sdm_set_stream", "sdm_synchronize",
-    "sdm_set_model_geometry", "sdm_feature_dim", "sdm_upload_images_u8", "sdm_set_images_device",
+    "sdm_set_model_geometry", "sdm_set_hog_mode", "sdm_get_hog_info", "sdm_feature_dim", "sdm_upload_images_u8", "sdm_set_images_device",
     "sdm_set_sample_image_index", "sdm_set_x", "sdm_get_x", "sdm_set_x_device", "sdm_get_x_device",
     "sdm_hog_features", "sdm_get_patch_indices", "sdm_set_regressor", "sdm_get_regressor", "sdm_apply",
     "sdm_detect_batch", "sdm_set_targets", "sdm_gram_rhs", "sdm_set_allreduce", "sdm_allreduce_gram_rhs",
     "sdm_solve", "sdm_train_level", "sdm_gram_device_ptr", "sdm_x_device_ptr", "sdm_features_device_ptr",
-    "sdm_enable_timing", "sdm_get_timing", "sdm_debug_patch", "sdm_debug_gradient_table",
+    "sdm_enable_timing", "sdm_get_timing", "sdm_debug_patch", "sdm_debug_hog_profile", "sdm_debug_gradient_table",
 ]
 
 
@@ -72,6 +73,8 @@ def lib() -> ctypes.CDLL:
             "sdm_set_model_geometry": [c_void_p, c_int, c_int_p, c_int, c_int_p, c_int, c_int,
                                        ctypes.POINTER(SdmHogParam)],
             "sdm_feature_dim": [c_void_p, c_int],
+            "sdm_set_hog_mode": [c_void_p, c_int],
+            "sdm_get_hog_info": [c_void_p, c_int, c_int_p, c_int_p],
             "sdm_upload_images_u8": [c_void_p, ctypes.POINTER(c_void_p), c_int_p, c_int_p, c_int_p, c_int],
             "sdm_set_images_device": [c_void_p, c_void_p, c_int, c_int, c_int, c_int],
             "sdm_set_sample_image_index": [c_void_p, c_int_p, c_int],
@@ -99,6 +102,7 @@ def lib() -> ctypes.CDLL:
             "sdm_debug_patch": [c_void_p, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_uint8),
                                 ctypes.POINTER(ctypes.c_uint8), c_float_p, c_float_p],
             "sdm_debug_gradient_table": [c_void_p, c_int, c_float_p, c_int_p],
+            "sdm_debug_hog_profile": [c_void_p, c_int, ctypes.POINTER(ctypes.c_ulonglong)],
         }
         for name, args in sigs.items():
             fn = getattr(L, name)

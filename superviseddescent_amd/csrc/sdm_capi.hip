@@ -66,6 +66,9 @@ struct sdm_ctx {
     EyeIdxDev eyes{};
     std::vector<HogLevelDev> levels;
     std::vector<sdm_hog_param> params;
+    std::vector<int> fast_kernel;   // per level: fused S<=64 kernel usable
+    std::vector<int> fast_bins;     // per level: un-normalised arg-max verified on all 511x511 gradients
+    int hog_mode = SDM_HOG_FAST;
     int Fmax = 0;
     long long ldf = 0;      // feature row stride: round_up(Fmax,128) + 128 (tail tile = training targets)
 
@@ -205,8 +208,13 @@ int do_hog(sdm_ctx* c, int level)
     }
     {
         Timer t(c, SDM_T_HOG);
-        sdm_launch_hog(image_set(c), c->idx_identity ? nullptr : c->img_idx.p, c->x[c->cur].p, c->N, c->L,
-                       c->eyes, c->levels[level], c->feat.p, c->ldf, c->patch_idx.p, c->status.p, c->stream);
+        if (c->fast_kernel[level])
+            sdm_launch_hog_fast(image_set(c), c->idx_identity ? nullptr : c->img_idx.p, c->x[c->cur].p, c->N, c->L,
+                                c->eyes, c->levels[level], c->feat.p, c->ldf, c->patch_idx.p, c->status.p,
+                                c->hog_mode == SDM_HOG_EXACT_ORDER, c->fast_bins[level], c->stream);
+        else   // generic S > 64 geometry: the reference-order kernel
+            sdm_launch_hog(image_set(c), c->idx_identity ? nullptr : c->img_idx.p, c->x[c->cur].p, c->N, c->L,
+                           c->eyes, c->levels[level], c->feat.p, c->ldf, c->patch_idx.p, c->status.p, c->stream);
     }
     HIP_TRY(hipGetLastError());
     c->feat_level = level;
@@ -318,7 +326,7 @@ int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int*
     c->eyes.nre = nre; c->eyes.nle = nle;
     for (int i = 0; i < nre; ++i) c->eyes.re[i] = re[i];
     for (int i = 0; i < nle; ++i) c->eyes.le[i] = le[i];
-    c->levels.clear(); c->params.clear();
+    c->levels.clear(); c->params.clear(); c->fast_kernel.clear(); c->fast_bins.clear();
     c->Fmax = 0;
     for (int l = 0; l < n_levels; ++l) {
         const sdm_hog_param& p = levels[l];
@@ -342,6 +350,17 @@ int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int*
         }
         if (sdm_hog_lds_bytes(lv, 4) > 160 * 1024) return fail(SDM_ERR_INVALID, "HOG geometry exceeds the LDS budget");
         c->levels.push_back(lv); c->params.push_back(p);
+        {
+            // exhaustive on-device check of the orientation shortcut for this level's orientation count
+            int mism = 1;
+            HIP_TRY(hipMemsetAsync(c->status.p, 0, sizeof(int), c->stream));
+            sdm_launch_verify_fast_bins(lv, c->status.p, c->stream);
+            HIP_TRY(hipMemcpyAsync(&mism, c->status.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipMemsetAsync(c->status.p, 0, sizeof(int), c->stream));
+            c->fast_bins.push_back(mism == 0 ? 1 : 0);
+            c->fast_kernel.push_back(sdm_hog_fast_supported(lv) ? 1 : 0);
+        }
         const int F = L * lv.P + 1;
         if (F > c->Fmax) c->Fmax = F;
     }
@@ -351,6 +370,21 @@ int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int*
     c->have_R.assign(n_levels, false);
     c->feat.release(); c->feat_level = -1;
     c->N = 0; c->have_targets = false; c->g_level = -1;
+    return SDM_OK;
+}
+
+int sdm_set_hog_mode(sdm_ctx* c, int mode)
+{
+    if (!c || (mode != SDM_HOG_EXACT_ORDER && mode != SDM_HOG_FAST)) return fail(SDM_ERR_INVALID, "bad HOG mode");
+    c->hog_mode = mode;
+    return SDM_OK;
+}
+
+int sdm_get_hog_info(sdm_ctx* c, int level, int* fast_kernel, int* fast_bins)
+{
+    if (!c || level < 0 || level >= (int)c->levels.size()) return fail(SDM_ERR_INVALID, "bad level");
+    if (fast_kernel) *fast_kernel = c->fast_kernel[level];
+    if (fast_bins) *fast_bins = c->fast_bins[level];
     return SDM_OK;
 }
 
@@ -701,6 +735,24 @@ int sdm_debug_patch(sdm_ctx* c, int level, int sample, int landmark, uint8_t* rs
     if (desc) HIP_TRY(hipMemcpyAsync(desc, d_d.p, nP * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     d_r.release(); d_b.release(); d_h.release(); d_d.release();
+    return SDM_OK;
+}
+
+int sdm_debug_hog_profile(sdm_ctx* c, int level, unsigned long long* out8)
+{
+    if (!c || level < 0 || level >= (int)c->levels.size() || !out8) return fail(SDM_ERR_INVALID, "bad arguments");
+    if (!c->img_base || c->N <= 0) return fail(SDM_ERR_INVALID, "no images / samples set");
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf<unsigned long long> d;
+    int rc = d.ensure(8, true, c->stream);
+    if (rc) return rc;
+    sdm_launch_hog_fast_profile(image_set(c), c->idx_identity ? nullptr : c->img_idx.p, c->x[c->cur].p, c->N, c->L,
+                                c->eyes, c->levels[level], c->feat.p, c->ldf, c->status.p, d.p, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out8, d.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    d.release();
+    c->feat_level = level;
     return SDM_OK;
 }
 

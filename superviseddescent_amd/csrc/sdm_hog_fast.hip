@@ -1,0 +1,562 @@
+// sdm_hog_fast.hip -- the production HOG kernel for gfx950 (resized ROI edge S <= 64).
+//
+// Same reference semantics as sdm_hog.hip (rcr::HogTransform::operator(), include/rcr/adaptive_vlhog.hpp:
+// 109-185; vl_hog_put_image / vl_hog_extract, include/rcr/hog.c:595-728, 857-1062) and the same mapping
+// (one 64-lane wavefront per (sample, landmark) patch, lane = pixel column), restructured around what the
+// first profile showed (profiles/r01_*): the v1 kernel was bound by LDS float atomics (ds_add_f32 retires
+// ONE lane per 3 cycles: 192 cycles per wave-instruction, measured with scripts/ubench/lds_atomic*.hip)
+// and by ~11k VALU instructions per patch.
+//
+//  * crop + cv::resize + u8->f32 are fused into the gradient loop: every lane keeps three resized rows of
+//    its column in registers (a rolling window), left/right neighbours come through DPP wave shifts, the
+//    resized ROI never touches LDS; the four source bytes of the next output row are prefetched while the
+//    current row is processed;
+//  * everything that depends only on the column (resize taps, cell index, bilinear weights) lives in
+//    registers for the whole patch; everything that depends only on the row is read once per row from a
+//    small LDS table and moved to scalar registers;
+//  * the histogram is padded by one cell on every side so that the four bilinear updates need no bounds
+//    predicates;
+//  * accumulation has two modes (template ACC):
+//      ACC_EXACT_ORDER  ds_add_f32 in the reference's raster order -> histogram bit-identical to hog.c
+//                       (what sdm_hog.hip does; kept for validation, ~3 cycles per contributing pixel);
+//      ACC_FIXED64      every f32 contribution (g*wx)*wy is converted EXACTLY to 2^-36 fixed point (one
+//                       v_fma_f64 "magic number" + mask) and summed with ds_add_u64 (16x faster than the
+//                       float atomic); the sum is exact and order independent, converted back to f32 with
+//                       ONE rounding.  Differs from the reference's sequentially rounded f32 sum by a few
+//                       ulp at most; integer decisions (ROI geometry, resized bytes, bins) are identical.
+//  * the orientation arg-max uses the un-normalised gradient (gx*ox + gy*oy) when, for the level's
+//    orientation count, that shortcut has been verified on the device to give the reference's bin for
+//    EVERY possible pair of u8 central differences (511 x 511 inputs); otherwise the reference's
+//    normalise-then-score arithmetic is used;
+//  * blockIdx is remapped so that the 22/68 patches of one face run on one XCD (its image is then fetched
+//    from HBM into one L2 instead of eight).
+#include "sdm_kernels.h"
+
+#pragma clang fp contract(off)
+
+#define HF_WAVES 4
+#define ACC_EXACT_ORDER 0
+#define ACC_FIXED64 1
+
+namespace {
+
+typedef unsigned long long u64;
+
+__device__ inline double ied_of(const float* __restrict__ xr, int L, const EyeIdxDev& e)
+{
+    float rx = 0.0f, ry = 0.0f, lx = 0.0f, ly = 0.0f;
+    for (int i = 0; i < e.nre; ++i) { rx += xr[e.re[i]]; ry += xr[e.re[i] + L]; }
+    rx /= (float)e.nre; ry /= (float)e.nre;
+    for (int i = 0; i < e.nle; ++i) { lx += xr[e.le[i]]; ly += xr[e.le[i] + L]; }
+    lx /= (float)e.nle; ly /= (float)e.nle;
+    float dxf = rx - lx, dyf = ry - ly;
+    double dx = dxf, dy = dyf;
+    return sqrt(dx * dx + dy * dy);
+}
+
+__device__ inline int sat_short_f(float v)
+{
+    int i = __float2int_rn(v);
+    return i > 32767 ? 32767 : (i < -32768 ? -32768 : i);
+}
+
+__device__ inline int vl_floor(float x)
+{
+    int xi = (int)x;
+    if (x >= 0 || (float)xi == x) return xi;
+    return xi - 1;
+}
+
+// lane i <- lane i-1 / lane i+1 (DPP wavefront shifts; lane 0 / lane 63 receive 0)
+__device__ inline float from_left(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ inline float from_right(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+
+// reference arithmetic, hog.c:637-672 (identical to sdm_hog.hip::gradient_bin)
+__device__ inline void bin_reference(float gx, float gy, float g, const HogLevelDev& lv, int& bin)
+{
+    float nx = g > 0.0f ? gx / g : 0.0f;
+    float ny = g > 0.0f ? gy / g : 0.0f;
+    float best = 0.0f;
+    bin = -1;
+    for (int k = 0; k < lv.O; ++k) {
+        float s = nx * lv.ox[k] + ny * lv.oy[k];
+        int b = k;
+        if (s < 0) { s = -s; b += lv.O; }
+        if (s > best) { best = s; bin = b; }
+    }
+}
+
+// shortcut: same arg-max on the un-normalised gradient (verified exhaustively per level, see
+// sdm_verify_fast_bins); the scores only need to ORDER correctly, so FMA is fine here.
+__device__ inline void bin_unnormalised(float gx, float gy, const HogLevelDev& lv, int& bin)
+{
+    float best = 0.0f;
+    bin = -1;
+    for (int k = 0; k < lv.O; ++k) {
+        float s = __builtin_fmaf(gx, lv.ox[k], gy * lv.oy[k]);
+        int b = s < 0 ? k + lv.O : k;
+        s = __builtin_fabsf(s);
+        if (s > best) { best = s; bin = b; }
+    }
+}
+
+// per-wave LDS layout.  Region A lives for the whole patch, region B is first the rolling private
+// accumulators of the row loop and afterwards the scratch of the normalisation phase.
+struct FastLds {
+    void* hfin;       // A: fixed point: u64 [2O][CC] finished histogram; exact order: f32 [2O][PW][PW] (padded)
+    u64* copies;      // B (row loop, fixed point): [2 band slots][2O][PW][R] private accumulators
+    float* histv;     // B (after): [2O][CC] histogram as f32
+    float* nrm;       // B: [CC]
+    double* fac;      // B: [4][CC]
+    double* hcc;      // B: [O][CC][4] clamped hc values for the texture sums
+    float* desc;      // B: [D][CC]
+};
+
+__host__ __device__ inline size_t al16(size_t v) { return (v + 15) & ~(size_t)15; }
+__host__ __device__ inline int copies_R(int cell) { return cell < 8 ? cell : 8; }
+
+__host__ __device__ inline size_t fast_lds_bytes(int cell, int C, int O, int D)
+{
+    const int CC = C * C, PW = C + 2;
+    const size_t a_fixed = al16((size_t)2 * O * CC * 8), a_exact = al16((size_t)2 * O * PW * PW * 4);
+    const size_t A = a_fixed > a_exact ? a_fixed : a_exact;
+    const size_t b_rows = al16((size_t)2 * 2 * O * PW * copies_R(cell) * 8);
+    const size_t b_norm = al16((size_t)2 * O * CC * 4) + al16((size_t)CC * 4) + al16((size_t)4 * CC * 8) +
+                          al16((size_t)O * CC * 4 * 8) + al16((size_t)D * CC * 4);
+    return A + (b_rows > b_norm ? b_rows : b_norm);
+}
+
+__device__ inline FastLds fast_carve(unsigned char* base, int C, int O, int D)
+{
+    const int CC = C * C, PW = C + 2;
+    const size_t a_fixed = al16((size_t)2 * O * CC * 8), a_exact = al16((size_t)2 * O * PW * PW * 4);
+    const size_t A = a_fixed > a_exact ? a_fixed : a_exact;
+    FastLds w;
+    w.hfin = (void*)base;
+    size_t o = A;
+    w.copies = (u64*)(base + o);
+    w.histv = (float*)(base + o); o += al16((size_t)2 * O * CC * 4);
+    w.nrm = (float*)(base + o); o += al16((size_t)CC * 4);
+    w.fac = (double*)(base + o); o += al16((size_t)4 * CC * 8);
+    w.hcc = (double*)(base + o); o += al16((size_t)O * CC * 4 * 8);
+    w.desc = (float*)(base + o);
+    return w;
+}
+
+__device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ inline float lane_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+
+// TO / TC: compile-time orientation count / cell count (0 = take the run-time value from lv)
+template <int ACC, bool FASTBIN, int TO, int TC, bool PROF = false>
+__device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* __restrict__ xr, int L, int landmark,
+                               const EyeIdxDev& eyes, const HogLevelDev& lv, unsigned char* lds_base,
+                               float* __restrict__ out_desc, int* idx_row, int* status,
+                               unsigned long long* prof = nullptr)
+{
+    long long tprev = PROF ? clock64() : 0;
+    auto mark = [&](int slot) {
+        if (PROF) {
+            const long long t = clock64();
+            if ((threadIdx.x & 63) == 0) atomicAdd(&prof[slot], (unsigned long long)(t - tprev));
+            tprev = t;
+        }
+    };
+    const int lane = threadIdx.x & 63;
+    const int S = lv.S, cell = lv.cell, D = lv.D;
+    const int O = TO ? TO : lv.O;
+    const int C = TC ? TC : lv.C;
+    const int CC = C * C, PW = C + 2, PWW = PW * PW;
+    FastLds w = fast_carve(lds_base, C, O, D);
+    float* histf = (float*)w.hfin;     // exact order: padded f32 histogram
+    u64* hfin = (u64*)w.hfin;          // fixed point: finished histogram [2O][CC]
+    const int R = copies_R(cell);      // private accumulator copies per (band, bin, column): lane x uses copy x % R
+
+    // ---- patch geometry (wave-uniform, moved to scalar registers; adaptive_vlhog.hpp:123,132-133) ------
+    const double ied = ied_of(xr, L, eyes);
+    const int h = uni((int)round((double)lv.rel * ied / 2));
+    const int cx = uni(__float2int_rn(xr[landmark]));
+    const int cy = uni(__float2int_rn(xr[landmark + L]));
+    if (idx_row && lane == 0) {
+        if (landmark == 0) idx_row[0] = h;
+        idx_row[1 + landmark] = cx;
+        idx_row[1 + L + landmark] = cy;
+    }
+    const bool empty = h <= 0;
+    if (empty && lane == 0) atomicOr(status, SDM_DEV_ERR_EMPTY_PATCH);
+    const int sw = empty ? 1 : 2 * h;
+    const int x0 = cx - h, y0 = cy - h;
+    const bool area2 = (sw == 2 * S);   // both scales exactly 2: INTER_LINEAR is redirected to the 2x2 box average
+    const double scale = 1.0 / ((double)S / (double)sw);
+
+    const int im = uni(im_in);
+    const uint8_t* img = imgs.base + imgs.offset[im];
+    const int iw = imgs.w[im], ih = imgs.h[im], istride = imgs.stride[im];
+
+    // ---- per-coordinate values: lane d computes coordinate d once.  The COLUMN copy stays in this lane's
+    //      registers; the ROW copy of coordinate yy is fetched from lane yy with v_readlane (no LDS) -----------
+    const int d = lane < S ? lane : S - 1;
+    int bxc; float wx1, wx2;          // HOG cell index / bilinear weights of coordinate d   (hog.c:697-704)
+    int row_src, row_beta;            // vertical resize taps of coordinate d (packed)
+    int px0, px1, a0, a1;             // horizontal resize taps of column d (image columns, masked weights)
+    {
+        const float hx = (float)((d + 0.5) / (double)cell - 0.5);
+        bxc = vl_floor(hx);
+        wx2 = hx - (float)bxc;
+        wx1 = (float)(1.0 - wx2);
+        float f = (float)((d + 0.5) * scale - 0.5);
+        const int s = (int)floorf(f);
+        f -= (float)s;
+        const int c0 = sat_short_f((1.f - f) * 2048.0f), c1 = sat_short_f(f * 2048.0f);
+        // vertical taps: clip the ROWS, keep the fraction
+        int sy0 = s < 0 ? 0 : (s > sw - 1 ? sw - 1 : s);
+        int sy1 = s + 1 < 0 ? 0 : (s + 1 > sw - 1 ? sw - 1 : s + 1);
+        if (area2) { sy0 = 2 * d; sy1 = 2 * d + 1; }
+        row_src = sy0 | (sy1 << 16);
+        row_beta = (c0 & 0xffff) | (c1 << 16);
+        // horizontal taps: clamped in the table
+        int sx = s;
+        a0 = c0; a1 = c1;
+        if (sx < 0) { sx = 0; a0 = 2048; a1 = 0; }
+        if (sx >= sw - 1) { sx = sw - 1; a0 = 2048; a1 = 0; }
+        if (area2) { sx = 2 * d; a0 = 1; a1 = 1; }
+        const int sx1 = (sx + 1 < sw) ? sx + 1 : sx;
+        px0 = x0 + sx; px1 = x0 + sx1;
+        // columns on the black canvas (or an empty patch) get weight 0 instead of a per-row mask
+        if (px0 < 0 || px0 >= iw || empty) a0 = 0;
+        if (px1 < 0 || px1 >= iw || empty) a1 = 0;
+        px0 = px0 < 0 ? 0 : (px0 > iw - 1 ? iw - 1 : px0);
+        px1 = px1 < 0 ? 0 : (px1 > iw - 1 ? iw - 1 : px1);
+    }
+    const float row_w1 = wx1, row_w2 = wx2;   // weights of coordinate d when it is used as a ROW
+    const int row_cell = bxc;
+    const bool col_active = (lane >= 1) && (lane < S - 1);
+    // padded histogram column of this lane (lanes outside the ROI contribute exact zeros to cell 0)
+    const int hcol = col_active ? bxc + 1 : 0;
+    if (!col_active) { wx1 = 0.0f; wx2 = 0.0f; }
+
+    mark(0);   // geometry + per-coordinate tables
+    if (ACC == ACC_FIXED64) {
+        for (int i = lane; i < 2 * 2 * O * PW * R; i += 64) w.copies[i] = 0ull;
+        for (int i = lane; i < 2 * O * CC; i += 64) hfin[i] = 0ull;
+    } else {
+        for (int i = lane; i < 2 * O * PWW; i += 64) histf[i] = 0.0f;
+    }
+    __syncthreads();
+    mark(1);   // histogram clear + barrier
+    // fixed point: the two cell-row bands (by, by+1) a pixel row feeds are accumulated in private copies (no two
+    // lanes of one instruction share an address); a band is folded into hfin when the rows have moved past it
+    const int rcopy = lane % R;
+    int cur_by = -2;
+    auto flush_band = [&](int band) {
+        const int slot = band & 1;
+        for (int t = lane; t < 2 * O * PW; t += 64) {
+            u64* cp = w.copies + (size_t)(slot * 2 * O * PW + t) * R;
+            u64 sum = 0;
+            for (int r = 0; r < R; ++r) { sum += cp[r]; cp[r] = 0ull; }
+            const int kbin = t / PW, hc = t - kbin * PW;
+            if (band >= 0 && band < C && hc >= 1 && hc <= C) hfin[kbin * CC + band * C + (hc - 1)] = sum;
+        }
+    };
+
+    // ---- fused crop + resize + gradient + accumulation, one output row per iteration -------------------
+    // issue: the four source bytes of output row y (two clipped source rows x two horizontal taps)
+    auto issue_row = [&](int y, int& q00, int& q01, int& q10, int& q11, int& bb) {
+        const int yy = y < S ? y : S - 1;
+        const int src = __builtin_amdgcn_readlane(row_src, yy);
+        int beta = __builtin_amdgcn_readlane(row_beta, yy);
+        int py0 = y0 + (src & 0xffff), py1 = y0 + (src >> 16);
+        // rows on the black canvas: vertical weight 0 (scalar), address clamped into the image
+        if (py0 < 0 || py0 >= ih) beta &= 0xffff0000;
+        if (py1 < 0 || py1 >= ih) beta &= 0x0000ffff;
+        py0 = py0 < 0 ? 0 : (py0 > ih - 1 ? ih - 1 : py0);
+        py1 = py1 < 0 ? 0 : (py1 > ih - 1 ? ih - 1 : py1);
+        const uint8_t* r0p = img + (long long)py0 * istride;
+        const uint8_t* r1p = img + (long long)py1 * istride;
+        q00 = r0p[px0]; q01 = r0p[px1]; q10 = r1p[px0]; q11 = r1p[px1];
+        bb = beta;
+    };
+    auto finish_row = [&](int q00, int q01, int q10, int q11, int beta) -> float {
+        const int H0 = q00 * a0 + q01 * a1;
+        const int H1 = q10 * a0 + q11 * a1;
+        int out;
+        if (area2) {
+            const int e0 = (beta & 0xffff) ? 1 : 0, e1 = (beta >> 16) ? 1 : 0;   // row validity survives in beta
+            out = (H0 * e0 + H1 * e1 + 2) >> 2;
+        } else {
+            const int b0 = beta & 0xffff, b1 = beta >> 16;
+            out = (((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2;
+        }
+        return (float)out;      // convertTo(CV_32F), adaptive_vlhog.hpp:157
+    };
+
+    float rm2 = 0.0f, rm1 = 0.0f;       // resized rows y-2, y-1 of this lane's column
+    int n00, n01, n10, n11, nbeta;
+    issue_row(0, n00, n01, n10, n11, nbeta);
+    for (int y = 0; y < S; ++y) {
+        const int c00 = n00, c01 = n01, c10 = n10, c11 = n11, cbeta = nbeta;
+        issue_row(y + 1, n00, n01, n10, n11, nbeta);               // prefetch (clamped past the last row)
+        const float r0 = finish_row(c00, c01, c10, c11, cbeta);
+        if (y >= 2) {
+            // gradient of row yy = y-1 (hog.c:616-672)
+            const int yy = y - 1;
+            const float gx = from_right(rm1) - from_left(rm1);
+            const float gy = r0 - rm2;
+            const float g2 = gx * gx + gy * gy;
+            float g = sqrtf(g2);
+            int bin;
+            if (FASTBIN) {
+                float best = 0.0f;
+                bin = -1;
+#pragma unroll
+                for (int k = 0; k < (TO ? TO : SDM_MAX_ORIENT); ++k) {
+                    if (TO == 0 && k >= O) break;
+                    float sc = __builtin_fmaf(gx, lv.ox[k], gy * lv.oy[k]);
+                    const int bsel = sc < 0 ? k + O : k;
+                    sc = __builtin_fabsf(sc);
+                    if (sc > best) { best = sc; bin = bsel; }
+                }
+            } else {
+                const float nx = g > 0.0f ? gx / g : 0.0f;
+                const float ny = g > 0.0f ? gy / g : 0.0f;
+                float best = 0.0f;
+                bin = -1;
+#pragma unroll
+                for (int k = 0; k < (TO ? TO : SDM_MAX_ORIENT); ++k) {
+                    if (TO == 0 && k >= O) break;
+                    float sc = nx * lv.ox[k] + ny * lv.oy[k];
+                    int bsel = k;
+                    if (sc < 0) { sc = -sc; bsel += O; }
+                    if (sc > best) { best = sc; bin = bsel; }
+                }
+            }
+            if (!col_active || bin < 0) { g = 0.0f; bin = 0; }
+            const int by = __builtin_amdgcn_readlane(row_cell, yy);
+            const float wy1 = lane_f(row_w1, yy), wy2 = lane_f(row_w2, yy);
+            const float t1 = g * wx1, t2 = g * wx2;             // (grad * wx) * wy, hog.c:714-723
+            const float va = t2 * wy1, vb = t1 * wy1, vc = t2 * wy2, vd = t1 * wy2;
+            if (ACC == ACC_FIXED64) {
+                if (by != cur_by) {          // wave-uniform: the rows entered the next cell-row band
+                    if (cur_by != -2) flush_band(cur_by);
+                    cur_by = by;
+                }
+                // exact f32 -> 2^-36 fixed point: fma(v, 2^36, 2^52) leaves the integer in the low 52 mantissa bits
+                auto fx = [](float v) -> u64 {
+                    const double yv = __builtin_fma((double)v, 68719476736.0, 4503599627370496.0);
+                    return (u64)__builtin_bit_cast(long long, yv) & 0x000fffffffffffffull;
+                };
+                u64* c0 = w.copies + (size_t)(((by & 1) * 2 * O + bin) * PW + hcol) * R + rcopy;        // band by
+                u64* c1 = w.copies + (size_t)((((by + 1) & 1) * 2 * O + bin) * PW + hcol) * R + rcopy;  // band by+1
+                atomicAdd(c0 + R, fx(va));
+                atomicAdd(c0, fx(vb));
+                atomicAdd(c1 + R, fx(vc));
+                atomicAdd(c1, fx(vd));
+            } else {
+                const int base = bin * PWW + (by + 1) * PW + hcol;
+                // reference order per accumulator: (bx+1,by) (bx,by) (bx+1,by+1) (bx,by+1), lanes ascending
+                if (va != 0.0f) atomicAdd(&histf[base + 1], va);
+                if (vb != 0.0f) atomicAdd(&histf[base], vb);
+                if (vc != 0.0f) atomicAdd(&histf[base + PW + 1], vc);
+                if (vd != 0.0f) atomicAdd(&histf[base + PW], vd);
+            }
+        }
+        rm2 = rm1; rm1 = r0;
+    }
+    if (ACC == ACC_FIXED64 && cur_by != -2) { flush_band(cur_by); flush_band(cur_by + 1); }
+    mark(2);   // row loop
+    __syncthreads();
+    mark(3);   // barrier after the row loop
+
+    // ---- histogram -> f32 [2O][CC] (one conversion per accumulator; region B, dead since the last flush,
+    //      becomes the scratch of the normalisation phase; region A is only read) ----------------------------
+    for (int t = lane; t < 2 * O * CC; t += 64) {
+        const int k = t / CC, c = t - k * CC;
+        const int cyy = c / C, cxx = c - cyy * C;
+        // fixed point: exact sum, ONE rounding (u64 -> f32), then the exact scale 2^-36
+        w.histv[t] = (ACC == ACC_FIXED64) ? (float)hfin[t] * 1.4551915228366852e-11f
+                                           : histf[k * PWW + (cyy + 1) * PW + (cxx + 1)];
+    }
+    __syncthreads();
+
+    // ---- cell norms (hog.c:875-890) ---------------------------------------------------------------------------
+    for (int c = lane; c < CC; c += 64) {
+        float n = 0.0f;
+        for (int k = 0; k < O; ++k) {
+            const float hs = w.histv[c + k * CC] + w.histv[c + (k + O) * CC];
+            n += hs * hs;
+        }
+        w.nrm[c] = n;
+    }
+    __syncthreads();
+    // ---- the four block factors of every cell (hog.c:930-981), one lane per (cell, block) ---------------------
+    for (int t = lane; t < 4 * CC; t += 64) {
+        const int j = t / CC, c = t - j * CC;
+        const int y = c / C, x = c - y * C;
+        const int xm = x - 1 > 0 ? x - 1 : 0, xp = x + 1 < C - 1 ? x + 1 : C - 1;
+        const int ym = y - 1 > 0 ? y - 1 : 0, yp = y + 1 < C - 1 ? y + 1 : C - 1;
+        // j=0: n1+n2+n4+n5  j=1: n2+n3+n5+n6  j=2: n4+n5+n7+n8  j=3: n5+n6+n8+n9   (left-to-right, + 1e-4 last)
+        const int xa = (j & 1) ? x : xm, xb = (j & 1) ? xp : x;
+        const int ya = (j & 2) ? y : ym, yb = (j & 2) ? yp : y;
+        const double na = w.nrm[xa + ya * C], nb = w.nrm[xb + ya * C];
+        const double nc = w.nrm[xa + yb * C], nd = w.nrm[xb + yb * C];
+        w.fac[j * CC + c] = 1.0 / sqrt(na + nb + nc + nd + 1e-4);
+    }
+    __syncthreads();
+    // ---- normalise, clamp, emit the 3 (UoCTTI) or 4 (Dalal-Triggs) outputs of every (cell, orientation) ------
+    for (int t = lane; t < O * CC; t += 64) {
+        const int k = t / CC, c = t - k * CC;
+        const double ha = w.histv[c + k * CC], hb = w.histv[c + (k + O) * CC];
+        const double f1 = w.fac[c], f2 = w.fac[CC + c], f3 = w.fac[2 * CC + c], f4 = w.fac[3 * CC + c];
+        double ha1 = f1 * ha, ha2 = f2 * ha, ha3 = f3 * ha, ha4 = f4 * ha;
+        double hb1 = f1 * hb, hb2 = f2 * hb, hb3 = f3 * hb, hb4 = f4 * hb;
+        double hc1 = ha1 + hb1, hc2 = ha2 + hb2, hc3 = ha3 + hb3, hc4 = ha4 + hb4;
+#define CL02(v) ((0.2 < (v)) ? 0.2 : (v))
+        ha1 = CL02(ha1); ha2 = CL02(ha2); ha3 = CL02(ha3); ha4 = CL02(ha4);
+        hb1 = CL02(hb1); hb2 = CL02(hb2); hb3 = CL02(hb3); hb4 = CL02(hb4);
+        hc1 = CL02(hc1); hc2 = CL02(hc2); hc3 = CL02(hc3); hc4 = CL02(hc4);
+#undef CL02
+        if (lv.variant == 1) {
+            w.desc[c + k * CC] = (float)(0.5 * (ha1 + ha2 + ha3 + ha4));
+            w.desc[c + (k + O) * CC] = (float)(0.5 * (hb1 + hb2 + hb3 + hb4));
+            w.desc[c + (k + 2 * O) * CC] = (float)(0.5 * (hc1 + hc2 + hc3 + hc4));
+            double* q = w.hcc + (size_t)(k * CC + c) * 4;
+            q[0] = hc1; q[1] = hc2; q[2] = hc3; q[3] = hc4;
+        } else {
+            w.desc[c + k * CC] = (float)hc1;
+            w.desc[c + (k + O) * CC] = (float)hc2;
+            w.desc[c + (k + 2 * O) * CC] = (float)hc3;
+            w.desc[c + (k + 3 * O) * CC] = (float)hc4;
+        }
+    }
+    __syncthreads();
+    // ---- texture features: t_j = sum over k (in order) of the clamped hc_j (hog.c:1020-1023, 1047-1052) ------
+    if (lv.variant == 1) {
+        const float tex = 1.0f / sqrtf(18.0f);
+        for (int t = lane; t < 4 * CC; t += 64) {
+            const int j = t / CC, c = t - j * CC;
+            double acc = 0.0;
+            for (int k = 0; k < O; ++k) acc += w.hcc[(size_t)(k * CC + c) * 4 + j];
+            w.desc[c + (3 * O + j) * CC] = (float)(tex * acc);
+        }
+        __syncthreads();
+    }
+    mark(4);   // normalisation / extraction
+    // ---- Matlab-order flatten (adaptive_vlhog.hpp:166-175): out[j*CC + xx*C + yy] = desc[j][yy][xx] ----------
+    for (int o = lane; o < lv.P; o += 64) {
+        const int j = o / CC, r = o - j * CC;
+        const int xx = r / C, yy = r - xx * C;
+        out_desc[o] = w.desc[j * CC + yy * C + xx];
+    }
+    mark(5);   // output stores
+}
+
+template <int ACC, bool FASTBIN, int TO, int TC, bool PROF = false>
+__global__ void __launch_bounds__(HF_WAVES * 64)
+hog_fast_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float* __restrict__ x, int N, int L,
+                EyeIdxDev eyes, HogLevelDev lv, float* __restrict__ feat, long long ldf,
+                int* __restrict__ idx_out, int* __restrict__ status, size_t lds_per_wave,
+                unsigned long long* prof = nullptr)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int wave = uni(threadIdx.x >> 6);
+    // XCD-aware remap (bijective): workgroups that the dispatcher places on XCD b%8 take a contiguous run of patches
+    const unsigned nb = gridDim.x, b = blockIdx.x;
+    const unsigned q = nb / 8, r = nb % 8, xcd = b % 8;
+    const unsigned blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
+    long long p = (long long)blk * HF_WAVES + wave;
+    const long long total = (long long)N * L;
+    if (p >= total) p = total - 1;   // tail waves redo the last patch (identical values) to keep barriers uniform
+    const int s = (int)(p / L), i = (int)(p - (long long)s * L);
+    const int im = img_idx ? img_idx[s] : s;
+    const float* xr = x + (long long)s * 2 * L;
+    float* row = feat + (long long)s * ldf;
+    hog_patch_fast<ACC, FASTBIN, TO, TC, PROF>(imgs, im, xr, L, i, eyes, lv, smem + (size_t)wave * lds_per_wave,
+                                               row + (long long)i * lv.P,
+                                               idx_out ? idx_out + (long long)s * (1 + 2 * L) : nullptr, status, prof);
+    if (PROF && (threadIdx.x & 63) == 0) atomicAdd(&prof[7], 1ull);
+    if (i == L - 1 && (threadIdx.x & 63) == 0) row[(long long)L * lv.P] = 1.0f;   // bias, adaptive_vlhog.hpp:182-183
+}
+
+// count the (gx, gy) pairs for which the un-normalised arg-max disagrees with the reference arithmetic
+__global__ void verify_fast_bins_kernel(HogLevelDev lv, int* __restrict__ mismatches)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 511 * 511) return;
+    const float gx = (float)(i % 511 - 255), gy = (float)(i / 511 - 255);
+    const float g = sqrtf(gx * gx + gy * gy);
+    int a, b;
+    bin_reference(gx, gy, g, lv, a);
+    bin_unnormalised(gx, gy, lv, b);
+    if (a != b) atomicAdd(mismatches, 1);
+}
+
+}  // namespace
+
+bool sdm_hog_fast_supported(const HogLevelDev& lv)
+{
+    return lv.S >= 4 && lv.S <= 64 && fast_lds_bytes(lv.cell, lv.C, lv.O, lv.D) * HF_WAVES <= 160 * 1024;
+}
+
+void sdm_launch_verify_fast_bins(const HogLevelDev& lv, int* mismatches_dev, hipStream_t stream)
+{
+    const int n = 511 * 511;
+    hipLaunchKernelGGL(verify_fast_bins_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, lv, mismatches_dev);
+}
+
+template <int TO, int TC>
+static void launch_fast_oc(const ImageSetDev& imgs, const int* img_idx, const float* x, int N, int L,
+                           const EyeIdxDev& eyes, const HogLevelDev& lv, float* feat, long long ldf, int* idx_out,
+                           int* status, int exact_order, int fast_bins, hipStream_t stream)
+{
+    const long long total = (long long)N * L;
+    const size_t per = fast_lds_bytes(lv.cell, lv.C, lv.O, lv.D);
+    const unsigned grid = (unsigned)((total + HF_WAVES - 1) / HF_WAVES);
+    const dim3 g(grid), b(HF_WAVES * 64);
+    const size_t lds = per * HF_WAVES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)hog_fast_kernel<ACC_EXACT_ORDER, true, TO, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)hog_fast_kernel<ACC_EXACT_ORDER, false, TO, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)hog_fast_kernel<ACC_FIXED64, true, TO, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)hog_fast_kernel<ACC_FIXED64, false, TO, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+#define LAUNCH(ACC, FB)                                                                                              \
+    hipLaunchKernelGGL((hog_fast_kernel<ACC, FB, TO, TC>), g, b, lds, stream, imgs, img_idx, x, N, L, eyes, lv, feat, \
+                       ldf, idx_out, status, per)
+    if (exact_order) { if (fast_bins) LAUNCH(ACC_EXACT_ORDER, true); else LAUNCH(ACC_EXACT_ORDER, false); }
+    else { if (fast_bins) LAUNCH(ACC_FIXED64, true); else LAUNCH(ACC_FIXED64, false); }
+#undef LAUNCH
+}
+
+// instrumented run (s_memtime per phase, summed over waves): prof[0..5] phase cycles, prof[7] waves
+void sdm_launch_hog_fast_profile(const ImageSetDev& imgs, const int* img_idx, const float* x, int N, int L,
+                                 const EyeIdxDev& eyes, const HogLevelDev& lv, float* feat, long long ldf,
+                                 int* status, unsigned long long* prof_dev, hipStream_t stream)
+{
+    const long long total = (long long)N * L;
+    if (total <= 0 || !(lv.O == 4 && lv.C == 5)) return;
+    const size_t per = fast_lds_bytes(lv.cell, lv.C, lv.O, lv.D);
+    const unsigned grid = (unsigned)((total + HF_WAVES - 1) / HF_WAVES);
+    hipLaunchKernelGGL((hog_fast_kernel<ACC_FIXED64, true, 4, 5, true>), dim3(grid), dim3(HF_WAVES * 64), per * HF_WAVES,
+                       stream, imgs, img_idx, x, N, L, eyes, lv, feat, ldf, (int*)nullptr, status, per, prof_dev);
+}
+
+void sdm_launch_hog_fast(const ImageSetDev& imgs, const int* img_idx, const float* x, int N, int L,
+                         const EyeIdxDev& eyes, const HogLevelDev& lv, float* feat, long long ldf, int* idx_out,
+                         int* status, int exact_order, int fast_bins, hipStream_t stream)
+{
+    if ((long long)N * L <= 0) return;
+    // specialised instances for the shipped (4 orientations) and the "31-bin" (9 orientations) 5x5-cell geometry
+    if (lv.O == 4 && lv.C == 5)
+        launch_fast_oc<4, 5>(imgs, img_idx, x, N, L, eyes, lv, feat, ldf, idx_out, status, exact_order, fast_bins, stream);
+    else if (lv.O == 9 && lv.C == 5)
+        launch_fast_oc<9, 5>(imgs, img_idx, x, N, L, eyes, lv, feat, ldf, idx_out, status, exact_order, fast_bins, stream);
+    else
+        launch_fast_oc<0, 0>(imgs, img_idx, x, N, L, eyes, lv, feat, ldf, idx_out, status, exact_order, fast_bins, stream);
+}

@@ -52,6 +52,19 @@ void sdm_launch_hog(const ImageSetDev& imgs, const int* img_idx, const float* x,
                     const EyeIdxDev& eyes, const HogLevelDev& lv, float* feat, long long ldf,
                     int* idx_out, int* status, hipStream_t stream);
 
+// Production kernel (sdm_hog_fast.hip), S <= 64.  exact_order: accumulate with ds_add_f32 in the reference's
+// raster order (bit-identical histogram) instead of the exact 2^-36 fixed-point sum; fast_bins: use the
+// un-normalised orientation arg-max (only when sdm_launch_verify_fast_bins counted 0 mismatches).
+bool sdm_hog_fast_supported(const HogLevelDev& lv);
+void sdm_launch_verify_fast_bins(const HogLevelDev& lv, int* mismatches_dev, hipStream_t stream);
+void sdm_launch_hog_fast(const ImageSetDev& imgs, const int* img_idx, const float* x, int N, int L,
+                         const EyeIdxDev& eyes, const HogLevelDev& lv, float* feat, long long ldf, int* idx_out,
+                         int* status, int exact_order, int fast_bins, hipStream_t stream);
+
+void sdm_launch_hog_fast_profile(const ImageSetDev& imgs, const int* img_idx, const float* x, int N, int L,
+                                 const EyeIdxDev& eyes, const HogLevelDev& lv, float* feat, long long ldf,
+                                 int* status, unsigned long long* prof_dev, hipStream_t stream);
+
 // Single-patch debug variant that also returns the resized ROI, per-pixel bins and raw histogram.
 void sdm_launch_hog_debug(const ImageSetDev& imgs, const int* img_idx, const float* x, int N, int L,
                           const EyeIdxDev& eyes, const HogLevelDev& lv, int sample, int landmark,

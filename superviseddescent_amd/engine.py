@@ -93,6 +93,16 @@ class Context:
                                                len(hog_params), arr))
         self.L, self.n_levels = num_landmarks, len(hog_params)
 
+    def set_hog_mode(self, mode: int):
+        """``_lib.SDM_HOG_FAST`` (default: exact fixed-point sum, rounded once) or ``_lib.SDM_HOG_EXACT_ORDER``
+        (reference accumulation order, features bit-identical to the reference's CPU path)."""
+        check(self._lib.sdm_set_hog_mode(self._h, int(mode)))
+
+    def hog_info(self, level: int):
+        fk, fb = ctypes.c_int(0), ctypes.c_int(0)
+        check(self._lib.sdm_get_hog_info(self._h, level, ctypes.byref(fk), ctypes.byref(fb)))
+        return {"fast_kernel": bool(fk.value), "fast_bins": bool(fb.value)}
+
     def feature_dim(self, level: int) -> int:
         return check(self._lib.sdm_feature_dim(self._h, level))
 
@@ -244,6 +254,13 @@ class Context:
         check(self._lib.sdm_debug_patch(self._h, level, sample, landmark, rsz.ctypes.data_as(u8),
                                         bins.ctypes.data_as(u8), _fp(hist), _fp(desc)))
         return rsz, bins, hist, desc
+
+    def debug_hog_profile(self, level: int):
+        out = (ctypes.c_ulonglong * 8)()
+        check(self._lib.sdm_debug_hog_profile(self._h, level, out))
+        n = max(int(out[7]), 1)
+        names = ["setup", "clear", "rows", "barrier", "normalise", "store"]
+        return {names[i]: out[i] / n for i in range(6)}, n
 
     def debug_gradient_table(self, level: int):
         g = np.empty((511, 511), np.float32)

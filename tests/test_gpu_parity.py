@@ -10,6 +10,7 @@ import pytest
 from oracle import sdm_oracle as orc
 from superviseddescent_amd import (Context, HoGParam, HogTransform, LinearRegressor, Regulariser, SdmError,
                                    SupervisedDescentOptimiser, detection_model, ibug, synth)
+from superviseddescent_amd._lib import SDM_HOG_EXACT_ORDER, SDM_HOG_FAST
 
 pytestmark = pytest.mark.gpu
 
@@ -22,6 +23,23 @@ O_SHIPPED = [orc.HoGParam(*p) for p in ibug.SHIPPED_HOG_PARAMS]
 
 def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def check_features(ctx_mode, got, want):
+    """EXACT_ORDER: bit-identical to the reference-order CPU sum.  FAST: the exact (fixed-point) sum rounded once,
+    which may differ from the sequentially rounded f32 sum by a few ulp of the histogram entries."""
+    if ctx_mode == SDM_HOG_EXACT_ORDER:
+        assert np.array_equal(bits(got), bits(want))
+    else:
+        assert np.abs(got - want).max() <= 1e-6          # descriptor values are <= 0.4
+        assert rel_l2(got, want) <= 5e-7
+
+
+@pytest.fixture(params=[SDM_HOG_EXACT_ORDER, SDM_HOG_FAST], ids=["exact_order", "fast"])
+def hog_mode(request, gpu_ctx):
+    gpu_ctx.set_hog_mode(request.param)
+    yield request.param
+    gpu_ctx.set_hog_mode(SDM_HOG_FAST)
 
 
 def rel_l2(a, b):
@@ -47,7 +65,7 @@ def test_gradient_table_exhaustive(gpu_ctx, level):
     assert np.array_equal(b, ob)
 
 
-def test_golden_rows_bitwise(gpu_ctx):
+def test_golden_rows_bitwise(gpu_ctx, hog_mode):
     """Committed vectors (reference hog.c + documented glue): Dalal-Triggs, 9 orientations, the exact-2x
     area path, patches poking outside the image, cvRound ties."""
     re, le = [int(GOLD["tr_eyes"][0])], [int(GOLD["tr_eyes"][1])]
@@ -60,7 +78,7 @@ def test_golden_rows_bitwise(gpu_ctx):
     for li in range(len(params)):
         feat = gpu_ctx.hog_features(li, fetch=True)
         assert np.array_equal(gpu_ctx.patch_indices(), GOLD[f"tr_idx_{li}"])
-        assert np.array_equal(bits(feat), bits(GOLD[f"tr_feat_{li}"])), li
+        check_features(hog_mode, feat, GOLD[f"tr_feat_{li}"])
 
 
 def test_patch_intermediates_bitwise(gpu_ctx, faces):
@@ -90,7 +108,7 @@ def test_patch_intermediates_bitwise(gpu_ctx, faces):
 
 
 @pytest.mark.parametrize("level", [0, 1, 2, 3])
-def test_rcr22_features_bitwise(gpu_ctx, faces, level):
+def test_rcr22_features_bitwise(gpu_ctx, faces, level, hog_mode):
     images, _, _, _, x0 = faces
     gpu_ctx.set_model_geometry(len(IDS), RE, LE, SHIPPED)
     gpu_ctx.upload_images(images)
@@ -99,11 +117,11 @@ def test_rcr22_features_bitwise(gpu_ctx, faces, level):
     feat = gpu_ctx.hog_features(level, fetch=True)
     ofeat, oidx = orc.hog_features_batch(images, None, x0, RE, LE, O_SHIPPED[level], n_threads=os.cpu_count() or 1,
                                          want_idx=True)
-    assert np.array_equal(gpu_ctx.patch_indices(), oidx)
-    assert np.array_equal(bits(feat), bits(ofeat))
+    assert np.array_equal(gpu_ctx.patch_indices(), oidx)      # integer decisions: identical in both modes
+    check_features(hog_mode, feat, ofeat)
 
 
-def test_baseline31_variant_and_image_index(gpu_ctx, faces):
+def test_baseline31_variant_and_image_index(gpu_ctx, faces, hog_mode):
     """'31-bin VlHog' (9 orientations) + perturbed rows sharing images + ragged batch size."""
     images, boxes, gt, _, _ = faces
     x_star, x0, idx = synth.make_samples(boxes[:37], gt[:37], IDS, n_perturb=2, seed=77)   # N = 111
@@ -117,10 +135,10 @@ def test_baseline31_variant_and_image_index(gpu_ctx, faces):
         ofeat = orc.hog_features_batch(images[:37], idx, x0, RE, LE, orc.HoGParam(*ibug.BASELINE31_HOG_PARAMS[level]),
                                        n_threads=os.cpu_count() or 1)
         assert feat.shape[1] == 22 * 25 * 31 + 1
-        assert np.array_equal(bits(feat), bits(ofeat))
+        check_features(hog_mode, feat, ofeat)
 
 
-def test_ragged_images(gpu_ctx):
+def test_ragged_images(gpu_ctx, hog_mode):
     rng = np.random.default_rng(9)
     imgs = [rng.integers(0, 256, (h, w)).astype(np.uint8) for (h, w) in [(120, 90), (64, 200), (181, 181)]]
     x = np.array([[30, 50, 60, 45, 40, 42, 70, 60], [20, 90, 150, 100, 30, 28, 50, 40], [60, 100, 140, 100, 80, 82, 120, 150]],
@@ -134,7 +152,28 @@ def test_ragged_images(gpu_ctx):
     L = orc.lib()
     for i in range(3):
         of = orc.hog_features_batch(imgs[i][None], None, x[i:i + 1], [0], [2], orc.HoGParam(1, 4, 5, 4, 0.8))
-        assert np.array_equal(bits(feat[i:i + 1]), bits(of))
+        check_features(hog_mode, feat[i:i + 1], of)
+
+
+def test_large_roi_uses_generic_kernel(gpu_ctx, faces):
+    """S = 5*16 = 80 > 64 lanes: served by the generic reference-order kernel (sdm_hog.hip), bit-exact."""
+    images, _, _, _, x0 = faces
+    p = HoGParam(1, 5, 16, 4, 1.2)
+    gpu_ctx.set_model_geometry(len(IDS), RE, LE, [p])
+    assert gpu_ctx.hog_info(0)["fast_kernel"] is False
+    gpu_ctx.upload_images(images[:16])
+    gpu_ctx.set_sample_image_index(None)
+    gpu_ctx.set_x(x0[:16])
+    feat = gpu_ctx.hog_features(0, fetch=True)
+    of = orc.hog_features_batch(images[:16], None, x0[:16], RE, LE, orc.HoGParam(1, 5, 16, 4, 1.2), n_threads=8)
+    assert np.array_equal(bits(feat), bits(of))
+
+
+def test_fast_bins_shortcut_is_verified(gpu_ctx):
+    """The un-normalised orientation arg-max is only enabled after an exhaustive on-device check."""
+    gpu_ctx.set_model_geometry(len(IDS), RE, LE, SHIPPED)
+    info = gpu_ctx.hog_info(0)
+    assert info["fast_kernel"] is True and isinstance(info["fast_bins"], bool)
 
 
 def test_empty_patch_reports_error(gpu_ctx, faces):
@@ -297,7 +336,10 @@ def test_full_batch_properties():
     assert np.array_equal(bits(c), bits(a[perm]))                # independent of the row order
     ctx.set_sample_image_index(None)
     ctx.set_x(x0)
+    f_fast = ctx.hog_features(3, fetch=True)
+    ctx.set_hog_mode(SDM_HOG_EXACT_ORDER)
     f = ctx.hog_features(3, fetch=True)
+    assert np.abs(f - f_fast).max() <= 1e-6
     assert np.all(f[:, -1] == 1.0) and np.isfinite(f).all() and f.min() >= 0.0
     # spot-check 64 random rows of the big batch against the oracle, bit for bit
     rows = np.sort(rng.choice(n, 64, replace=False))
@@ -317,6 +359,7 @@ def test_rcr68_shapes(faces):
     ctx.upload_images(images[:24])
     ctx.set_sample_image_index(None)
     ctx.set_x(x0)
+    ctx.set_hog_mode(SDM_HOG_EXACT_ORDER)
     f = ctx.hog_features(0, fetch=True)
     of = orc.hog_features_batch(images[:24], None, x0, re, le, O_SHIPPED[2], n_threads=os.cpu_count() or 1)
     assert f.shape == (24, 27201) and np.array_equal(bits(f), bits(of))
