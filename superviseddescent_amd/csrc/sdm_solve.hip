@@ -168,109 +168,196 @@ __global__ void add_diag_kernel(float* __restrict__ G, long long ldg, int F, int
     }
 }
 
-// ---- Cholesky of one 128x128 diagonal tile (upper: G_kk = U^T U), in LDS ------------------------------
+// =====================================================================================================
+// Tile kernels of the blocked Cholesky / substitutions.  All of them distribute a 128 x 128 (or 128 x nrhs)
+// tile over 256 threads in a 16 x 16 cyclic layout -- thread (tr, tc) owns rows tr+16i and columns tc+16j in
+// REGISTERS -- and walk the 128 elimination steps with one barrier per step: the pivot row is broadcast
+// through a double-buffered LDS line, everything else is register FMAs.  (The first version kept the tile
+// in LDS with three barriers and two integer divisions per element per step: 404 us per diagonal tile,
+// profiles/r01_first_contact.log; this layout is ~10x faster.)
+// =====================================================================================================
 #define LDT 129
+
+// ---- Cholesky of one diagonal tile (upper: G_kk = U^T U) ------------------------------------------------
 __global__ void __launch_bounds__(256)
 potrf_tile_kernel(float* __restrict__ G, long long ldg, int k0, int* __restrict__ status)
 {
-    extern __shared__ __attribute__((aligned(16))) float T[];   // [128][LDT]
-    const int t = threadIdx.x;
+    __shared__ float rowbuf[2][TILE];
+    const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
     float* Gk = G + (long long)k0 * ldg + k0;
-    for (int idx = t; idx < TILE * TILE; idx += 256) {
-        const int r = idx >> 7, c = idx & 127;
-        T[r * LDT + c] = (c >= r) ? Gk[(long long)r * ldg + c] : 0.0f;
-    }
-    __syncthreads();
+    float a[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = tr + 16 * i, c = tc + 16 * j;
+            a[i][j] = (c >= r) ? Gk[(long long)r * ldg + c] : 0.0f;
+        }
     for (int j = 0; j < TILE; ++j) {
-        const float djj = T[j * LDT + j];
-        if (!(djj > 0.0f)) {
+        float* rb = rowbuf[j & 1];
+        const int oi = j >> 4;
+        const bool owner = (tr == (j & 15));
+        if (owner) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i == oi) {
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) rb[tc + 16 * jj] = a[i][jj];
+                }
+        }
+        __syncthreads();
+        const float d = rb[j];
+        if (!(d > 0.0f)) {            // uniform: every thread reads the same word
             if (t == 0) atomicOr(status, 2);
-            return;   // uniform: every thread reads the same value
+            return;
         }
-        const float d = sqrtf(djj);
-        __syncthreads();
-        for (int c = j + t; c < TILE; c += 256) T[j * LDT + c] = (c == j) ? d : T[j * LDT + c] / d;
-        __syncthreads();
-        // trailing update T[r][c] -= U[j][r] * U[j][c], j < r <= c
-        const int n = TILE - 1 - j;
-        for (int idx = t; idx < n * n; idx += 256) {
-            const int r = j + 1 + idx / n, c = j + 1 + idx % n;
-            if (c >= r) T[r * LDT + c] -= T[j * LDT + r] * T[j * LDT + c];
+        const float sd = sqrtf(d), inv = 1.0f / sd;
+        float ur[8], uc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ur[i] = (tr + 16 * i > j) ? rb[tr + 16 * i] * inv : 0.0f;   // U[j][r], rows below the pivot only
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) uc[jj] = rb[tc + 16 * jj] * inv; // U[j][c]
+        // rank-1 update of every row below the pivot; entries left of the diagonal are scratch (never read
+        // as data: a pivot row only feeds columns >= its own index), so no per-element predicate is needed
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) a[i][jj] -= ur[i] * uc[jj];
+        if (owner) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i == oi) {
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const int c = tc + 16 * jj;
+                        if (c > j) a[i][jj] = uc[jj]; else if (c == j) a[i][jj] = sd;
+                    }
+                }
         }
-        __syncthreads();
     }
-    for (int idx = t; idx < TILE * TILE; idx += 256) {
-        const int r = idx >> 7, c = idx & 127;
-        Gk[(long long)r * ldg + c] = T[r * LDT + c];   // strict lower part becomes zero
-    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = tr + 16 * i, c = tc + 16 * j;
+            Gk[(long long)r * ldg + c] = (c >= r) ? a[i][j] : 0.0f;   // strict lower part becomes zero
+        }
 }
 
-// ---- panel solve: G[k0:k0+128, tj*128 : +128] <- U_kk^-T * (same), one column per thread ------------
-__global__ void __launch_bounds__(128)
+// ---- panel solve: G[k0:k0+128, tj*128 : +128] <- U_kk^-T * (same); one workgroup per column tile ----------
+__global__ void __launch_bounds__(256)
 trsm_tile_kernel(float* __restrict__ G, long long ldg, int k0, int tile_j0)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* U = sm;                 // [128][LDT]  U_kk
-    float* Y = sm + TILE * LDT;    // [128][128]  the tile, solved in place
-    const int t = threadIdx.x;
+    float* U = sm;                      // [128][LDT]  U_kk
+    float* rowbuf = sm + TILE * LDT;    // [2][128]
+    const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
     const long long j0 = (long long)(tile_j0 + blockIdx.x) * TILE;
     const float* Gk = G + (long long)k0 * ldg + k0;
     float* B = G + (long long)k0 * ldg + j0;
-    for (int idx = t; idx < TILE * TILE; idx += 128) {
+    for (int idx = t; idx < TILE * TILE; idx += 256) {
         const int r = idx >> 7, c = idx & 127;
         U[r * LDT + c] = Gk[(long long)r * ldg + c];
-        Y[r * TILE + c] = B[(long long)r * ldg + c];
     }
+    float a[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[i][j] = B[(long long)(tr + 16 * i) * ldg + tc + 16 * j];
     __syncthreads();
-    // forward substitution with L = U^T:  y[r] = (b[r] - sum_{m<r} U[m][r] y[m]) / U[r][r]
+    // forward substitution with L = U^T, right-looking: y_r = b_r / U[r][r]; b_r' -= U[r][r'] * y_r for r' > r
     for (int r = 0; r < TILE; ++r) {
-        float s = Y[r * TILE + t];
-        for (int m = 0; m < r; ++m) s -= U[m * LDT + r] * Y[m * TILE + t];
-        Y[r * TILE + t] = s / U[r * LDT + r];
+        float* rb = rowbuf + (r & 1) * TILE;
+        const int oi = r >> 4;
+        if (tr == (r & 15)) {
+            const float inv = 1.0f / U[r * LDT + r];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i == oi) {
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) { a[i][jj] *= inv; rb[tc + 16 * jj] = a[i][jj]; }
+                }
+        }
+        __syncthreads();
+        float ur[8], yc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ur[i] = (tr + 16 * i > r) ? U[r * LDT + tr + 16 * i] : 0.0f;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) yc[jj] = rb[tc + 16 * jj];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) a[i][jj] -= ur[i] * yc[jj];
     }
-    __syncthreads();
-    for (int idx = t; idx < TILE * TILE; idx += 128) {
-        const int r = idx >> 7, c = idx & 127;
-        B[(long long)r * ldg + c] = Y[r * TILE + c];
-    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) B[(long long)(tr + 16 * i) * ldg + tc + 16 * j] = a[i][j];
 }
 
 // ---- back substitution ------------------------------------------------------------------------------
-// R[k0:k0+128, 0:nrhs] = U_kk^-1 * Y_k,  Y_k = G[k0:k0+128, rhs0:rhs0+nrhs]
+// R[k0:k0+128, 0:nrhs] = U_kk^-1 * Y_k,  Y_k = G[k0:k0+128, rhs0:rhs0+nrhs]; nrhs = 16*NJ <= 144
 __global__ void __launch_bounds__(256)
 backsolve_tile_kernel(const float* __restrict__ G, long long ldg, int k0, int rhs0, int nrhs,
                       float* __restrict__ R, long long ldr)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* U = sm;                 // [128][LDT]
-    float* Y = sm + TILE * LDT;    // [128][nrhs]
-    const int t = threadIdx.x;
+    float* U = sm;                      // [128][LDT]
+    float* rowbuf = sm + TILE * LDT;    // [2][144]
+    const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
+    const int NJ = nrhs >> 4;
     const float* Gk = G + (long long)k0 * ldg + k0;
     const float* Yg = G + (long long)k0 * ldg + rhs0;
     for (int idx = t; idx < TILE * TILE; idx += 256) {
         const int r = idx >> 7, c = idx & 127;
         U[r * LDT + c] = Gk[(long long)r * ldg + c];
     }
-    for (int idx = t; idx < TILE * nrhs; idx += 256) {
-        const int r = idx / nrhs, c = idx - r * nrhs;
-        Y[r * nrhs + c] = Yg[(long long)r * ldg + c];
-    }
+    float y[8][9];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) y[i][j] = (j < NJ) ? Yg[(long long)(tr + 16 * i) * ldg + tc + 16 * j] : 0.0f;
     __syncthreads();
-    if (t < nrhs) {
-        for (int r = TILE - 1; r >= 0; --r) {
-            float s = Y[r * nrhs + t];
-            for (int m = r + 1; m < TILE; ++m) s -= U[r * LDT + m] * Y[m * nrhs + t];
-            Y[r * nrhs + t] = s / U[r * LDT + r];
+    // x_r = y_r / U[r][r]; y_r' -= U[r'][r] * x_r for r' < r   (r descending)
+    for (int r = TILE - 1; r >= 0; --r) {
+        float* rb = rowbuf + (r & 1) * 144;
+        const int oi = r >> 4;
+        if (tr == (r & 15)) {
+            const float inv = 1.0f / U[r * LDT + r];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i == oi) {
+#pragma unroll
+                    for (int jj = 0; jj < 9; ++jj)
+                        if (jj < NJ) { y[i][jj] *= inv; rb[tc + 16 * jj] = y[i][jj]; }
+                }
+        }
+        __syncthreads();
+        float ur[8], xc[9];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ur[i] = (tr + 16 * i < r) ? U[(tr + 16 * i) * LDT + r] : 0.0f;
+#pragma unroll
+        for (int jj = 0; jj < 9; ++jj) xc[jj] = (jj < NJ) ? rb[tc + 16 * jj] : 0.0f;
+        if (NJ <= 3) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) y[i][jj] -= ur[i] * xc[jj];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 9; ++jj) y[i][jj] -= ur[i] * xc[jj];
         }
     }
-    __syncthreads();
-    for (int idx = t; idx < TILE * nrhs; idx += 256) {
-        const int r = idx / nrhs, c = idx - r * nrhs;
-        R[(long long)(k0 + r) * ldr + c] = Y[r * nrhs + c];
-    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+            if (j < NJ) R[(long long)(k0 + tr + 16 * i) * ldr + tc + 16 * j] = y[i][j];
 }
 
-// Y_i -= U_ik * R_k for every tile row i < k  (one block per i)
+// Y_i -= U_ik * R_k for every tile row i < k  (one workgroup per i)
 __global__ void __launch_bounds__(256)
 backsolve_update_kernel(float* __restrict__ G, long long ldg, int k0, int rhs0, int nrhs,
                         const float* __restrict__ R, long long ldr)
@@ -278,7 +365,8 @@ backsolve_update_kernel(float* __restrict__ G, long long ldg, int k0, int rhs0, 
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* U = sm;                 // [128][LDT]  U_ik
     float* Rk = sm + TILE * LDT;   // [128][nrhs]
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
+    const int NJ = nrhs >> 4;
     const long long i0 = (long long)blockIdx.x * TILE;
     const float* Uik = G + i0 * ldg + k0;
     float* Yi = G + i0 * ldg + rhs0;
@@ -291,12 +379,34 @@ backsolve_update_kernel(float* __restrict__ G, long long ldg, int k0, int rhs0, 
         Rk[r * nrhs + c] = R[(long long)(k0 + r) * ldr + c];
     }
     __syncthreads();
-    for (int idx = t; idx < TILE * nrhs; idx += 256) {
-        const int r = idx / nrhs, c = idx - r * nrhs;
-        float s = 0.0f;
-        for (int m = 0; m < TILE; ++m) s += U[r * LDT + m] * Rk[m * nrhs + c];
-        Yi[(long long)r * ldg + c] -= s;
+    float acc[8][9];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 9; ++j) acc[i][j] = 0.0f;
+    for (int m = 0; m < TILE; ++m) {
+        float ur[8], xc[9];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ur[i] = U[(tr + 16 * i) * LDT + m];
+#pragma unroll
+        for (int jj = 0; jj < 9; ++jj) xc[jj] = (jj < NJ) ? Rk[m * nrhs + tc + 16 * jj] : 0.0f;
+        if (NJ <= 3) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) acc[i][jj] += ur[i] * xc[jj];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 9; ++jj) acc[i][jj] += ur[i] * xc[jj];
+        }
     }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+            if (j < NJ) Yi[(long long)(tr + 16 * i) * ldg + tc + 16 * j] -= acc[i][j];
 }
 
 }  // namespace
@@ -332,12 +442,11 @@ void sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrh
     const int Tf = (F + TILE - 1) / TILE;          // factor tiles
     const int ncols = rhs0 + TILE;                 // factor tiles + one RHS tile column
     const int T = ncols / TILE;
-    const size_t lds_potrf = (size_t)TILE * LDT * sizeof(float);
-    const size_t lds_trsm = ((size_t)TILE * LDT + (size_t)TILE * TILE) * sizeof(float);
+    const size_t lds_trsm = ((size_t)TILE * LDT + 2 * TILE) * sizeof(float);
+    const size_t lds_backs = ((size_t)TILE * LDT + 2 * 144) * sizeof(float);
     const size_t lds_back = ((size_t)TILE * LDT + (size_t)TILE * nrhs) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)potrf_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)trsm_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)backsolve_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)backsolve_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -345,17 +454,17 @@ void sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrh
     }
     for (int k = 0; k < Tf; ++k) {
         const int k0 = k * TILE;
-        hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(256), lds_potrf, stream, G, ldg, k0, status);
+        hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(256), 0, stream, G, ldg, k0, status);
         const int ntr = T - (k + 1);
         if (ntr > 0) {
-            hipLaunchKernelGGL(trsm_tile_kernel, dim3(ntr), dim3(128), lds_trsm, stream, G, ldg, k0, k + 1);
+            hipLaunchKernelGGL(trsm_tile_kernel, dim3(ntr), dim3(256), lds_trsm, stream, G, ldg, k0, k + 1);
             // trailing update of tiles (ti >= k+1, tj >= ti) from the freshly solved panel rows
             sdm_launch_syrk_tn(G + (long long)k0 * ldg, ldg, TILE, ncols, G, ldg, -1.0f, 1, k + 1, stream);
         }
     }
     for (int k = Tf - 1; k >= 0; --k) {
         const int k0 = k * TILE;
-        hipLaunchKernelGGL(backsolve_tile_kernel, dim3(1), dim3(256), lds_back, stream, G, ldg, k0, rhs0, nrhs,
+        hipLaunchKernelGGL(backsolve_tile_kernel, dim3(1), dim3(256), lds_backs, stream, G, ldg, k0, rhs0, nrhs,
                            R_out, ldr);
         if (k > 0)
             hipLaunchKernelGGL(backsolve_update_kernel, dim3(k), dim3(256), lds_back, stream, G, ldg, k0, rhs0,
