@@ -146,6 +146,14 @@ int sdm_allreduce_gram_rhs(sdm_ctx* ctx);
  * PartialPivLU: the regularised Gram matrix is SPD).  Stores R as the level's regressor; R_host may be NULL. */
 int sdm_solve(sdm_ctx* ctx, int level, int reg_type, float reg_param, int regularise_last_row,
               long long n_train_global, float* R_host, float* lambda_out);
+/* Stand-alone normal equations for host data (any projection function, not only HOG): what
+ * LinearRegressor<Solver>::learn hands to Solver::solve(data, labels, regulariser)
+ * (regressors.hpp:199-234, 345-350).  A is n_rows x n_features, b is n_rows x n_outputs (<= 144),
+ * R_host receives n_features x n_outputs.  Gram/RHS build, regulariser and Cholesky run on the GPU.
+ * Does not need sdm_set_model_geometry. */
+int sdm_solve_normal_equations(sdm_ctx* ctx, const float* A_host, int n_rows, int n_features,
+                               const float* b_host, int n_outputs, int reg_type, float reg_param,
+                               int regularise_last_row, float* R_host, float* lambda_out);
 /* Convenience: the four calls above + sdm_apply. */
 int sdm_train_level(sdm_ctx* ctx, int level, int reg_type, float reg_param, int regularise_last_row,
                     long long n_train_global);

@@ -97,6 +97,13 @@ double orc_get_ied(const float *x, int L, const int *re, int nre, const int *le,
     }
 }
 
+/* InterEyeDistanceNormalisation::operator() for N rows (model.hpp:94-98): out[n] = (float)(1.0 / ied(row n)) */
+void orc_ied_norm_batch(const float *x, int N, int L, const int *re, int nre, const int *le, int nle, float *out)
+{
+    int n;
+    for (n = 0; n < N; ++n) out[n] = (float)(1.0 / orc_get_ied(x + (size_t)n * 2 * L, L, re, nre, le, nle));
+}
+
 /* ------------------------------------------------------------------------------------
  * cv::resize, CV_8UC1, INTER_LINEAR  (called at adaptive_vlhog.hpp:155).
  * Fixed-point bilinear, INTER_RESIZE_COEF_BITS = 11:

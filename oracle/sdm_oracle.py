@@ -334,11 +334,12 @@ class InterEyeDistanceNormalisation:
         self.right_eye, self.left_eye = list(right_eye), list(left_eye)
 
     def __call__(self, params: np.ndarray) -> np.ndarray:
-        params = np.atleast_2d(np.asarray(params, np.float32))
-        out = np.empty_like(params)
-        for i in range(params.shape[0]):
-            out[i, :] = np.float32(1.0 / get_ied(params[i], self.right_eye, self.left_eye))
-        return out
+        params = np.ascontiguousarray(np.atleast_2d(np.asarray(params, np.float32)))
+        N, twoL = params.shape
+        re, le = _ints(self.right_eye), _ints(self.left_eye)
+        n = np.empty(N, np.float32)
+        lib().orc_ied_norm_batch(_p(params), N, twoL // 2, _p(re, ctypes.c_int), re.size, _p(le, ctypes.c_int), le.size, _p(n))
+        return np.repeat(n[:, None], twoL, axis=1)
 
 
 class SupervisedDescentOptimiser:

@@ -663,6 +663,40 @@ int sdm_solve(sdm_ctx* c, int level, int reg_type, float reg_param, int regulari
     return SDM_OK;
 }
 
+int sdm_solve_normal_equations(sdm_ctx* c, const float* A, int N, int F, const float* b, int M, int reg_type,
+                               float reg_param, int regularise_last_row, float* R_host, float* lambda_out)
+{
+    if (!c || !A || !b || !R_host || N <= 0 || F <= 0 || M <= 0) return fail(SDM_ERR_INVALID, "bad arguments");
+    if (M > 144) return fail(SDM_ERR_INVALID, "at most 144 outputs supported");
+    if (reg_type != SDM_REG_MANUAL && reg_type != SDM_REG_MATRIX_NORM) return fail(SDM_ERR_INVALID, "bad regulariser type");
+    HIP_TRY(hipSetDevice(c->device));
+    const int Fp = round_up(F, 128), ncols = Fp + 128, Mp = Mp_of(M);
+    DevBuf<float> dA, dG, dR; DevBuf<double> dfro;
+    int rc;
+    if ((rc = dA.ensure((size_t)N * ncols, true, c->stream)) || (rc = dG.ensure((size_t)ncols * ncols)) ||
+        (rc = dR.ensure((size_t)Fp * Mp)) || (rc = dfro.ensure((size_t)F + 1)))
+        return rc;
+    HIP_TRY(hipMemcpy2DAsync(dA.p, (size_t)ncols * sizeof(float), A, (size_t)F * sizeof(float), (size_t)F * sizeof(float), N,
+                             hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpy2DAsync(dA.p + Fp, (size_t)ncols * sizeof(float), b, (size_t)M * sizeof(float), (size_t)M * sizeof(float), N,
+                             hipMemcpyHostToDevice, c->stream));
+    { Timer t(c, SDM_T_GRAM); sdm_launch_syrk_tn(dA.p, ncols, N, ncols, dG.p, ncols, 1.0f, 0, 0, c->stream); }
+    {
+        Timer t(c, SDM_T_REG);
+        if (reg_type == SDM_REG_MATRIX_NORM) sdm_launch_fro2_upper(dG.p, ncols, F, dfro.p, c->stream);
+        sdm_launch_add_diag(dG.p, ncols, F, dfro.p + F, reg_type, reg_param, N, regularise_last_row, c->lambda_dev.p, c->stream);
+    }
+    { Timer t(c, SDM_T_FACTOR); sdm_launch_cholesky_solve(dG.p, ncols, F, Fp, Mp, dR.p, Mp, nullptr, c->status.p, c->stream); }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy2DAsync(R_host, (size_t)M * sizeof(float), dR.p, (size_t)Mp * sizeof(float), (size_t)M * sizeof(float), F,
+                             hipMemcpyDeviceToHost, c->stream));
+    if (lambda_out) HIP_TRY(hipMemcpyAsync(lambda_out, c->lambda_dev.p, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    rc = check_status(c);
+    dA.release(); dG.release(); dR.release(); dfro.release();
+    return rc;
+}
+
 int sdm_train_level(sdm_ctx* c, int level, int reg_type, float reg_param, int regularise_last_row,
                     long long n_train_global)
 {

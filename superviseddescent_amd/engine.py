@@ -216,6 +216,17 @@ class Context:
                                   n_train_global, _fp(R) if fetch else None, ctypes.byref(lam)))
         return R, lam.value
 
+    def solve_normal_equations(self, data: np.ndarray, labels: np.ndarray, reg_type: int = 0, reg_param: float = 0.0,
+                               regularise_last_row: bool = True):
+        """Solver::solve(data, labels, regulariser) of regressors.hpp:199-234 on the GPU, for host matrices."""
+        A = np.ascontiguousarray(data, np.float32)
+        b = np.ascontiguousarray(labels, np.float32)
+        R = np.empty((A.shape[1], b.shape[1]), np.float32)
+        lam = ctypes.c_float(0.0)
+        check(self._lib.sdm_solve_normal_equations(self._h, _fp(A), A.shape[0], A.shape[1], _fp(b), b.shape[1], reg_type,
+                                                   reg_param, int(regularise_last_row), _fp(R), ctypes.byref(lam)))
+        return R, lam.value
+
     def train_level(self, level: int, reg_type: int, reg_param: float, regularise_last_row: bool,
                     n_train_global: int = 0):
         check(self._lib.sdm_train_level(self._h, level, reg_type, reg_param, int(regularise_last_row),
@@ -333,10 +344,12 @@ class SupervisedDescentOptimiser:
     once per level and every rank solves the identical system (see parallel.py)."""
 
     def __init__(self, regressors: List[LinearRegressor], normalisation: Optional[InterEyeDistanceNormalisation] = None,
-                 device: int = 0, stream: Optional[int] = None):
+                 device: int = 0, stream: Optional[int] = None, ctx=None):
         self.regressors = regressors
         self.normalisation = normalisation
-        self.ctx = Context(device, stream)
+        # ``ctx``: an object with Context's methods; the CPU tests of the data-parallel logic inject one built on
+        # the oracle, the product path always builds the HIP context here
+        self.ctx = ctx if ctx is not None else Context(device, stream)
         self._bound = None
 
     def _bind(self, projection: HogTransform):

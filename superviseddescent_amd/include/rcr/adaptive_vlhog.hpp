@@ -1,0 +1,152 @@
+// rcr/adaptive_vlhog.hpp -- HoGParam and the HogTransform projection functor (counterpart of the reference's
+// include/rcr/adaptive_vlhog.hpp:41-60, 70-195; VlHogVariant from include/rcr/hog.h:72).
+//
+// Same constructor and call signature as the reference.  The arithmetic (IED-adaptive ROI, zero-padded crop,
+// cv::resize 8U bilinear, VLFeat HOG, Matlab-order flatten, bias) runs in the gfx950 kernel
+// superviseddescent_amd/csrc/sdm_hog_fast.hip through the C-ABI:
+//   * inside SupervisedDescentOptimiser::{train,test,predict} the whole batch of one cascade level is ONE
+//     kernel launch (detail::BatchedBackend in rcr/model.hpp) and operator() is never called;
+//   * operator()(parameters, level, training_index) itself -- the reference's per-sample entry point -- runs the
+//     same kernel for a batch of one row and returns the 1 x F feature row.
+#pragma once
+
+#ifndef ADAPTIVE_VLHOG_HPP_
+#define ADAPTIVE_VLHOG_HPP_
+
+#include "rcr/helpers.hpp"
+#include "sdm_cv/core.hpp"
+#include "superviseddescent/hip_backend.hpp"
+
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+/** HOG variants, numbered as in VLFeat (reference hog.h:72). */
+enum VlHogVariant { VlHogVariantDalalTriggs, VlHogVariantUoctti };
+
+namespace rcr {
+
+struct HoGParam {
+    VlHogVariant vlhog_variant;
+    int num_cells;
+    int cell_size;
+    int num_bins;
+    float relative_patch_size;   ///< patch size in percent of the inter-eye distance of the current estimate
+
+    template <class Archive>
+    void serialize(Archive& ar)
+    {
+        ar(vlhog_variant, num_cells, cell_size, num_bins, relative_patch_size);   // reference :58
+    }
+};
+
+namespace detail {
+
+// single-channel u8 view of an image; BGR images are converted ONCE per image with OpenCV's fixed-point
+// weights (B*1868 + G*9617 + R*4899 + 8192) >> 14 (the reference converts per sample and per level,
+// adaptive_vlhog.hpp:114-120)
+inline cv::Mat to_gray(const cv::Mat& img)
+{
+    if (img.channels() == 1) return img;
+    cv::Mat g(img.rows, img.cols, CV_8UC1);
+    for (int r = 0; r < img.rows; ++r) {
+        const uint8_t* s = img.ptr<uint8_t>(r);
+        uint8_t* d = g.ptr<uint8_t>(r);
+        for (int c = 0; c < img.cols; ++c) d[c] = (uint8_t)((s[3 * c] * 1868 + s[3 * c + 1] * 9617 + s[3 * c + 2] * 4899 + 8192) >> 14);
+    }
+    return g;
+}
+
+// device state shared by all copies of one HogTransform (the optimiser copies the functor freely)
+struct HogDeviceState {
+    std::unique_ptr<superviseddescent::hip::Handle> handle;
+    std::mutex mu;
+    bool images_uploaded = false;
+};
+
+inline void configure(superviseddescent::hip::Handle& h, const std::vector<cv::Mat>& images,
+                      const std::vector<HoGParam>& hog_params, const std::vector<std::string>& landmark_ids,
+                      const std::vector<std::string>& right_eye_ids, const std::vector<std::string>& left_eye_ids,
+                      bool upload_images)
+{
+    using superviseddescent::hip::check;
+    const std::vector<int> re = positions_of(landmark_ids, right_eye_ids, "rightEyeIdentifiers");
+    const std::vector<int> le = positions_of(landmark_ids, left_eye_ids, "leftEyeIdentifiers");
+    std::vector<sdm_hog_param> lv;
+    for (const auto& p : hog_params)
+        lv.push_back(sdm_hog_param{p.vlhog_variant == VlHogVariantUoctti ? SDM_VARIANT_UOCTTI : SDM_VARIANT_DALALTRIGGS,
+                                   p.num_cells, p.cell_size, p.num_bins, p.relative_patch_size});
+    check(sdm_set_model_geometry(h.get(), (int)landmark_ids.size(), re.data(), (int)re.size(), le.data(), (int)le.size(),
+                                 (int)lv.size(), lv.data()),
+          "sdm_set_model_geometry");
+    if (upload_images) {
+        std::vector<cv::Mat> gray;
+        std::vector<const uint8_t*> ptrs;
+        std::vector<int> w, hh, st;
+        for (const auto& im : images) {
+            gray.push_back(to_gray(im));
+            ptrs.push_back(gray.back().ptr<uint8_t>(0));
+            w.push_back(gray.back().cols);
+            hh.push_back(gray.back().rows);
+            st.push_back((int)gray.back().step());
+        }
+        check(sdm_upload_images_u8(h.get(), ptrs.data(), w.data(), hh.data(), st.data(), (int)ptrs.size()), "sdm_upload_images_u8");
+    }
+}
+
+}  // namespace detail
+
+class HogTransform {
+public:
+    /** Same arguments as the reference (:92).  `images` must outlive the transform (a reference is stored). */
+    HogTransform(const std::vector<cv::Mat>& images, std::vector<HoGParam> hog_params, std::vector<std::string> modelLandmarksList,
+                 std::vector<std::string> rightEyeIdentifiers, std::vector<std::string> leftEyeIdentifiers)
+        : images(images), hog_params(hog_params), modelLandmarksList(modelLandmarksList),
+          rightEyeIdentifiers(rightEyeIdentifiers), leftEyeIdentifiers(leftEyeIdentifiers), state(std::make_shared<detail::HogDeviceState>())
+    {
+    }
+
+    /** Features of ONE sample at its current landmark estimate (reference :109-185): 1 x (L*C*C*D + 1). */
+    cv::Mat operator()(cv::Mat parameters, size_t regressorLevel, int trainingIndex = 0)
+    {
+        using superviseddescent::hip::check;
+        if (parameters.rows != 1) throw std::runtime_error("HogTransform: parameters must be a single row");
+        std::lock_guard<std::mutex> lock(state->mu);   // the device handle is not thread-safe
+        if (!state->handle) state->handle.reset(new superviseddescent::hip::Handle(0));
+        sdm_ctx* c = state->handle->get();
+        if (!state->images_uploaded) {
+            detail::configure(*state->handle, images, hog_params, modelLandmarksList, rightEyeIdentifiers, leftEyeIdentifiers, true);
+            state->images_uploaded = true;
+        }
+        cv::Mat row = parameters.isContinuous() ? parameters : parameters.clone();
+        check(sdm_set_sample_image_index(c, &trainingIndex, 1), "sdm_set_sample_image_index");
+        check(sdm_set_x(c, row.ptr<float>(0), 1), "sdm_set_x");
+        const int F = sdm_feature_dim(c, (int)regressorLevel);
+        check(F, "sdm_feature_dim");
+        cv::Mat features(1, F, CV_32FC1);
+        check(sdm_hog_features(c, (int)regressorLevel, features.ptr<float>(0)), "sdm_hog_features");
+        return features;
+    }
+
+    // read access for the batched backend
+    const std::vector<cv::Mat>& get_images() const { return images; }
+    const std::vector<HoGParam>& get_hog_params() const { return hog_params; }
+    const std::vector<std::string>& get_landmark_ids() const { return modelLandmarksList; }
+    const std::vector<std::string>& get_right_eye_ids() const { return rightEyeIdentifiers; }
+    const std::vector<std::string>& get_left_eye_ids() const { return leftEyeIdentifiers; }
+    /** Optional sample -> image map for batched calls (perturbed rows share an image, reference rcr-train.cpp:421-431).
+     *  Empty = row i uses image i. */
+    std::vector<int> sample_image_index;
+
+private:
+    const std::vector<cv::Mat>& images;
+    std::vector<HoGParam> hog_params;
+    std::vector<std::string> modelLandmarksList;
+    std::vector<std::string> rightEyeIdentifiers;
+    std::vector<std::string> leftEyeIdentifiers;
+    std::shared_ptr<detail::HogDeviceState> state;
+};
+
+}  // namespace rcr
+#endif /* ADAPTIVE_VLHOG_HPP_ */

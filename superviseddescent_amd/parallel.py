@@ -1,0 +1,76 @@
+"""Data-parallel scaling of the hot path: one process per GPU, ``torch.distributed`` (backend "nccl" = RCCL over
+xGMI on ROCm; "gloo" in the CPU tests).
+
+* **detect** shards by sample and needs no collective at all (rows are independent);
+* **train** needs exactly one exchange per cascade level: every rank builds the Gram matrix ``A_r^T A_r`` and the
+  right-hand side ``A_r^T b_r`` of ITS rows, the two are summed over ranks in one all-reduce, and every rank then
+  solves the identical regularised system (no broadcast of the regressor needed).  ``MatrixNorm`` regularisation
+  uses the norm of the GLOBAL Gram matrix and the GLOBAL row count, so the result equals single-process training
+  on the concatenated rows up to summation order (reference: include/superviseddescent/regressors.hpp:126-148,
+  199-234; the reference itself is single-process).
+
+The C-ABI exposes the exchange as a callback (``sdm_set_allreduce``); this module supplies the torch one.
+"""
+from __future__ import annotations
+
+from typing import Callable, Tuple
+
+import numpy as np
+
+
+def shard_range(n_rows: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Contiguous block of rows owned by ``rank`` (sizes differ by at most one)."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank out of range")
+    base, extra = divmod(n_rows, world_size)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+class _DeviceSpan:
+    """Zero-copy view of engine-owned HBM for torch (``__cuda_array_interface__``, also honoured on ROCm)."""
+
+    def __init__(self, ptr: int, count: int):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f4", "data": (int(ptr), False),
+                                         "version": 3, "strides": None}
+
+
+def make_torch_allreduce(device_index: int) -> Callable[[int, int, int], int]:
+    """Callback for ``Context.set_allreduce``: sums ``count`` floats at ``ptr`` over all ranks in place.
+
+    The engine context must run on torch's current stream of that device (``Context(device, stream=
+    torch.cuda.current_stream().cuda_stream)``) so that the collective is ordered after the Gram kernel."""
+    import torch
+    import torch.distributed as dist
+
+    def allreduce(ptr: int, count: int, _stream: int) -> int:
+        t = torch.as_tensor(_DeviceSpan(ptr, count), device=torch.device("cuda", device_index))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return 0
+
+    return allreduce
+
+
+def make_host_allreduce() -> Callable[[np.ndarray], None]:
+    """All-reduce for host buffers (gloo): used by the CPU tests of the data-parallel logic."""
+    import torch
+    import torch.distributed as dist
+
+    def allreduce(buf: np.ndarray) -> None:
+        t = torch.from_numpy(buf)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+    return allreduce
+
+
+def global_row_count(n_local: int) -> int:
+    """Sum of the per-rank row counts (the N of ``MatrixNorm``'s lambda = param * ||G||_F / N)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return n_local
+    t = torch.tensor([n_local], dtype=torch.int64)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())

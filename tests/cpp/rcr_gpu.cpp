@@ -1,0 +1,113 @@
+// GPU test driver for the C++ header layer (run by tests/test_cpp_layer.py on the MI355X box).
+// Reads a scenario written by the Python test (raw little-endian arrays), runs it through the reference-shaped
+// C++ API -- SupervisedDescentOptimiser<LinearRegressor<VerbosePartialPivLUSolver>, InterEyeDistanceNormalisation>
+// ::train / test, rcr::detection_model::detect, save/load_detection_model, HogTransform::operator() -- and writes
+// the results back for comparison with the Python host layer and the CPU oracle.
+//   usage: rcr_gpu <dir>
+#include "rcr/model.hpp"
+
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+using cv::Mat;
+using namespace superviseddescent;
+
+template <class T>
+static std::vector<T> read_all(const std::string& path)
+{
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f) throw std::runtime_error("cannot open " + path);
+    const size_t n = (size_t)f.tellg();
+    f.seekg(0);
+    std::vector<T> v(n / sizeof(T));
+    f.read((char*)v.data(), (std::streamsize)n);
+    return v;
+}
+static void write_mat(const std::string& path, const Mat& m)
+{
+    std::ofstream f(path, std::ios::binary);
+    for (int r = 0; r < m.rows; ++r) f.write((const char*)m.ptr<float>(r), (std::streamsize)m.cols * 4);
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 2) { std::fprintf(stderr, "usage: rcr_gpu <dir>\n"); return 2; }
+    const std::string dir = argv[1];
+    try {
+        // meta: n_images H W N L n_levels, then per level: variant cells cell bins rel, then ids..., right eye ids, left eye ids
+        std::ifstream meta(dir + "/meta.txt");
+        int n_img, H, W, N, L, n_levels, n_test;
+        meta >> n_img >> H >> W >> N >> L >> n_levels >> n_test;
+        std::vector<rcr::HoGParam> hog_params;
+        for (int l = 0; l < n_levels; ++l) {
+            int v, c, cs, b; float rel;
+            meta >> v >> c >> cs >> b >> rel;
+            hog_params.push_back({v ? VlHogVariantUoctti : VlHogVariantDalalTriggs, c, cs, b, rel});
+        }
+        std::vector<std::string> ids(L), re(2), le(2);
+        for (auto& s : ids) meta >> s;
+        for (auto& s : re) meta >> s;
+        for (auto& s : le) meta >> s;
+        int reg_type; float reg_param; int reg_last;
+        meta >> reg_type >> reg_param >> reg_last;
+
+        auto img_bytes = read_all<uint8_t>(dir + "/images.u8");
+        std::vector<Mat> images;
+        for (int i = 0; i < n_img; ++i) images.push_back(Mat(H, W, CV_8UC1, img_bytes.data() + (size_t)i * H * W));
+        auto x0v = read_all<float>(dir + "/x0.f32");
+        auto xsv = read_all<float>(dir + "/xstar.f32");
+        auto idx = read_all<int>(dir + "/img_index.i32");
+        Mat x0(N, 2 * L, CV_32FC1, x0v.data()), xstar(N, 2 * L, CV_32FC1, xsv.data());
+
+        // ---- train (reference rcr-train.cpp:439-461) ----
+        using LR = LinearRegressor<VerbosePartialPivLUSolver>;
+        std::vector<LR> regressors;
+        for (int l = 0; l < n_levels; ++l)
+            regressors.emplace_back(LR(Regulariser(reg_type ? Regulariser::RegularisationType::MatrixNorm : Regulariser::RegularisationType::Manual,
+                                                   reg_param, reg_last != 0)));
+        SupervisedDescentOptimiser<LR, rcr::InterEyeDistanceNormalisation> model(regressors, rcr::InterEyeDistanceNormalisation(ids, re, le));
+        rcr::HogTransform hog(images, hog_params, ids, re, le);
+        hog.sample_image_index = idx;
+        int epochs = 0;
+        Mat last;
+        model.train(xstar, x0, Mat(), hog, [&](const Mat& cur) { ++epochs; last = cur; });
+        if (epochs != n_levels) throw std::runtime_error("callback count");
+        write_mat(dir + "/cpp_x_train.f32", last);
+        for (int l = 0; l < n_levels; ++l) write_mat(dir + "/cpp_R" + std::to_string(l) + ".f32", model.get_regressors()[l].x);
+        write_mat(dir + "/cpp_x_test.f32", model.test(x0, Mat(), hog));
+
+        // ---- save / load / detect (reference model.hpp:132-157, 192-219) ----
+        auto meanv = read_all<float>(dir + "/mean.f32");
+        Mat mean(1, 2 * L, CV_32FC1, meanv.data());
+        rcr::detection_model dm(model, mean, ids, hog_params, re, le);
+        rcr::save_detection_model(dm, dir + "/cpp_model.bin");
+        rcr::detection_model loaded = rcr::load_detection_model(dir + "/cpp_model.bin");
+        auto boxes = read_all<int>(dir + "/test_boxes.i32");   // n_test x 5: image index, x, y, w, h
+        std::vector<cv::Rect> rects;
+        std::vector<int> bidx;
+        for (int i = 0; i < n_test; ++i) { bidx.push_back(boxes[5 * i]); rects.emplace_back(boxes[5 * i + 1], boxes[5 * i + 2], boxes[5 * i + 3], boxes[5 * i + 4]); }
+        write_mat(dir + "/cpp_detect_batch.f32", loaded.detect_batch(images, rects, bidx));
+        auto lms = loaded.detect(images[bidx[0]], rects[0]);
+        write_mat(dir + "/cpp_detect_single.f32", rcr::to_row(lms));
+        if (lms[0].name != ids[0]) throw std::runtime_error("landmark names lost");
+
+        // ---- per-sample projection call, the reference's HogTransform::operator() ----
+        rcr::HogTransform hog1(images, hog_params, ids, re, le);
+        write_mat(dir + "/cpp_feat_row.f32", hog1(x0.row(3), 1, idx[3]));
+
+        // ---- stand-alone device solver on host matrices ----
+        auto Av = read_all<float>(dir + "/lr_A.f32");
+        auto bv = read_all<float>(dir + "/lr_b.f32");
+        const int lrF = 37, lrM = 5, lrN = (int)Av.size() / lrF;
+        LR lr(Regulariser(Regulariser::RegularisationType::Manual, 0.5f, true));
+        lr.learn(Mat(lrN, lrF, CV_32FC1, Av.data()), Mat(lrN, lrM, CV_32FC1, bv.data()));
+        write_mat(dir + "/cpp_lr_x.f32", lr.x);
+        std::printf("rcr_gpu ok\n");
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "rcr_gpu failed: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,136 @@
+"""Data-parallel training logic with world_size 2 on CPU (gloo): the per-level exchange
+(sum of per-rank Gram/RHS, global row count for MatrixNorm) must reproduce single-process training on the
+concatenated rows.  The GPU kernels cannot run here, so the per-rank compute is served by an oracle-backed
+stand-in with the same interface as superviseddescent_amd.Context; what is under test is the host
+orchestration in engine.SupervisedDescentOptimiser.train + parallel.py."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PARAMS = [(1, 3, 12, 4, 0.9), (1, 3, 9, 4, 0.6)]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class OracleContext:
+    """CPU stand-in for engine.Context built on the oracle (tests only)."""
+
+    def __init__(self):
+        from oracle import sdm_oracle as orc
+        self.orc = orc
+        self.allreduce, self.world = None, 1
+
+    def set_model_geometry(self, L, re, le, params):
+        self.L, self.re, self.le = L, list(re), list(le)
+        self.params = [self.orc.HoGParam(p.vlhog_variant, p.num_cells, p.cell_size, p.num_bins, p.relative_patch_size) for p in params]
+
+    def upload_images(self, images): self.images = np.asarray(images)
+    def set_sample_image_index(self, idx): self.idx = idx
+    def set_x(self, x): self.x = np.asarray(x, np.float32).copy(); self.N = self.x.shape[0]
+    def set_targets(self, xs): self.xs = np.asarray(xs, np.float32)
+    def get_x(self): return self.x.copy()
+    def set_allreduce(self, fn, world): self.allreduce, self.world = fn, world
+
+    def hog_features(self, level, fetch=False):
+        self.A = self.orc.hog_features_batch(self.images, self.idx, self.x, self.re, self.le, self.params[level], n_threads=2)
+
+    def gram_rhs(self, level):
+        n = self.orc.InterEyeDistanceNormalisation(self.re, self.le)(self.x)
+        b = ((self.x - self.xs) * n).astype(np.float32)
+        F = self.A.shape[1]
+        self.G = np.zeros((F, F + b.shape[1]), np.float32)
+        self.G[:, :F] = self.A.T @ self.A
+        self.G[:, F:] = self.A.T @ b
+
+    def allreduce_gram_rhs(self):
+        if self.allreduce is not None and self.world > 1:
+            self.allreduce(self.G)
+
+    def solve(self, level, reg_type, reg_param, last_row, n_global=0, fetch=True):
+        from scipy.linalg import cho_factor, cho_solve
+        F = self.G.shape[0]
+        G, B = self.G[:, :F].copy(), self.G[:, F:]
+        lam = self.orc.Regulariser(reg_type, reg_param, last_row).get_lambda(G, n_global or self.N)
+        d = np.full(F, lam, np.float32)
+        if not last_row:
+            d[-1] = 0
+        G[np.diag_indices(F)] += d
+        self.R = cho_solve(cho_factor(G.astype(np.float64)), B.astype(np.float64)).astype(np.float32)
+        return self.R, float(lam)
+
+    def apply(self, level):
+        n = self.orc.InterEyeDistanceNormalisation(self.re, self.le)(self.x)
+        self.x = (self.x - (self.A @ self.R).astype(np.float32) * (np.float32(1.0) / n)).astype(np.float32)
+
+
+def _make_data():
+    from superviseddescent_amd import ibug, synth
+    ids = ibug.RCR22_IDS
+    images, boxes, gt = synth.make_faces(24, seed=77)
+    x_star, x0, idx = synth.make_samples(boxes, gt, ids, n_perturb=2, seed=78)
+    return ids, images, x_star, x0, idx
+
+
+def _train(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from superviseddescent_amd import HoGParam, HogTransform, LinearRegressor, Regulariser, ibug, parallel
+    from superviseddescent_amd.engine import SupervisedDescentOptimiser
+    ids, images, x_star, x0, idx = _make_data()
+    a, b = 0, x0.shape[0]
+    allreduce = None
+    if world > 1:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        a, b = parallel.shard_range(x0.shape[0], rank, world)
+        allreduce = parallel.make_host_allreduce()
+    n_global = parallel.global_row_count(b - a) if world > 1 else b - a
+    sdo = SupervisedDescentOptimiser([LinearRegressor(Regulariser(1, 1.5, False)) for _ in PARAMS], ctx=OracleContext())
+    hog = HogTransform(images, [HoGParam(*p) for p in PARAMS], ids, ibug.RIGHT_EYE_IDS, ibug.LEFT_EYE_IDS, idx[a:b])
+    x = sdo.train(x_star[a:b], x0[a:b], None, hog, allreduce=allreduce, world_size=world, n_train_global=n_global)
+    np.savez(out.format(rank=rank), x=x, a=a, b=b, n_global=n_global, lam=[r.last_lambda for r in sdo.regressors],
+             **{f"R{i}": r.x for i, r in enumerate(sdo.regressors)})
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_shard_range_partitions_rows():
+    from superviseddescent_amd import parallel
+    for n, w in [(10, 3), (7, 8), (100000, 8), (1, 1)]:
+        spans = [parallel.shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        parallel.shard_range(10, 3, 3)
+
+
+def test_two_rank_training_equals_single_process(tmp_path):
+    out = str(tmp_path / "rank{rank}.npz")
+    _train(0, 1, 0, str(tmp_path / "single{rank}.npz"))
+    port = _free_port()
+    mp.spawn(_train, args=(2, port, out), nprocs=2, join=True)
+    single = np.load(str(tmp_path / "single0.npz"))
+    r0, r1 = np.load(out.format(rank=0)), np.load(out.format(rank=1))
+    assert int(r0["n_global"]) == int(r1["n_global"]) == single["x"].shape[0]
+    assert (int(r0["a"]), int(r1["b"])) == (0, single["x"].shape[0]) and int(r0["b"]) == int(r1["a"])
+    for lvl in range(len(PARAMS)):
+        # every rank ends up with the same regressor (identical system after the all-reduce) ...
+        assert np.array_equal(r0[f"R{lvl}"], r1[f"R{lvl}"])
+        # ... which is the single-process one up to the summation order of the Gram matrix
+        ref = single[f"R{lvl}"]
+        assert np.linalg.norm(r0[f"R{lvl}"] - ref) / np.linalg.norm(ref) < 2e-3
+        assert r0["lam"][lvl] == pytest.approx(single["lam"][lvl], rel=1e-5)
+    x = np.concatenate([r0["x"], r1["x"]])
+    assert np.linalg.norm(x - single["x"]) / np.linalg.norm(single["x"]) < 1e-5
