@@ -391,11 +391,15 @@ class HogTransform:
         self.images, self.hog_params = images, hog_params
         self.right_eye, self.left_eye = list(right_eye), list(left_eye)
         self.img_index, self.n_threads = img_index, n_threads
+        self._buf = None   # feature matrix reused across levels (avoids re-faulting 100+ MB per level)
 
     def __call__(self, x: np.ndarray, level: int) -> np.ndarray:
         x = np.atleast_2d(np.asarray(x, np.float32))
+        F = feature_dim(x.shape[1] // 2, self.hog_params[level])
+        if self._buf is None or self._buf.shape != (x.shape[0], F):
+            self._buf = np.empty((x.shape[0], F), np.float32)
         return hog_features_batch(self.images, self.img_index, x, self.right_eye, self.left_eye,
-                                  self.hog_params[level], self.n_threads)
+                                  self.hog_params[level], self.n_threads, out=self._buf)
 
 
 def align_mean(mean: np.ndarray, box, scaling_x=1.0, scaling_y=1.0, translation_x=0.0,

@@ -1,0 +1,44 @@
+#!/bin/bash
+# Round profile: rocprofv3 --kernel-trace --stats of the default bench + separate PMC passes (HBM bytes, MFMA busy),
+# summaries written to gpurun_out/profile_<tag>/ (copy the *.txt / *.csv you want judged into profiles/).
+set -u
+TAG=${1:-run}
+REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$REPO/gpurun_out/profile_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+CMD="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $CMD > $OUT/bench_under_trace.json 2> $OUT/trace_stderr.log
+cp $OUT/trace/t_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
+i=0
+for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES" \
+           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $OUT/p$i -o pmc -- $CMD > /dev/null 2> $OUT/p${i}_stderr.log
+done
+python - <<PY
+import csv, glob, collections, re
+out="$OUT"
+def short(n):
+    m=re.search(r'(\w+_kernel)', n); return m.group(1) if m else n.split("(")[0][:40]
+with open(out+"/summary.txt","w") as fh:
+    fh.write("== rocprofv3 --kernel-trace --stats : python bench.py --steps 10 --warmup 2 --no-cpu ==\n")
+    fh.write("%-28s %7s %13s %11s %7s\n" % ("kernel","calls","total_us","avg_us","%"))
+    for r in list(csv.DictReader(open(out+"/kernel_stats.csv")))[:14]:
+        fh.write("%-28s %7s %13.1f %11.2f %7.2f\n" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"])/1e3, float(r["AverageNs"])/1e3, float(r["Percentage"])))
+    rows=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter()
+    for f in glob.glob(out+"/p*/*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            k=short(r["Kernel_Name"])
+            if k not in ("hog_fast_kernel","apply_partial_kernel","syrk_tn_kernel"): continue
+            rows[k][r["Counter_Name"]]+=float(r["Counter_Value"]); cnt[(k,r["Counter_Name"])]+=1
+    fh.write("\n== PMC (separate passes), per-dispatch averages ==\n")
+    for k,v in sorted(rows.items()):
+        fh.write(k+"\n")
+        for c,val in sorted(v.items()):
+            fh.write("   %-28s %14.6g  (n=%d)\n" % (c, val/cnt[(k,c)], cnt[(k,c)]))
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            fs=v["FETCH_SIZE"]/cnt[(k,"FETCH_SIZE")]; ws=v["WRITE_SIZE"]/cnt[(k,"WRITE_SIZE")]
+            fh.write("   -> HBM traffic per launch: FETCH_SIZE %.1f KB x2 (gfx950 half-count correction, MI355X_MICROARCH.md HBM) + WRITE_SIZE %.1f KB = %.1f MB\n" % (fs, ws, (2*fs+ws)/1024))
+print(open(out+"/summary.txt").read())
+PY
