@@ -77,6 +77,22 @@ __device__ inline float from_right(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 }
 
+// Correctly rounded sqrt for the values that occur here (sums of two squared u8 differences: integers <= 130050):
+// the hardware approximation (<= 1 ulp) corrected by one residual test on each neighbour, without the denormal
+// scaling of the general-purpose sqrtf.  Used only after sdm_verify_fast_bins found it bit-identical to sqrtf on
+// every possible input.
+__device__ inline float sqrt_int_exact(float x)
+{
+    const float r = __builtin_amdgcn_sqrtf(x);
+    const float rm = __builtin_bit_cast(float, __builtin_bit_cast(int, r) - 1);
+    const float rp = __builtin_bit_cast(float, __builtin_bit_cast(int, r) + 1);
+    const float em = __builtin_fmaf(-rm, r, x);
+    const float ep = __builtin_fmaf(-rp, r, x);
+    float y = (em <= 0.0f) ? rm : r;
+    y = (ep > 0.0f) ? rp : y;
+    return y;
+}
+
 // reference arithmetic, hog.c:637-672 (identical to sdm_hog.hip::gradient_bin)
 __device__ inline void bin_reference(float gx, float gy, float g, const HogLevelDev& lv, int& bin)
 {
@@ -251,7 +267,7 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
     mark(1);   // histogram clear + barrier
     // fixed point: the two cell-row bands (by, by+1) a pixel row feeds are accumulated in private copies (no two
     // lanes of one instruction share an address); a band is folded into hfin when the rows have moved past it
-    const int rcopy = lane % R;
+    const int lane_off = hcol * R + lane % R;
     int cur_by = -2;
     auto flush_band = [&](int band) {
         const int slot = band & 1;
@@ -266,6 +282,9 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
 
     // ---- fused crop + resize + gradient + accumulation, one output row per iteration -------------------
     // issue: the four source bytes of output row y (two clipped source rows x two horizontal taps)
+    // the image as a raw buffer: per-lane byte offset (column) in the vector offset, the row offset in a scalar
+    // register -> no per-row vector address arithmetic at all
+    const __amdgpu_buffer_rsrc_t img_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)img, 0, ih * istride, 0x00020000);
     auto issue_row = [&](int y, int& q00, int& q01, int& q10, int& q11, int& bb) {
         const int yy = y < S ? y : S - 1;
         const int src = __builtin_amdgcn_readlane(row_src, yy);
@@ -276,25 +295,30 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
         if (py1 < 0 || py1 >= ih) beta &= 0x0000ffff;
         py0 = py0 < 0 ? 0 : (py0 > ih - 1 ? ih - 1 : py0);
         py1 = py1 < 0 ? 0 : (py1 > ih - 1 ? ih - 1 : py1);
-        const uint8_t* r0p = img + (long long)py0 * istride;
-        const uint8_t* r1p = img + (long long)py1 * istride;
-        q00 = r0p[px0]; q01 = r0p[px1]; q10 = r1p[px0]; q11 = r1p[px1];
+        const int o0 = py0 * istride, o1 = py1 * istride;
+        q00 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, px0, o0, 0);
+        q01 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, px1, o0, 0);
+        q10 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, px0, o1, 0);
+        q11 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, px1, o1, 0);
         bb = beta;
     };
     auto finish_row = [&](int q00, int q01, int q10, int q11, int beta) -> float {
-        const int H0 = q00 * a0 + q01 * a1;
-        const int H1 = q10 * a0 + q11 * a1;
+        const int H0 = __mul24(q00, a0) + __mul24(q01, a1);
+        const int H1 = __mul24(q10, a0) + __mul24(q11, a1);
         int out;
         if (area2) {
             const int e0 = (beta & 0xffff) ? 1 : 0, e1 = (beta >> 16) ? 1 : 0;   // row validity survives in beta
             out = (H0 * e0 + H1 * e1 + 2) >> 2;
         } else {
             const int b0 = beta & 0xffff, b1 = beta >> 16;
-            out = (((b0 * (H0 >> 4)) >> 16) + ((b1 * (H1 >> 4)) >> 16) + 2) >> 2;
+            // operands < 2^24 (b <= 2048, H >> 4 <= 32640): the 24-bit multiplier is exact and full rate
+            out = (int)(((__umul24((unsigned)b0, (unsigned)(H0 >> 4)) >> 16) + (__umul24((unsigned)b1, (unsigned)(H1 >> 4)) >> 16) + 2u) >> 2);
         }
         return (float)out;      // convertTo(CV_32F), adaptive_vlhog.hpp:157
     };
 
+    double two52 = 4503599627370496.0;   // 2^52, kept in a register pair for the fixed-point conversion
+    asm volatile("" : "+v"(two52));       // (opaque to the optimiser so that it is not re-materialised per use)
     float rm2 = 0.0f, rm1 = 0.0f;       // resized rows y-2, y-1 of this lane's column
     int n00, n01, n10, n11, nbeta;
     issue_row(0, n00, n01, n10, n11, nbeta);
@@ -308,7 +332,7 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
             const float gx = from_right(rm1) - from_left(rm1);
             const float gy = r0 - rm2;
             const float g2 = gx * gx + gy * gy;
-            float g = sqrtf(g2);
+            float g = FASTBIN ? sqrt_int_exact(g2) : sqrtf(g2);
             int bin;
             if (FASTBIN) {
                 float best = 0.0f;
@@ -346,16 +370,21 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
                     cur_by = by;
                 }
                 // exact f32 -> 2^-36 fixed point: fma(v, 2^36, 2^52) leaves the integer in the low 52 mantissa bits
-                auto fx = [](float v) -> u64 {
-                    const double yv = __builtin_fma((double)v, 68719476736.0, 4503599627370496.0);
-                    return (u64)__builtin_bit_cast(long long, yv) & 0x000fffffffffffffull;
+                auto fx = [&](float v) -> u64 {
+                    double yv;
+                    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(yv) : "v"((double)v), "s"(68719476736.0), "v"(two52));
+                    const unsigned hi = (unsigned)__double2hiint(yv) & 0xfffffu, lo = (unsigned)__double2loint(yv);
+                    return ((u64)hi << 32) | lo;
                 };
-                u64* c0 = w.copies + (size_t)(((by & 1) * 2 * O + bin) * PW + hcol) * R + rcopy;        // band by
-                u64* c1 = w.copies + (size_t)((((by + 1) & 1) * 2 * O + bin) * PW + hcol) * R + rcopy;  // band by+1
-                atomicAdd(c0 + R, fx(va));
-                atomicAdd(c0, fx(vb));
-                atomicAdd(c1 + R, fx(vc));
-                atomicAdd(c1, fx(vd));
+                // private copy index ((slot*2O + bin)*PW + hcol)*R + (x % R), split into a per-lane constant, a scalar
+                // band-slot offset and one 24-bit multiply-add on the bin (no 64-bit or full 32-bit multiplies per row)
+                const int slot_stride = 2 * O * PW * R;
+                const int i0 = (int)(__umul24((unsigned)bin, (unsigned)(PW * R)) + (unsigned)(lane_off + (by & 1) * slot_stride));
+                const int i1 = (int)(__umul24((unsigned)bin, (unsigned)(PW * R)) + (unsigned)(lane_off + ((by + 1) & 1) * slot_stride));
+                atomicAdd(w.copies + i0 + R, fx(va));     // band by,   column bx+1
+                atomicAdd(w.copies + i0, fx(vb));         // band by,   column bx
+                atomicAdd(w.copies + i1 + R, fx(vc));     // band by+1, column bx+1
+                atomicAdd(w.copies + i1, fx(vd));         // band by+1, column bx
             } else {
                 const int base = bin * PWW + (by + 1) * PW + hcol;
                 // reference order per accumulator: (bx+1,by) (bx,by) (bx+1,by+1) (bx,by+1), lanes ascending
@@ -492,7 +521,9 @@ __global__ void verify_fast_bins_kernel(HogLevelDev lv, int* __restrict__ mismat
     int a, b;
     bin_reference(gx, gy, g, lv, a);
     bin_unnormalised(gx, gy, lv, b);
-    if (a != b) atomicAdd(mismatches, 1);
+    const float g2 = gx * gx + gy * gy;
+    const bool sqrt_ok = __builtin_bit_cast(int, sqrt_int_exact(g2)) == __builtin_bit_cast(int, sqrtf(g2));
+    if (a != b || !sqrt_ok) atomicAdd(mismatches, 1);
 }
 
 }  // namespace
