@@ -169,244 +169,284 @@ __global__ void add_diag_kernel(float* __restrict__ G, long long ldg, int F, int
 }
 
 // =====================================================================================================
-// Tile kernels of the blocked Cholesky / substitutions.  All of them distribute a 128 x 128 (or 128 x nrhs)
-// tile over 256 threads in a 16 x 16 cyclic layout -- thread (tr, tc) owns rows tr+16i and columns tc+16j in
-// REGISTERS -- and walk the 128 elimination steps with one barrier per step: the pivot row is broadcast
-// through a double-buffered LDS line, everything else is register FMAs.  (The first version kept the tile
-// in LDS with three barriers and two integer divisions per element per step: 404 us per diagonal tile,
-// profiles/r01_first_contact.log; this layout is ~10x faster.)
+// Tile kernels of the blocked Cholesky / substitutions.
+//
+// A 128 x 128 tile step is latency bound, not flop bound (128^3/3 flops is nothing): the first two versions walked
+// the 128 elimination steps with one or three barriers each and took 80-400 us per tile (profiles/r01_*).  These
+// kernels are blocked by 16 inside the tile and give every thread ONE column: the 16 x 16 triangular solves and the
+// rank-16 updates of a column are thread-local register arithmetic fed by broadcast LDS reads (ds_read_b128 of 16
+// consecutive coefficients), so a tile needs 16 barriers (potrf) or none at all (the substitutions).
 // =====================================================================================================
-#define LDT 129
+#define IB 16                      // inner block
+#define NIB (TILE / IB)
 
-// ---- Cholesky of one diagonal tile (upper: G_kk = U^T U) ------------------------------------------------
-__global__ void __launch_bounds__(256)
-potrf_tile_kernel(float* __restrict__ G, long long ldg, int k0, int* __restrict__ status)
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+
+__device__ inline void ld16(const float* p, float (&v)[IB])
 {
-    __shared__ float rowbuf[2][TILE];
-    const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
-    float* Gk = G + (long long)k0 * ldg + k0;
-    float a[8][8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int r = tr + 16 * i, c = tc + 16 * j;
-            a[i][j] = (c >= r) ? Gk[(long long)r * ldg + c] : 0.0f;
-        }
-    for (int j = 0; j < TILE; ++j) {
-        float* rb = rowbuf[j & 1];
-        const int oi = j >> 4;
-        const bool owner = (tr == (j & 15));
-        if (owner) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (i == oi) {
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) rb[tc + 16 * jj] = a[i][jj];
-                }
-        }
-        __syncthreads();
-        const float d = rb[j];
-        if (!(d > 0.0f)) {            // uniform: every thread reads the same word
-            if (t == 0) atomicOr(status, 2);
-            return;
-        }
-        const float sd = sqrtf(d), inv = 1.0f / sd;
-        float ur[8], uc[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) ur[i] = (tr + 16 * i > j) ? rb[tr + 16 * i] * inv : 0.0f;   // U[j][r], rows below the pivot only
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) uc[jj] = rb[tc + 16 * jj] * inv; // U[j][c]
-        // rank-1 update of every row below the pivot; entries left of the diagonal are scratch (never read
-        // as data: a pivot row only feeds columns >= its own index), so no per-element predicate is needed
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) a[i][jj] -= ur[i] * uc[jj];
-        if (owner) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (i == oi) {
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) {
-                        const int c = tc + 16 * jj;
-                        if (c > j) a[i][jj] = uc[jj]; else if (c == j) a[i][jj] = sd;
-                    }
-                }
-        }
+    for (int q = 0; q < IB / 4; ++q) {
+        const f32x4s t = *(const f32x4s*)(p + 4 * q);
+        v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
     }
+}
+__device__ inline void st16(float* p, const float (&v)[IB])
+{
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int r = tr + 16 * i, c = tc + 16 * j;
-            Gk[(long long)r * ldg + c] = (c >= r) ? a[i][j] : 0.0f;   // strict lower part becomes zero
-        }
+    for (int q = 0; q < IB / 4; ++q) *(f32x4s*)(p + 4 * q) = (f32x4s){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
 }
 
-// ---- panel solve: G[k0:k0+128, tj*128 : +128] <- U_kk^-T * (same); one workgroup per column tile ----------
-__global__ void __launch_bounds__(256)
+// ---- Cholesky of one diagonal tile (upper: G_kk = U^T U); thread c owns column c ---------------------------------
+__global__ void __launch_bounds__(TILE)
+potrf_tile_kernel(float* __restrict__ G, long long ldg, int k0, int* __restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* T = sm;                    // [128][128] working tile, row-major (upper triangle is data)
+    float* P = sm + TILE * TILE;      // [128][16]  current panel, transposed: P[c][m] = U[j0+m][c]
+    float* Dt = P + TILE * IB;        // [16][16]   factor of the current diagonal block, transposed: Dt[i][q] = U[j0+q][j0+i]
+    float* badf = Dt + IB * IB;       // "not positive definite" flag (all LDS of this kernel is dynamic)
+    const int c = threadIdx.x;
+    float* Gk = G + (long long)k0 * ldg + k0;
+    if (c == 0) *badf = 0.0f;
+#pragma unroll 16
+    for (int r = 0; r < TILE; ++r) T[r * TILE + c] = Gk[(long long)r * ldg + c];   // coalesced rows
+    __syncthreads();
+
+    for (int jb = 0; jb < NIB; ++jb) {
+        const int j0 = jb * IB;
+        // (a) 16 x 16 diagonal block: lane i of the first wave owns its column i in registers; pivots and the scaled
+        //     pivot row travel through v_readlane (no LDS round trips, no barriers)
+        if (c < 64) {
+            const int i = c & 15;
+            float d[IB];
+#pragma unroll
+            for (int r = 0; r < IB; ++r) d[r] = T[(j0 + r) * TILE + j0 + i];
+#pragma unroll
+            for (int s_ = 0; s_ < IB; ++s_) {
+                const float piv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d[s_]), s_));
+                const float sd = sqrtf(piv);
+                if (!(piv > 0.0f)) *badf = 1.0f;
+                const float u = (i == s_) ? sd : d[s_] / sd;          // U[s][i] for i >= s
+                d[s_] = u;
+#pragma unroll
+                for (int r = s_ + 1; r < IB; ++r) {
+                    const float ur = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u), r));   // U[s][r]
+                    d[r] -= ur * u;                                   // meaningful for i >= r
+                }
+            }
+            if (c < IB) {
+#pragma unroll
+                for (int r = 0; r < IB; ++r) {
+                    T[(j0 + r) * TILE + j0 + i] = (i >= r) ? d[r] : 0.0f;
+                    Dt[i * IB + r] = (i >= r) ? d[r] : 0.0f;
+                }
+            }
+        }
+        __syncthreads();
+        if (*badf != 0.0f) {
+            if (c == 0) atomicOr(status, 2);
+            return;
+        }
+        // (b) panel: column c right of the block: U[j0+m][c] = (T[j0+m][c] - sum_{q<m} U[j0+q][j0+m] U[j0+q][c]) / U[j0+m][j0+m]
+        float y[IB];
+        const bool right = c >= j0 + IB;
+        if (right) {
+#pragma unroll
+            for (int m = 0; m < IB; ++m) y[m] = T[(j0 + m) * TILE + c];
+#pragma unroll
+            for (int m = 0; m < IB; ++m) {
+                float dcol[IB];
+                ld16(Dt + m * IB, dcol);                              // U[j0+q][j0+m], q = 0..15
+                float acc = y[m];
+#pragma unroll
+                for (int q = 0; q < m; ++q) acc -= dcol[q] * y[q];
+                y[m] = acc / dcol[m];
+            }
+#pragma unroll
+            for (int m = 0; m < IB; ++m) T[(j0 + m) * TILE + c] = y[m];
+            st16(P + c * IB, y);
+        }
+        __syncthreads();
+        // (c) trailing update of column c: T[r][c] -= sum_m U[j0+m][r] U[j0+m][c],  j0+16 <= r <= c
+        if (right) {
+#pragma unroll 4
+            for (int r = j0 + IB; r <= c; ++r) {
+                float pr[IB];
+                ld16(P + r * IB, pr);
+                float acc = T[r * TILE + c];
+#pragma unroll
+                for (int m = 0; m < IB; ++m) acc -= pr[m] * y[m];
+                T[r * TILE + c] = acc;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll 16
+    for (int r = 0; r < TILE; ++r) Gk[(long long)r * ldg + c] = (c >= r) ? T[r * TILE + c] : 0.0f;
+}
+
+// ---- panel solve: G[k0:k0+128, tj*128 : +128] <- U_kk^-T * (same); thread c owns column c, no barriers in the loop ----
+__global__ void __launch_bounds__(TILE)
 trsm_tile_kernel(float* __restrict__ G, long long ldg, int k0, int tile_j0)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* U = sm;                      // [128][LDT]  U_kk
-    float* rowbuf = sm + TILE * LDT;    // [2][128]
-    const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
-    const long long j0 = (long long)(tile_j0 + blockIdx.x) * TILE;
+    float* UT = sm;                    // [128][128] U_kk transposed: UT[r][m] = U[m][r]
+    float* Y = sm + TILE * TILE;       // [128][128] the tile, solved in place; thread c touches only column c
+    const int c = threadIdx.x;
+    const long long j0g = (long long)(tile_j0 + blockIdx.x) * TILE;
     const float* Gk = G + (long long)k0 * ldg + k0;
-    float* B = G + (long long)k0 * ldg + j0;
-    for (int idx = t; idx < TILE * TILE; idx += 256) {
-        const int r = idx >> 7, c = idx & 127;
-        U[r * LDT + c] = Gk[(long long)r * ldg + c];
-    }
-    float a[8][8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) a[i][j] = B[(long long)(tr + 16 * i) * ldg + tc + 16 * j];
-    __syncthreads();
-    // forward substitution with L = U^T, right-looking: y_r = b_r / U[r][r]; b_r' -= U[r][r'] * y_r for r' > r
+    float* B = G + (long long)k0 * ldg + j0g;
+#pragma unroll 16
     for (int r = 0; r < TILE; ++r) {
-        float* rb = rowbuf + (r & 1) * TILE;
-        const int oi = r >> 4;
-        if (tr == (r & 15)) {
-            const float inv = 1.0f / U[r * LDT + r];
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (i == oi) {
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) { a[i][jj] *= inv; rb[tc + 16 * jj] = a[i][jj]; }
-                }
-        }
-        __syncthreads();
-        float ur[8], yc[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) ur[i] = (tr + 16 * i > r) ? U[r * LDT + tr + 16 * i] : 0.0f;
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) yc[jj] = rb[tc + 16 * jj];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) a[i][jj] -= ur[i] * yc[jj];
+        UT[c * TILE + r] = Gk[(long long)r * ldg + c];      // coalesced global read, transposed store
+        Y[r * TILE + c] = B[(long long)r * ldg + c];
     }
+    __syncthreads();
+    for (int jb = 0; jb < NIB; ++jb) {
+        const int j0 = jb * IB;
+        float y[IB];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+        for (int m = 0; m < IB; ++m) y[m] = Y[(j0 + m) * TILE + c];
+        // 16 x 16 forward substitution with L = U^T: y[m] = (b[m] - sum_{q<m} U[j0+q][j0+m] y[q]) / U[j0+m][j0+m]
 #pragma unroll
-        for (int j = 0; j < 8; ++j) B[(long long)(tr + 16 * i) * ldg + tc + 16 * j] = a[i][j];
+        for (int m = 0; m < IB; ++m) {
+            float col[IB];
+            ld16(UT + (j0 + m) * TILE + j0, col);
+            float acc = y[m];
+#pragma unroll
+            for (int q = 0; q < m; ++q) acc -= col[q] * y[q];
+            y[m] = acc / col[m];
+        }
+#pragma unroll
+        for (int m = 0; m < IB; ++m) Y[(j0 + m) * TILE + c] = y[m];
+        // rows below the block: b[r] -= sum_m U[j0+m][r] y[m]
+#pragma unroll 4
+        for (int r = j0 + IB; r < TILE; ++r) {
+            float col[IB];
+            ld16(UT + r * TILE + j0, col);
+            float acc = Y[r * TILE + c];
+#pragma unroll
+            for (int m = 0; m < IB; ++m) acc -= col[m] * y[m];
+            Y[r * TILE + c] = acc;
+        }
+    }
+    __syncthreads();
+#pragma unroll 16
+    for (int r = 0; r < TILE; ++r) B[(long long)r * ldg + c] = Y[r * TILE + c];
 }
 
 // ---- back substitution ------------------------------------------------------------------------------
-// R[k0:k0+128, 0:nrhs] = U_kk^-1 * Y_k,  Y_k = G[k0:k0+128, rhs0:rhs0+nrhs]; nrhs = 16*NJ <= 144
-__global__ void __launch_bounds__(256)
+// R[k0:k0+128, 0:nrhs] = U_kk^-1 * Y_k,  Y_k = G[k0:k0+128, rhs0:rhs0+nrhs]; thread c owns RHS column c (nrhs <= 144)
+__global__ void __launch_bounds__(192)
 backsolve_tile_kernel(const float* __restrict__ G, long long ldg, int k0, int rhs0, int nrhs,
                       float* __restrict__ R, long long ldr)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* U = sm;                      // [128][LDT]
-    float* rowbuf = sm + TILE * LDT;    // [2][144]
-    const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
-    const int NJ = nrhs >> 4;
+    float* U = sm;                     // [128][128] U_kk row-major
+    float* Y = sm + TILE * TILE;       // [128][nrhs]
+    const int c = threadIdx.x;
     const float* Gk = G + (long long)k0 * ldg + k0;
     const float* Yg = G + (long long)k0 * ldg + rhs0;
-    for (int idx = t; idx < TILE * TILE; idx += 256) {
-        const int r = idx >> 7, c = idx & 127;
-        U[r * LDT + c] = Gk[(long long)r * ldg + c];
+    for (int idx = c; idx < TILE * TILE; idx += 192) {
+        const int r = idx >> 7, cc = idx & 127;
+        U[idx] = Gk[(long long)r * ldg + cc];
     }
-    float y[8][9];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 9; ++j) y[i][j] = (j < NJ) ? Yg[(long long)(tr + 16 * i) * ldg + tc + 16 * j] : 0.0f;
+    for (int idx = c; idx < TILE * nrhs; idx += 192) {
+        const int r = idx / nrhs, cc = idx - r * nrhs;
+        Y[idx] = Yg[(long long)r * ldg + cc];
+    }
     __syncthreads();
-    // x_r = y_r / U[r][r]; y_r' -= U[r'][r] * x_r for r' < r   (r descending)
-    for (int r = TILE - 1; r >= 0; --r) {
-        float* rb = rowbuf + (r & 1) * 144;
-        const int oi = r >> 4;
-        if (tr == (r & 15)) {
-            const float inv = 1.0f / U[r * LDT + r];
+    if (c < nrhs) {
+        for (int jb = NIB - 1; jb >= 0; --jb) {
+            const int j0 = jb * IB;
+            float x[IB];
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (i == oi) {
+            for (int m = 0; m < IB; ++m) x[m] = Y[(j0 + m) * nrhs + c];
+            // x[i] = (y[i] - sum_{m>i} U[j0+i][j0+m] x[m]) / U[j0+i][j0+i], i descending
 #pragma unroll
-                    for (int jj = 0; jj < 9; ++jj)
-                        if (jj < NJ) { y[i][jj] *= inv; rb[tc + 16 * jj] = y[i][jj]; }
-                }
-        }
-        __syncthreads();
-        float ur[8], xc[9];
+            for (int i = IB - 1; i >= 0; --i) {
+                float row[IB];
+                ld16(U + (j0 + i) * TILE + j0, row);
+                float acc = x[i];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ur[i] = (tr + 16 * i < r) ? U[(tr + 16 * i) * LDT + r] : 0.0f;
+                for (int m = i + 1; m < IB; ++m) acc -= row[m] * x[m];
+                x[i] = acc / row[i];
+            }
 #pragma unroll
-        for (int jj = 0; jj < 9; ++jj) xc[jj] = (jj < NJ) ? rb[tc + 16 * jj] : 0.0f;
-        if (NJ <= 3) {
+            for (int m = 0; m < IB; ++m) Y[(j0 + m) * nrhs + c] = x[m];
+            // rows above the block: y[r] -= sum_m U[r][j0+m] x[m]
+#pragma unroll 4
+            for (int r = 0; r < j0; ++r) {
+                float row[IB];
+                ld16(U + r * TILE + j0, row);
+                float acc = Y[r * nrhs + c];
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int jj = 0; jj < 3; ++jj) y[i][jj] -= ur[i] * xc[jj];
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int jj = 0; jj < 9; ++jj) y[i][jj] -= ur[i] * xc[jj];
+                for (int m = 0; m < IB; ++m) acc -= row[m] * x[m];
+                Y[r * nrhs + c] = acc;
+            }
         }
     }
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 9; ++j)
-            if (j < NJ) R[(long long)(k0 + tr + 16 * i) * ldr + tc + 16 * j] = y[i][j];
+    __syncthreads();
+    for (int idx = c; idx < TILE * nrhs; idx += 192) {
+        const int r = idx / nrhs, cc = idx - r * nrhs;
+        R[(long long)(k0 + r) * ldr + cc] = Y[idx];
+    }
 }
 
-// Y_i -= U_ik * R_k for every tile row i < k  (one workgroup per i)
+// Y_i -= U_ik * R_k for every tile row i < k  (one workgroup per i; thread (tr, tc): rows tr+16a, columns tc+16b)
 __global__ void __launch_bounds__(256)
 backsolve_update_kernel(float* __restrict__ G, long long ldg, int k0, int rhs0, int nrhs,
                         const float* __restrict__ R, long long ldr)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* U = sm;                 // [128][LDT]  U_ik
-    float* Rk = sm + TILE * LDT;   // [128][nrhs]
+    float* U = sm;                     // [128][128+4] U_ik row-major (padded: rows tr+16a of one wave hit distinct banks)
+    float* Rk = sm + TILE * (TILE + 4);   // [128][nrhs]
     const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
     const int NJ = nrhs >> 4;
     const long long i0 = (long long)blockIdx.x * TILE;
     const float* Uik = G + i0 * ldg + k0;
     float* Yi = G + i0 * ldg + rhs0;
     for (int idx = t; idx < TILE * TILE; idx += 256) {
-        const int r = idx >> 7, c = idx & 127;
-        U[r * LDT + c] = Uik[(long long)r * ldg + c];
+        const int r = idx >> 7, cc = idx & 127;
+        U[r * (TILE + 4) + cc] = Uik[(long long)r * ldg + cc];
     }
     for (int idx = t; idx < TILE * nrhs; idx += 256) {
-        const int r = idx / nrhs, c = idx - r * nrhs;
-        Rk[r * nrhs + c] = R[(long long)(k0 + r) * ldr + c];
+        const int r = idx / nrhs, cc = idx - r * nrhs;
+        Rk[idx] = R[(long long)(k0 + r) * ldr + cc];
     }
     __syncthreads();
     float acc[8][9];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int a = 0; a < 8; ++a)
 #pragma unroll
-        for (int j = 0; j < 9; ++j) acc[i][j] = 0.0f;
-    for (int m = 0; m < TILE; ++m) {
-        float ur[8], xc[9];
+        for (int b = 0; b < 9; ++b) acc[a][b] = 0.0f;
+    for (int m = 0; m < TILE; m += 4) {
+        f32x4s ur[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ur[i] = U[(tr + 16 * i) * LDT + m];
+        for (int a = 0; a < 8; ++a) ur[a] = *(const f32x4s*)(U + (tr + 16 * a) * (TILE + 4) + m);
 #pragma unroll
-        for (int jj = 0; jj < 9; ++jj) xc[jj] = (jj < NJ) ? Rk[m * nrhs + tc + 16 * jj] : 0.0f;
-        if (NJ <= 3) {
+        for (int e = 0; e < 4; ++e) {
+            float xc[9];
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int b = 0; b < 9; ++b) xc[b] = (b < NJ) ? Rk[(m + e) * nrhs + tc + 16 * b] : 0.0f;
+            if (NJ <= 3) {
 #pragma unroll
-                for (int jj = 0; jj < 3; ++jj) acc[i][jj] += ur[i] * xc[jj];
-        } else {
+                for (int a = 0; a < 8; ++a)
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+                    for (int b = 0; b < 3; ++b) acc[a][b] += ur[a][e] * xc[b];
+            } else {
 #pragma unroll
-                for (int jj = 0; jj < 9; ++jj) acc[i][jj] += ur[i] * xc[jj];
+                for (int a = 0; a < 8; ++a)
+#pragma unroll
+                    for (int b = 0; b < 9; ++b) acc[a][b] += ur[a][e] * xc[b];
+            }
         }
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int a = 0; a < 8; ++a)
 #pragma unroll
-        for (int j = 0; j < 9; ++j)
-            if (j < NJ) Yi[(long long)(tr + 16 * i) * ldg + tc + 16 * j] -= acc[i][j];
+        for (int b = 0; b < 9; ++b)
+            if (b < NJ) Yi[(long long)(tr + 16 * a) * ldg + tc + 16 * b] -= acc[a][b];
 }
 
 }  // namespace
@@ -442,11 +482,13 @@ void sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrh
     const int Tf = (F + TILE - 1) / TILE;          // factor tiles
     const int ncols = rhs0 + TILE;                 // factor tiles + one RHS tile column
     const int T = ncols / TILE;
-    const size_t lds_trsm = ((size_t)TILE * LDT + 2 * TILE) * sizeof(float);
-    const size_t lds_backs = ((size_t)TILE * LDT + 2 * 144) * sizeof(float);
-    const size_t lds_back = ((size_t)TILE * LDT + (size_t)TILE * nrhs) * sizeof(float);
+    const size_t lds_potrf = ((size_t)TILE * TILE + TILE * IB + IB * IB + 4) * sizeof(float);
+    const size_t lds_trsm = ((size_t)2 * TILE * TILE) * sizeof(float);
+    const size_t lds_backs = ((size_t)TILE * TILE + (size_t)TILE * nrhs) * sizeof(float);
+    const size_t lds_back = ((size_t)TILE * (TILE + 4) + (size_t)TILE * nrhs) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)potrf_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)trsm_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)backsolve_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)backsolve_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -454,17 +496,17 @@ void sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrh
     }
     for (int k = 0; k < Tf; ++k) {
         const int k0 = k * TILE;
-        hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(256), 0, stream, G, ldg, k0, status);
+        hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(TILE), lds_potrf, stream, G, ldg, k0, status);
         const int ntr = T - (k + 1);
         if (ntr > 0) {
-            hipLaunchKernelGGL(trsm_tile_kernel, dim3(ntr), dim3(256), lds_trsm, stream, G, ldg, k0, k + 1);
+            hipLaunchKernelGGL(trsm_tile_kernel, dim3(ntr), dim3(TILE), lds_trsm, stream, G, ldg, k0, k + 1);
             // trailing update of tiles (ti >= k+1, tj >= ti) from the freshly solved panel rows
             sdm_launch_syrk_tn(G + (long long)k0 * ldg, ldg, TILE, ncols, G, ldg, -1.0f, 1, k + 1, stream);
         }
     }
     for (int k = Tf - 1; k >= 0; --k) {
         const int k0 = k * TILE;
-        hipLaunchKernelGGL(backsolve_tile_kernel, dim3(1), dim3(256), lds_backs, stream, G, ldg, k0, rhs0, nrhs,
+        hipLaunchKernelGGL(backsolve_tile_kernel, dim3(1), dim3(192), lds_backs, stream, G, ldg, k0, rhs0, nrhs,
                            R_out, ldr);
         if (k > 0)
             hipLaunchKernelGGL(backsolve_update_kernel, dim3(k), dim3(256), lds_back, stream, G, ldg, k0, rhs0,
