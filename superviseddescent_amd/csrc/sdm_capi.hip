@@ -70,7 +70,8 @@ struct sdm_ctx {
     std::vector<int> fast_bins;     // per level: un-normalised arg-max verified on all 511x511 gradients
     int hog_mode = SDM_HOG_FAST;
     int Fmax = 0;
-    long long ldf = 0;      // feature row stride: round_up(Fmax,128) + 128 (tail tile = training targets)
+    long long ldf = 0;      // feature row stride: round_up(Fmax,128) + 128*rhs_tiles (tail tiles = training targets)
+    int rhs_tiles = 1;      // 128-column tiles that hold the 2L target columns (2 when 2L > 128)
 
     // images
     DevBuf<uint8_t> img_owned;
@@ -100,9 +101,11 @@ struct sdm_ctx {
     // normal equations
     DevBuf<float> G;       // [ncols][ncols]
     int g_ncols = 0;
+    int g_fp = 0;
     int g_level = -1;
     DevBuf<double> fro;
     DevBuf<float> Rsol;    // [Fp][Mp_ld]
+    DevBuf<float> winv;    // [Fp/128][128][128] transposed inverses of the diagonal factor tiles
     DevBuf<float> lambda_dev;
 
     sdm_allreduce_fn allreduce = nullptr;
@@ -287,7 +290,7 @@ void sdm_destroy(sdm_ctx* c)
     c->img_owned.release(); c->img_off.release(); c->img_w.release(); c->img_h.release();
     c->img_stride.release(); c->img_idx.release(); c->x[0].release(); c->x[1].release();
     c->xstar.release(); c->feat.release(); c->patch_idx.release(); c->status.release();
-    c->partial.release(); c->G.release(); c->fro.release(); c->Rsol.release(); c->lambda_dev.release();
+    c->partial.release(); c->G.release(); c->fro.release(); c->Rsol.release(); c->winv.release(); c->lambda_dev.release();
     for (auto& r : c->Rt) r.release();
     if (c->own_stream) e = hipStreamDestroy(c->stream);
     delete c;
@@ -364,7 +367,8 @@ int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int*
         const int F = L * lv.P + 1;
         if (F > c->Fmax) c->Fmax = F;
     }
-    c->ldf = (long long)round_up(c->Fmax, 128) + 128;
+    c->rhs_tiles = (round_up(c->M, 16) + 127) / 128;
+    c->ldf = (long long)round_up(c->Fmax, 128) + 128 * c->rhs_tiles;
     for (auto& r : c->Rt) r.release();
     c->Rt.assign(n_levels, DevBuf<float>());
     c->have_R.assign(n_levels, false);
@@ -583,16 +587,16 @@ int sdm_gram_rhs(sdm_ctx* c, int level)
     if (!c->have_targets) return fail(SDM_ERR_INVALID, "sdm_gram_rhs: no targets set");
     HIP_TRY(hipSetDevice(c->device));
     const int F = level_F(c, level);
-    const int Fp = round_up(F, 128), ncols = Fp + 128;
+    const int Fp = round_up(F, 128), ncols = Fp + 128 * c->rhs_tiles;
     int rc = c->G.ensure((size_t)ncols * ncols);
     if (rc) return rc;
     Timer t(c, SDM_T_GRAM);
     // the tail tile of every feature row holds b; clear it first (columns beyond 2L must be 0)
-    HIP_TRY(hipMemset2DAsync(c->feat.p + Fp, (size_t)c->ldf * sizeof(float), 0, 128 * sizeof(float), c->N, c->stream));
+    HIP_TRY(hipMemset2DAsync(c->feat.p + Fp, (size_t)c->ldf * sizeof(float), 0, 128 * c->rhs_tiles * sizeof(float), c->N, c->stream));
     sdm_launch_targets(c->x[c->cur].p, c->xstar.p, c->N, c->L, c->eyes, c->feat.p, c->ldf, Fp, c->stream);
     sdm_launch_syrk_tn(c->feat.p, c->ldf, c->N, ncols, c->G.p, ncols, 1.0f, 0, 0, c->stream);
     HIP_TRY(hipGetLastError());
-    c->g_ncols = ncols; c->g_level = level;
+    c->g_ncols = ncols; c->g_fp = Fp; c->g_level = level;
     return SDM_OK;
 }
 
@@ -609,7 +613,7 @@ int sdm_allreduce_gram_rhs(sdm_ctx* c)
     if (!c->allreduce || c->world_size == 1) return SDM_OK;
     Timer t(c, SDM_T_ALLREDUCE);
     // rows [0, Fp) hold every tile the solve reads (Gram upper tiles + RHS tile column)
-    const size_t count = (size_t)(c->g_ncols - 128) * c->g_ncols;
+    const size_t count = (size_t)c->g_fp * c->g_ncols;
     if (c->allreduce(c->G.p, count, (void*)c->stream, c->allreduce_user) != 0)
         return fail(SDM_ERR_COMM, "all-reduce callback reported failure");
     return SDM_OK;
@@ -627,6 +631,7 @@ int sdm_solve(sdm_ctx* c, int level, int reg_type, float reg_param, int regulari
     int rc;
     if ((rc = c->fro.ensure((size_t)F + 1))) return rc;
     if ((rc = c->Rsol.ensure((size_t)Fp * Mp))) return rc;
+    if ((rc = c->winv.ensure((size_t)Fp * 128))) return rc;
     if ((rc = c->Rt[level].ensure((size_t)Mp * c->ldf))) return rc;
     {
         Timer t(c, SDM_T_REG);
@@ -638,7 +643,7 @@ int sdm_solve(sdm_ctx* c, int level, int reg_type, float reg_param, int regulari
     {
         Timer t(c, SDM_T_FACTOR);
         // factor + forward substitution (the back substitution is part of the same launcher)
-        sdm_launch_cholesky_solve(c->G.p, ncols, F, Fp, Mp, c->Rsol.p, Mp, nullptr, c->status.p, c->stream);
+        sdm_launch_cholesky_solve(c->G.p, ncols, F, Fp, Mp, c->Rsol.p, Mp, c->winv.p, c->status.p, c->stream);
     }
     HIP_TRY(hipGetLastError());
     // R (Fp x Mp) -> Rt (Mp x ldf), zero padded
@@ -670,11 +675,12 @@ int sdm_solve_normal_equations(sdm_ctx* c, const float* A, int N, int F, const f
     if (M > 144) return fail(SDM_ERR_INVALID, "at most 144 outputs supported");
     if (reg_type != SDM_REG_MANUAL && reg_type != SDM_REG_MATRIX_NORM) return fail(SDM_ERR_INVALID, "bad regulariser type");
     HIP_TRY(hipSetDevice(c->device));
-    const int Fp = round_up(F, 128), ncols = Fp + 128, Mp = Mp_of(M);
-    DevBuf<float> dA, dG, dR; DevBuf<double> dfro;
+    const int Mp = Mp_of(M);
+    const int Fp = round_up(F, 128), ncols = Fp + 128 * ((Mp + 127) / 128);
+    DevBuf<float> dA, dG, dR, dW; DevBuf<double> dfro;
     int rc;
     if ((rc = dA.ensure((size_t)N * ncols, true, c->stream)) || (rc = dG.ensure((size_t)ncols * ncols)) ||
-        (rc = dR.ensure((size_t)Fp * Mp)) || (rc = dfro.ensure((size_t)F + 1)))
+        (rc = dR.ensure((size_t)Fp * Mp)) || (rc = dW.ensure((size_t)Fp * 128)) || (rc = dfro.ensure((size_t)F + 1)))
         return rc;
     HIP_TRY(hipMemcpy2DAsync(dA.p, (size_t)ncols * sizeof(float), A, (size_t)F * sizeof(float), (size_t)F * sizeof(float), N,
                              hipMemcpyHostToDevice, c->stream));
@@ -686,14 +692,14 @@ int sdm_solve_normal_equations(sdm_ctx* c, const float* A, int N, int F, const f
         if (reg_type == SDM_REG_MATRIX_NORM) sdm_launch_fro2_upper(dG.p, ncols, F, dfro.p, c->stream);
         sdm_launch_add_diag(dG.p, ncols, F, dfro.p + F, reg_type, reg_param, N, regularise_last_row, c->lambda_dev.p, c->stream);
     }
-    { Timer t(c, SDM_T_FACTOR); sdm_launch_cholesky_solve(dG.p, ncols, F, Fp, Mp, dR.p, Mp, nullptr, c->status.p, c->stream); }
+    { Timer t(c, SDM_T_FACTOR); sdm_launch_cholesky_solve(dG.p, ncols, F, Fp, Mp, dR.p, Mp, dW.p, c->status.p, c->stream); }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy2DAsync(R_host, (size_t)M * sizeof(float), dR.p, (size_t)Mp * sizeof(float), (size_t)M * sizeof(float), F,
                              hipMemcpyDeviceToHost, c->stream));
     if (lambda_out) HIP_TRY(hipMemcpyAsync(lambda_out, c->lambda_dev.p, sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     rc = check_status(c);
-    dA.release(); dG.release(); dR.release(); dfro.release();
+    dA.release(); dG.release(); dR.release(); dW.release(); dfro.release();
     return rc;
 }
 
@@ -711,7 +717,7 @@ int sdm_train_level(sdm_ctx* c, int level, int reg_type, float reg_param, int re
 int sdm_gram_device_ptr(sdm_ctx* c, void** p, size_t* count)
 {
     if (!c || c->g_level < 0) return fail(SDM_ERR_INVALID, "no Gram matrix");
-    *p = c->G.p; *count = (size_t)(c->g_ncols - 128) * c->g_ncols;
+    *p = c->G.p; *count = (size_t)c->g_fp * c->g_ncols;
     return SDM_OK;
 }
 

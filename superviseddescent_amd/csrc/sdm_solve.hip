@@ -196,8 +196,11 @@ __device__ inline void st16(float* p, const float (&v)[IB])
     for (int q = 0; q < IB / 4; ++q) *(f32x4s*)(p + 4 * q) = (f32x4s){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
 }
 
-// ---- Cholesky of one diagonal tile (upper: G_kk = U^T U); thread c owns column c ---------------------------------
-__global__ void __launch_bounds__(TILE)
+// ---- Cholesky of one diagonal tile (upper: G_kk = U^T U).  512 threads: thread (q, c) = (t / 128, t % 128) works on
+//      column c; the diagonal-block factor and the panel solve are done by the q == 0 thread of a column, the
+//      rank-16 trailing update of the column is split row-cyclically over its four threads -------------------------
+#define PQ 4
+__global__ void __launch_bounds__(TILE * PQ)
 potrf_tile_kernel(float* __restrict__ G, long long ldg, int k0, int* __restrict__ status)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -205,19 +208,20 @@ potrf_tile_kernel(float* __restrict__ G, long long ldg, int k0, int* __restrict_
     float* P = sm + TILE * TILE;      // [128][16]  current panel, transposed: P[c][m] = U[j0+m][c]
     float* Dt = P + TILE * IB;        // [16][16]   factor of the current diagonal block, transposed: Dt[i][q] = U[j0+q][j0+i]
     float* badf = Dt + IB * IB;       // "not positive definite" flag (all LDS of this kernel is dynamic)
-    const int c = threadIdx.x;
+    const int t = threadIdx.x, c = t & (TILE - 1), q = t >> 7;
     float* Gk = G + (long long)k0 * ldg + k0;
-    if (c == 0) *badf = 0.0f;
-#pragma unroll 16
-    for (int r = 0; r < TILE; ++r) T[r * TILE + c] = Gk[(long long)r * ldg + c];   // coalesced rows
+    if (t == 0) *badf = 0.0f;
+    const int lr = t >> 5, lc = (t & 31) * 4;   // 16-byte loads: thread t takes 4 columns of rows t/32 + 16*pass
+#pragma unroll 8
+    for (int r = lr; r < TILE; r += 16) *(f32x4s*)(T + r * TILE + lc) = *(const f32x4s*)(Gk + (long long)r * ldg + lc);
     __syncthreads();
 
     for (int jb = 0; jb < NIB; ++jb) {
         const int j0 = jb * IB;
         // (a) 16 x 16 diagonal block: lane i of the first wave owns its column i in registers; pivots and the scaled
         //     pivot row travel through v_readlane (no LDS round trips, no barriers)
-        if (c < 64) {
-            const int i = c & 15;
+        if (t < 64) {
+            const int i = t & 15;
             float d[IB];
 #pragma unroll
             for (int r = 0; r < IB; ++r) d[r] = T[(j0 + r) * TILE + j0 + i];
@@ -234,7 +238,7 @@ potrf_tile_kernel(float* __restrict__ G, long long ldg, int k0, int* __restrict_
                     d[r] -= ur * u;                                   // meaningful for i >= r
                 }
             }
-            if (c < IB) {
+            if (t < IB) {
 #pragma unroll
                 for (int r = 0; r < IB; ++r) {
                     T[(j0 + r) * TILE + j0 + i] = (i >= r) ? d[r] : 0.0f;
@@ -244,22 +248,22 @@ potrf_tile_kernel(float* __restrict__ G, long long ldg, int k0, int* __restrict_
         }
         __syncthreads();
         if (*badf != 0.0f) {
-            if (c == 0) atomicOr(status, 2);
+            if (t == 0) atomicOr(status, 2);
             return;
         }
-        // (b) panel: column c right of the block: U[j0+m][c] = (T[j0+m][c] - sum_{q<m} U[j0+q][j0+m] U[j0+q][c]) / U[j0+m][j0+m]
-        float y[IB];
+        // (b) panel: column c right of the block: U[j0+m][c] = (T[j0+m][c] - sum_{p<m} U[j0+p][j0+m] U[j0+p][c]) / U[j0+m][j0+m]
         const bool right = c >= j0 + IB;
-        if (right) {
+        if (right && q == 0) {
+            float y[IB];
 #pragma unroll
             for (int m = 0; m < IB; ++m) y[m] = T[(j0 + m) * TILE + c];
 #pragma unroll
             for (int m = 0; m < IB; ++m) {
                 float dcol[IB];
-                ld16(Dt + m * IB, dcol);                              // U[j0+q][j0+m], q = 0..15
+                ld16(Dt + m * IB, dcol);                              // U[j0+p][j0+m], p = 0..15
                 float acc = y[m];
 #pragma unroll
-                for (int q = 0; q < m; ++q) acc -= dcol[q] * y[q];
+                for (int p = 0; p < m; ++p) acc -= dcol[p] * y[p];
                 y[m] = acc / dcol[m];
             }
 #pragma unroll
@@ -267,186 +271,179 @@ potrf_tile_kernel(float* __restrict__ G, long long ldg, int k0, int* __restrict_
             st16(P + c * IB, y);
         }
         __syncthreads();
-        // (c) trailing update of column c: T[r][c] -= sum_m U[j0+m][r] U[j0+m][c],  j0+16 <= r <= c
+        // (c) trailing update of column c: T[r][c] -= sum_m U[j0+m][r] U[j0+m][c],  j0+16 <= r <= c, rows r = q mod 4
         if (right) {
-#pragma unroll 4
-            for (int r = j0 + IB; r <= c; ++r) {
+            float y[IB];
+            ld16(P + c * IB, y);
+#pragma unroll 2
+            for (int r = j0 + IB + q; r <= c; r += PQ) {
                 float pr[IB];
                 ld16(P + r * IB, pr);
-                float acc = T[r * TILE + c];
+                float acc0 = T[r * TILE + c], acc1 = 0.0f;
 #pragma unroll
-                for (int m = 0; m < IB; ++m) acc -= pr[m] * y[m];
-                T[r * TILE + c] = acc;
+                for (int m = 0; m < IB; m += 2) { acc0 -= pr[m] * y[m]; acc1 -= pr[m + 1] * y[m + 1]; }
+                T[r * TILE + c] = acc0 + acc1;
             }
         }
         __syncthreads();
     }
-#pragma unroll 16
-    for (int r = 0; r < TILE; ++r) Gk[(long long)r * ldg + c] = (c >= r) ? T[r * TILE + c] : 0.0f;
+#pragma unroll 8
+    for (int r = lr; r < TILE; r += 16) {
+        f32x4s v = *(const f32x4s*)(T + r * TILE + lc);
+        v[0] = (lc + 0 >= r) ? v[0] : 0.0f; v[1] = (lc + 1 >= r) ? v[1] : 0.0f;
+        v[2] = (lc + 2 >= r) ? v[2] : 0.0f; v[3] = (lc + 3 >= r) ? v[3] : 0.0f;
+        *(f32x4s*)(Gk + (long long)r * ldg + lc) = v;     // strict lower part becomes zero
+    }
 }
 
-// ---- panel solve: G[k0:k0+128, tj*128 : +128] <- U_kk^-T * (same); thread c owns column c, no barriers in the loop ----
-__global__ void __launch_bounds__(TILE)
-trsm_tile_kernel(float* __restrict__ G, long long ldg, int k0, int tile_j0)
+// ---- panel solve: G[k0:k0+128, tj*128 : +128] <- U_kk^-T * (same); thread c owns column c, no barriers in the loop.
+//      The extra last workgroup solves for the identity instead and stores U_kk^-T (= the transposed inverse of the
+//      diagonal factor) into winv_t: the back substitution then needs only products, no serial solves ----------------
+__global__ void __launch_bounds__(TILE * PQ)
+trsm_tile_kernel(float* __restrict__ G, long long ldg, int k0, int tile_j0, int n_tiles, float* __restrict__ winv_t)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* UT = sm;                    // [128][128] U_kk transposed: UT[r][m] = U[m][r]
-    float* Y = sm + TILE * TILE;       // [128][128] the tile, solved in place; thread c touches only column c
-    const int c = threadIdx.x;
+    float* Y = sm + TILE * TILE;       // [128][128] the tile, solved in place; only the threads of column c touch column c
+    const int t = threadIdx.x, c = t & (TILE - 1), q = t >> 7;
+    const bool inverse = (int)blockIdx.x == n_tiles;
     const long long j0g = (long long)(tile_j0 + blockIdx.x) * TILE;
     const float* Gk = G + (long long)k0 * ldg + k0;
-    float* B = G + (long long)k0 * ldg + j0g;
-#pragma unroll 16
-    for (int r = 0; r < TILE; ++r) {
-        UT[c * TILE + r] = Gk[(long long)r * ldg + c];      // coalesced global read, transposed store
-        Y[r * TILE + c] = B[(long long)r * ldg + c];
+    float* B = inverse ? winv_t : G + (long long)k0 * ldg + j0g;
+    const long long ldb = inverse ? TILE : ldg;
+    // 16-byte loads: thread t takes 4 columns of row (t/32 + 16*pass)
+    const int lr = t >> 5, lc = (t & 31) * 4;
+#pragma unroll 8
+    for (int r = lr; r < TILE; r += 16) {
+        const f32x4s u = *(const f32x4s*)(Gk + (long long)r * ldg + lc);
+        UT[(lc + 0) * TILE + r] = u[0]; UT[(lc + 1) * TILE + r] = u[1];
+        UT[(lc + 2) * TILE + r] = u[2]; UT[(lc + 3) * TILE + r] = u[3];
+        f32x4s b;
+        if (inverse) b = (f32x4s){r == lc ? 1.f : 0.f, r == lc + 1 ? 1.f : 0.f, r == lc + 2 ? 1.f : 0.f, r == lc + 3 ? 1.f : 0.f};
+        else b = *(const f32x4s*)(B + (long long)r * ldb + lc);
+        *(f32x4s*)(Y + r * TILE + lc) = b;
     }
     __syncthreads();
     for (int jb = 0; jb < NIB; ++jb) {
         const int j0 = jb * IB;
+        // every one of the column's four threads solves the 16 x 16 block redundantly (it needs y in registers) ...
         float y[IB];
 #pragma unroll
         for (int m = 0; m < IB; ++m) y[m] = Y[(j0 + m) * TILE + c];
-        // 16 x 16 forward substitution with L = U^T: y[m] = (b[m] - sum_{q<m} U[j0+q][j0+m] y[q]) / U[j0+m][j0+m]
+        // forward substitution with L = U^T: y[m] = (b[m] - sum_{p<m} U[j0+p][j0+m] y[p]) / U[j0+m][j0+m]
 #pragma unroll
         for (int m = 0; m < IB; ++m) {
             float col[IB];
             ld16(UT + (j0 + m) * TILE + j0, col);
             float acc = y[m];
 #pragma unroll
-            for (int q = 0; q < m; ++q) acc -= col[q] * y[q];
+            for (int p = 0; p < m; ++p) acc -= col[p] * y[p];
             y[m] = acc / col[m];
         }
+        __syncthreads();   // all four threads have read the block rows before thread 0 overwrites them
+        if (q == 0) {
 #pragma unroll
-        for (int m = 0; m < IB; ++m) Y[(j0 + m) * TILE + c] = y[m];
-        // rows below the block: b[r] -= sum_m U[j0+m][r] y[m]
-#pragma unroll 4
-        for (int r = j0 + IB; r < TILE; ++r) {
+            for (int m = 0; m < IB; ++m) Y[(j0 + m) * TILE + c] = y[m];
+        }
+        // ... and takes every fourth of the rows below: b[r] -= sum_m U[j0+m][r] y[m]
+#pragma unroll 2
+        for (int r = j0 + IB + q; r < TILE; r += PQ) {
             float col[IB];
             ld16(UT + r * TILE + j0, col);
-            float acc = Y[r * TILE + c];
+            float acc0 = Y[r * TILE + c], acc1 = 0.0f;
 #pragma unroll
-            for (int m = 0; m < IB; ++m) acc -= col[m] * y[m];
-            Y[r * TILE + c] = acc;
+            for (int m = 0; m < IB; m += 2) { acc0 -= col[m] * y[m]; acc1 -= col[m + 1] * y[m + 1]; }
+            Y[r * TILE + c] = acc0 + acc1;
         }
+        __syncthreads();   // the next block's rows are complete
     }
-    __syncthreads();
-#pragma unroll 16
-    for (int r = 0; r < TILE; ++r) B[(long long)r * ldg + c] = Y[r * TILE + c];
+#pragma unroll 8
+    for (int r = lr; r < TILE; r += 16) *(f32x4s*)(B + (long long)r * ldb + lc) = *(const f32x4s*)(Y + r * TILE + lc);
 }
 
-// ---- back substitution ------------------------------------------------------------------------------
-// R[k0:k0+128, 0:nrhs] = U_kk^-1 * Y_k,  Y_k = G[k0:k0+128, rhs0:rhs0+nrhs]; thread c owns RHS column c (nrhs <= 144)
-__global__ void __launch_bounds__(192)
-backsolve_tile_kernel(const float* __restrict__ G, long long ldg, int k0, int rhs0, int nrhs,
-                      float* __restrict__ R, long long ldr)
-{
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* U = sm;                     // [128][128] U_kk row-major
-    float* Y = sm + TILE * TILE;       // [128][nrhs]
-    const int c = threadIdx.x;
-    const float* Gk = G + (long long)k0 * ldg + k0;
-    const float* Yg = G + (long long)k0 * ldg + rhs0;
-    for (int idx = c; idx < TILE * TILE; idx += 192) {
-        const int r = idx >> 7, cc = idx & 127;
-        U[idx] = Gk[(long long)r * ldg + cc];
-    }
-    for (int idx = c; idx < TILE * nrhs; idx += 192) {
-        const int r = idx / nrhs, cc = idx - r * nrhs;
-        Y[idx] = Yg[(long long)r * ldg + cc];
-    }
-    __syncthreads();
-    if (c < nrhs) {
-        for (int jb = NIB - 1; jb >= 0; --jb) {
-            const int j0 = jb * IB;
-            float x[IB];
-#pragma unroll
-            for (int m = 0; m < IB; ++m) x[m] = Y[(j0 + m) * nrhs + c];
-            // x[i] = (y[i] - sum_{m>i} U[j0+i][j0+m] x[m]) / U[j0+i][j0+i], i descending
-#pragma unroll
-            for (int i = IB - 1; i >= 0; --i) {
-                float row[IB];
-                ld16(U + (j0 + i) * TILE + j0, row);
-                float acc = x[i];
-#pragma unroll
-                for (int m = i + 1; m < IB; ++m) acc -= row[m] * x[m];
-                x[i] = acc / row[i];
-            }
-#pragma unroll
-            for (int m = 0; m < IB; ++m) Y[(j0 + m) * nrhs + c] = x[m];
-            // rows above the block: y[r] -= sum_m U[r][j0+m] x[m]
-#pragma unroll 4
-            for (int r = 0; r < j0; ++r) {
-                float row[IB];
-                ld16(U + r * TILE + j0, row);
-                float acc = Y[r * nrhs + c];
-#pragma unroll
-                for (int m = 0; m < IB; ++m) acc -= row[m] * x[m];
-                Y[r * nrhs + c] = acc;
-            }
-        }
-    }
-    __syncthreads();
-    for (int idx = c; idx < TILE * nrhs; idx += 192) {
-        const int r = idx / nrhs, cc = idx - r * nrhs;
-        R[(long long)(k0 + r) * ldr + cc] = Y[idx];
-    }
-}
-
-// Y_i -= U_ik * R_k for every tile row i < k  (one workgroup per i; thread (tr, tc): rows tr+16a, columns tc+16b)
+// ---- back substitution, one launch per tile step k (descending) ------------------------------------------------
+// every workgroup first forms R_k = U_kk^-1 Y_k = (W^T)^T Y_k from the stored transposed inverse (a 128x128x nrhs
+// product, redundantly: it is cheaper than a launch boundary); workgroup k stores it, workgroup i < k then updates
+// Y_i -= U_ik R_k.  Thread (tr, tc) owns rows tr+16a and columns tc+16b.
+template <int NJ>
 __global__ void __launch_bounds__(256)
-backsolve_update_kernel(float* __restrict__ G, long long ldg, int k0, int rhs0, int nrhs,
-                        const float* __restrict__ R, long long ldr)
+backsolve_step_kernel(float* __restrict__ G, long long ldg, int k0, int rhs0, const float* __restrict__ winv_t,
+                      float* __restrict__ R_base, long long ldr, int col0)
 {
+    // this launch handles the RHS columns [col0, col0 + 16*NJ) (wide right-hand sides are processed in column chunks)
+    constexpr int nrhs = NJ * 16;
+    rhs0 += col0;
+    float* R = R_base + col0;
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* U = sm;                     // [128][128+4] U_ik row-major (padded: rows tr+16a of one wave hit distinct banks)
-    float* Rk = sm + TILE * (TILE + 4);   // [128][nrhs]
+    float* A = sm;                          // [128][128+4]: first W^T (k-major for the product), then U_ik
+    float* Yk = sm + TILE * (TILE + 4);     // [128][nrhs]
+    float* Rk = Yk + TILE * nrhs;           // [128][nrhs]
     const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
-    const int NJ = nrhs >> 4;
+    const int k = k0 / TILE;
+    const bool last = (int)blockIdx.x == k;
+    const int lr = t >> 5, lc = (t & 31) * 4;
+    const float* Yg = G + (long long)k0 * ldg + rhs0;
+    for (int r = lr; r < TILE; r += 8) *(f32x4s*)(A + r * (TILE + 4) + lc) = *(const f32x4s*)(winv_t + r * TILE + lc);
+    for (int idx = t; idx < TILE * nrhs; idx += 256) {
+        const int r = idx / nrhs, cc = idx - r * nrhs;     // nrhs is a compile-time constant here
+        Yk[idx] = Yg[(long long)r * ldg + cc];
+    }
+    __syncthreads();
+    float acc[8][NJ];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < NJ; ++b) acc[a][b] = 0.0f;
+    // R_k[r][c] = sum_m W^T[m][r] * Y_k[m][c]
+    for (int m = 0; m < TILE; ++m) {
+        float wr[8], yc[NJ];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) wr[a] = A[m * (TILE + 4) + tr + 16 * a];
+#pragma unroll
+        for (int b = 0; b < NJ; ++b) yc[b] = Yk[m * nrhs + tc + 16 * b];
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b < NJ; ++b) acc[a][b] += wr[a] * yc[b];
+    }
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < NJ; ++b) {
+            Rk[(tr + 16 * a) * nrhs + tc + 16 * b] = acc[a][b];
+            if (last) R[(long long)(k0 + tr + 16 * a) * ldr + tc + 16 * b] = acc[a][b];
+        }
+    if (last) return;
+    __syncthreads();
+    // Y_i -= U_ik * R_k
     const long long i0 = (long long)blockIdx.x * TILE;
     const float* Uik = G + i0 * ldg + k0;
     float* Yi = G + i0 * ldg + rhs0;
-    for (int idx = t; idx < TILE * TILE; idx += 256) {
-        const int r = idx >> 7, cc = idx & 127;
-        U[r * (TILE + 4) + cc] = Uik[(long long)r * ldg + cc];
-    }
-    for (int idx = t; idx < TILE * nrhs; idx += 256) {
-        const int r = idx / nrhs, cc = idx - r * nrhs;
-        Rk[idx] = R[(long long)(k0 + r) * ldr + cc];
-    }
+    for (int r = lr; r < TILE; r += 8) *(f32x4s*)(A + r * (TILE + 4) + lc) = *(const f32x4s*)(Uik + (long long)r * ldg + lc);
     __syncthreads();
-    float acc[8][9];
 #pragma unroll
     for (int a = 0; a < 8; ++a)
 #pragma unroll
-        for (int b = 0; b < 9; ++b) acc[a][b] = 0.0f;
+        for (int b = 0; b < NJ; ++b) acc[a][b] = 0.0f;
     for (int m = 0; m < TILE; m += 4) {
         f32x4s ur[8];
 #pragma unroll
-        for (int a = 0; a < 8; ++a) ur[a] = *(const f32x4s*)(U + (tr + 16 * a) * (TILE + 4) + m);
+        for (int a = 0; a < 8; ++a) ur[a] = *(const f32x4s*)(A + (tr + 16 * a) * (TILE + 4) + m);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float xc[9];
+            float xc[NJ];
 #pragma unroll
-            for (int b = 0; b < 9; ++b) xc[b] = (b < NJ) ? Rk[(m + e) * nrhs + tc + 16 * b] : 0.0f;
-            if (NJ <= 3) {
+            for (int b = 0; b < NJ; ++b) xc[b] = Rk[(m + e) * nrhs + tc + 16 * b];
 #pragma unroll
-                for (int a = 0; a < 8; ++a)
+            for (int a = 0; a < 8; ++a)
 #pragma unroll
-                    for (int b = 0; b < 3; ++b) acc[a][b] += ur[a][e] * xc[b];
-            } else {
-#pragma unroll
-                for (int a = 0; a < 8; ++a)
-#pragma unroll
-                    for (int b = 0; b < 9; ++b) acc[a][b] += ur[a][e] * xc[b];
-            }
+                for (int b = 0; b < NJ; ++b) acc[a][b] += ur[a][e] * xc[b];
         }
     }
 #pragma unroll
     for (int a = 0; a < 8; ++a)
 #pragma unroll
-        for (int b = 0; b < 9; ++b)
-            if (b < NJ) Yi[(long long)(tr + 16 * a) * ldg + tc + 16 * b] -= acc[a][b];
+        for (int b = 0; b < NJ; ++b) Yi[(long long)(tr + 16 * a) * ldg + tc + 16 * b] -= acc[a][b];
 }
 
 }  // namespace
@@ -478,38 +475,45 @@ void sdm_launch_add_diag(float* G, long long ldg, int F, const double* fro2, int
 void sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs, float* R_out,
                                long long ldr, float* work, int* status, hipStream_t stream)
 {
-    (void)work;
+    // work: Tf * 128 * 128 floats, receives the transposed inverses U_kk^-T of the diagonal factor tiles
     const int Tf = (F + TILE - 1) / TILE;          // factor tiles
-    const int ncols = rhs0 + TILE;                 // factor tiles + one RHS tile column
+    const int ncols = rhs0 + TILE * ((nrhs + TILE - 1) / TILE);   // factor tiles + one or two RHS tile columns
     const int T = ncols / TILE;
     const size_t lds_potrf = ((size_t)TILE * TILE + TILE * IB + IB * IB + 4) * sizeof(float);
     const size_t lds_trsm = ((size_t)2 * TILE * TILE) * sizeof(float);
-    const size_t lds_backs = ((size_t)TILE * TILE + (size_t)TILE * nrhs) * sizeof(float);
-    const size_t lds_back = ((size_t)TILE * (TILE + 4) + (size_t)TILE * nrhs) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)potrf_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)trsm_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)backsolve_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)backsolve_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define BSATTR(NJv) (void)hipFuncSetAttribute((const void*)backsolve_step_kernel<NJv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+        BSATTR(1); BSATTR(2); BSATTR(3); BSATTR(4); BSATTR(5);
+#undef BSATTR
         attr_done = true;
     }
     for (int k = 0; k < Tf; ++k) {
         const int k0 = k * TILE;
-        hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(TILE), lds_potrf, stream, G, ldg, k0, status);
+        hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(TILE * PQ), lds_potrf, stream, G, ldg, k0, status);
         const int ntr = T - (k + 1);
-        if (ntr > 0) {
-            hipLaunchKernelGGL(trsm_tile_kernel, dim3(ntr), dim3(TILE), lds_trsm, stream, G, ldg, k0, k + 1);
-            // trailing update of tiles (ti >= k+1, tj >= ti) from the freshly solved panel rows
-            sdm_launch_syrk_tn(G + (long long)k0 * ldg, ldg, TILE, ncols, G, ldg, -1.0f, 1, k + 1, stream);
-        }
+        // ntr panel tiles + one workgroup that produces U_kk^-T for the back substitution
+        hipLaunchKernelGGL(trsm_tile_kernel, dim3(ntr + 1), dim3(TILE * PQ), lds_trsm, stream, G, ldg, k0, k + 1, ntr,
+                           work + (size_t)k * TILE * TILE);
+        // trailing update of tiles (ti >= k+1, tj >= ti) from the freshly solved panel rows
+        if (ntr > 0) sdm_launch_syrk_tn(G + (long long)k0 * ldg, ldg, TILE, ncols, G, ldg, -1.0f, 1, k + 1, stream);
     }
+    const int nj = nrhs / 16;   // nrhs is a multiple of 16, <= 144
     for (int k = Tf - 1; k >= 0; --k) {
-        const int k0 = k * TILE;
-        hipLaunchKernelGGL(backsolve_tile_kernel, dim3(1), dim3(192), lds_backs, stream, G, ldg, k0, rhs0, nrhs,
-                           R_out, ldr);
-        if (k > 0)
-            hipLaunchKernelGGL(backsolve_update_kernel, dim3(k), dim3(256), lds_back, stream, G, ldg, k0, rhs0,
-                               nrhs, R_out, ldr);
+        float* wk = work + (size_t)k * TILE * TILE;
+#define BS(NJv, C0) hipLaunchKernelGGL(backsolve_step_kernel<NJv>, dim3(k + 1), dim3(256), \
+                                       ((size_t)TILE * (TILE + 4) + 2 * (size_t)TILE * NJv * 16) * sizeof(float), stream, G, ldg, k * TILE, rhs0, wk, R_out, ldr, C0)
+        // the right-hand sides are independent per column: at most 5 column tiles (80 columns) per launch keep the
+        // workgroup inside the 160 KB of LDS
+        for (int done = 0; done < nj;) {
+            const int left = nj - done;
+            const int take = left <= 5 ? left : (left >= 8 ? 4 : left - 3);   // 6 -> 3+3, 7 -> 4+3, 8 -> 4+4, 9 -> 4+5
+            switch (take) { case 1: BS(1, done * 16); break; case 2: BS(2, done * 16); break; case 3: BS(3, done * 16); break;
+                            case 4: BS(4, done * 16); break; default: BS(5, done * 16); break; }
+            done += take;
+        }
+#undef BS
     }
 }

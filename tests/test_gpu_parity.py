@@ -257,6 +257,27 @@ def test_train_cascade_matches_oracle(faces, reg):
     assert rel_l2(pred, opred) < 1e-4
 
 
+def test_train_rcr68_two_rhs_tiles(faces):
+    """RCR-68: 2L = 136 target columns do not fit one 128-wide tile -> two RHS tile columns through Gram, Cholesky
+    and back substitution; also exercises the Manual regulariser with the bias row regularised."""
+    images, boxes, gt, _, _ = faces
+    ids = ibug.IBUG68_IDS
+    re, le = ibug.eye_indices(ids)
+    x_star, x0, idx = synth.make_samples(boxes[:96], gt[:96], ids, n_perturb=2, seed=15)   # N = 288
+    params = [(1, 2, 14, 4, 0.8), (1, 2, 10, 4, 0.5)]                                       # F = 68*4*16+1 = 4353
+    sdo = SupervisedDescentOptimiser([LinearRegressor(Regulariser(0, 25.0, True)) for _ in params])
+    hog = HogTransform(images[:96], [HoGParam(*p) for p in params], ids, ibug.RIGHT_EYE_IDS, ibug.LEFT_EYE_IDS, idx)
+    x_gpu = sdo.train(x_star, x0, None, hog)
+    assert sdo.regressors[0].x.shape == (4353, 136)
+    ohog = orc.HogTransform(images[:96], [orc.HoGParam(*p) for p in params], re, le, idx, n_threads=os.cpu_count() or 1)
+    osdo = orc.SupervisedDescentOptimiser([orc.LinearRegressor(orc.Regulariser(0, 25.0, True)) for _ in params],
+                                          orc.InterEyeDistanceNormalisation(re, le))
+    x_orc = osdo.train(x_star, x0, None, ohog)
+    assert rel_l2(x_gpu, x_orc) < 1e-4
+    A0 = ohog(x0, 0)
+    assert rel_l2(A0 @ sdo.regressors[0].x, A0 @ osdo.regressors[0].x) < 1e-3   # the regressors predict the same updates
+
+
 def test_detect_rcr22_free_running_and_teacher_forced(gpu_ctx, faces):
     """Config 'RCR-22 detect' with an oracle-supplied model: free-running landmarks within 1e-4, and with
     the oracle's x_k fed to level k (teacher forcing) the integer patch decisions are identical."""
