@@ -90,7 +90,7 @@ void sdm_launch_targets(const float* x, const float* xstar, int N, int L, const 
 // ncols x ncols matrix (i-tile <= j-tile); A is [rows][lda], C is [ncols][ldc]. ncols % 128 == 0.
 // tile_i0 / tile_j0 restrict the update to tiles with i-tile >= tile_i0 (used by the Cholesky).
 void sdm_launch_syrk_tn(const float* A, long long lda, int rows, int ncols, float* C, long long ldc,
-                        float alpha, int accumulate, int tile_i0, hipStream_t stream);
+                        float alpha, int accumulate, int tile_i0, hipStream_t stream, int tile_rows = 0);
 
 // Frobenius norm^2 (double) of the symmetric matrix whose upper triangle (incl. diagonal) of the
 // leading F x F block is stored in G; result accumulated into *out (must be zeroed).

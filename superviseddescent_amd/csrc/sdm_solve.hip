@@ -449,11 +449,13 @@ backsolve_step_kernel(float* __restrict__ G, long long ldg, int k0, int rhs0, co
 }  // namespace
 
 void sdm_launch_syrk_tn(const float* A, long long lda, int rows, int ncols, float* C, long long ldc,
-                        float alpha, int accumulate, int tile_i0, hipStream_t stream)
+                        float alpha, int accumulate, int tile_i0, hipStream_t stream, int tile_rows)
 {
+    // tiles (ti, tj) with tile_i0 <= ti < tile_i0 + tile_rows (all remaining tile rows when tile_rows <= 0), tj >= ti
     const int T = ncols / TILE - tile_i0;
     if (T <= 0 || rows <= 0) return;
-    hipLaunchKernelGGL(syrk_tn_kernel, dim3(T, T), dim3(256), 0, stream, A, lda, rows, C, ldc, alpha,
+    const int Ty = (tile_rows > 0 && tile_rows < T) ? tile_rows : T;
+    hipLaunchKernelGGL(syrk_tn_kernel, dim3(T, Ty), dim3(256), 0, stream, A, lda, rows, C, ldc, alpha,
                        accumulate, tile_i0);
 }
 
@@ -490,15 +492,23 @@ void sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrh
 #undef BSATTR
         attr_done = true;
     }
+    // Panels are processed in groups of LAZY: inside a group only the NEXT tile row receives the pending rank-128
+    // updates (a thin launch); the whole trailing matrix is updated once per group with K = 128*LAZY.  That is 1/LAZY of
+    // the passes over the (up to 3 GB) trailing matrix of the plain right-looking scheme and a 4x deeper MFMA K-loop.
+    const int LAZY = 4;
     for (int k = 0; k < Tf; ++k) {
         const int k0 = k * TILE;
+        const int g0 = (k / LAZY) * LAZY;                 // first panel of this group
+        if (k > g0)   // bring tile row k up to date with the panels g0 .. k-1 of its group
+            sdm_launch_syrk_tn(G + (long long)g0 * TILE * ldg, ldg, (k - g0) * TILE, ncols, G, ldg, -1.0f, 1, k, stream, 1);
         hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(TILE * PQ), lds_potrf, stream, G, ldg, k0, status);
         const int ntr = T - (k + 1);
         // ntr panel tiles + one workgroup that produces U_kk^-T for the back substitution
         hipLaunchKernelGGL(trsm_tile_kernel, dim3(ntr + 1), dim3(TILE * PQ), lds_trsm, stream, G, ldg, k0, k + 1, ntr,
                            work + (size_t)k * TILE * TILE);
-        // trailing update of tiles (ti >= k+1, tj >= ti) from the freshly solved panel rows
-        if (ntr > 0) sdm_launch_syrk_tn(G + (long long)k0 * ldg, ldg, TILE, ncols, G, ldg, -1.0f, 1, k + 1, stream);
+        const bool group_end = (k + 1) % LAZY == 0 || k == Tf - 1;
+        if (group_end && ntr > 0)   // trailing update of all tiles (ti >= k+1, tj >= ti) from the group's panel rows
+            sdm_launch_syrk_tn(G + (long long)g0 * TILE * ldg, ldg, (k + 1 - g0) * TILE, ncols, G, ldg, -1.0f, 1, k + 1, stream, 0);
     }
     const int nj = nrhs / 16;   // nrhs is a multiple of 16, <= 144
     for (int k = Tf - 1; k >= 0; --k) {
