@@ -77,13 +77,25 @@ apply_partial_kernel(const float* __restrict__ feat, long long ldf, int N, int k
 #pragma unroll
     for (int c = 0; c < NT; ++c) brow[c] = Rt + (long long)(16 * c + li) * ldr + 4 * lq;
 
-    for (int g = g0 + wave; g < g1; g += APPLY_WAVES) {
+    // software pipeline: the operands of k-group g+4 are in flight while the 4*RT*NT MFMAs of group g issue
+    f32x4 a[RT], b[NT], an[RT], bn[NT];
+    int g = g0 + wave;
+    if (g < g1) {
         const long long k0 = (long long)g * 16;
-        f32x4 a[RT], b[NT];
 #pragma unroll
         for (int r = 0; r < RT; ++r) a[r] = *(const f32x4*)(arow[r] + k0);
 #pragma unroll
         for (int c = 0; c < NT; ++c) b[c] = *(const f32x4*)(brow[c] + k0);
+    }
+    for (; g < g1; g += APPLY_WAVES) {
+        const int gn = g + APPLY_WAVES;
+        if (gn < g1) {
+            const long long k1 = (long long)gn * 16;
+#pragma unroll
+            for (int r = 0; r < RT; ++r) an[r] = *(const f32x4*)(arow[r] + k1);
+#pragma unroll
+            for (int c = 0; c < NT; ++c) bn[c] = *(const f32x4*)(brow[c] + k1);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -91,6 +103,10 @@ apply_partial_kernel(const float* __restrict__ feat, long long ldf, int N, int k
 #pragma unroll
                 for (int c = 0; c < NT; ++c)
                     acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][e], b[c][e], acc[r][c], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) a[r] = an[r];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) b[c] = bn[c];
     }
 
     // cross-wave reduction in wave order (deterministic)
