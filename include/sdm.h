@@ -93,8 +93,9 @@ int sdm_feature_dim(const sdm_ctx* ctx, int level);          /* F of that level,
 #define SDM_HOG_EXACT_ORDER 0
 #define SDM_HOG_FAST 1
 int sdm_set_hog_mode(sdm_ctx* ctx, int mode);
-/* Which kernel a level runs: *fast_kernel = 1 when the fused S<=64 kernel is used, *fast_bins = 1 when the
- * un-normalised orientation arg-max was verified exhaustively (511x511 gradients) for that level. */
+/* Which kernel a level runs: *fast_kernel = 1 when the fused S<=64 kernel is used; *fast_bins = the orientation
+ * binning method that passed the exhaustive on-device check (511x511 gradients) for that level: 2 = sector count,
+ * 1 = un-normalised arg-max, 0 = the reference's normalise-and-score arithmetic. */
 int sdm_get_hog_info(sdm_ctx* ctx, int level, int* fast_kernel, int* fast_bins);
 
 /* Images: the `const std::vector<cv::Mat>& images` of HogTransform (adaptive_vlhog.hpp:92,188),

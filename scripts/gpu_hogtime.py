@@ -1,0 +1,19 @@
+"""Times sdm_hog_features per level (4096 faces, RCR-22, shipped HoG params); SDM_HIP_LIB selects an experiment build."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from superviseddescent_amd import Context, HoGParam, ibug, synth
+ids = ibug.RCR22_IDS; re, le = ibug.eye_indices(ids)
+params = [HoGParam(*p) for p in ibug.SHIPPED_HOG_PARAMS]
+images, boxes, gt = synth.make_faces(4096, seed=11)
+xs, x0, idx = synth.make_samples(boxes, gt, ids, 0, seed=12)
+ctx = Context(0); ctx.set_model_geometry(len(ids), re, le, params); ctx.upload_images(images); ctx.set_sample_image_index(None); ctx.set_x(x0)
+ctx.enable_timing(True)
+out = []
+for l in range(4):
+    for _ in range(3): ctx.hog_features(l)
+    ctx.synchronize(); ctx.get_timing(reset=True)
+    for _ in range(10): ctx.hog_features(l)
+    ctx.synchronize(); t = ctx.get_timing(reset=True)["hog"][0] / 10
+    out.append(t)
+print(os.environ.get("SDM_HIP_LIB", "default"), " ".join(f"{t:.3f}" for t in out), f"sum {sum(out):.3f} ms")

@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsdm_hip.so")
+LIB_PATH = os.environ.get("SDM_HIP_LIB") or os.path.join(_HERE, "lib", "libsdm_hip.so")
 
 SDM_OK = 0
 SDM_ERR_INVALID, SDM_ERR_NO_DEVICE, SDM_ERR_HIP, SDM_ERR_EMPTY_PATCH, SDM_ERR_NOT_SPD, SDM_ERR_COMM = \

@@ -351,17 +351,22 @@ int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int*
             lv.ox[k] = (float)cos(angle);
             lv.oy[k] = (float)sin(angle);
         }
+        lv.n_sector = lv.O / 2;
+        for (int j = 0; j < lv.n_sector; ++j) lv.sector_t[j] = (float)tan((2 * j + 1) * 3.141592653589793 / (2.0 * lv.O));
         if (sdm_hog_lds_bytes(lv, 4) > 160 * 1024) return fail(SDM_ERR_INVALID, "HOG geometry exceeds the LDS budget");
         c->levels.push_back(lv); c->params.push_back(p);
         {
             // exhaustive on-device check of the orientation shortcut for this level's orientation count
-            int mism = 1;
-            HIP_TRY(hipMemsetAsync(c->status.p, 0, sizeof(int), c->stream));
-            sdm_launch_verify_fast_bins(lv, c->status.p, c->stream);
-            HIP_TRY(hipMemcpyAsync(&mism, c->status.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            int mism[2] = {1, 1};
+            DevBuf<int> dm;
+            int rcv = dm.ensure(2, true, c->stream);
+            if (rcv) return rcv;
+            sdm_launch_verify_fast_bins(lv, dm.p, c->stream);
+            HIP_TRY(hipMemcpyAsync(mism, dm.p, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
-            HIP_TRY(hipMemsetAsync(c->status.p, 0, sizeof(int), c->stream));
-            c->fast_bins.push_back(mism == 0 ? 1 : 0);
+            dm.release();
+            // 2 = sector count, 1 = un-normalised arg-max, 0 = reference arithmetic
+            c->fast_bins.push_back(mism[1] == 0 ? 2 : (mism[0] == 0 ? 1 : 0));
             c->fast_kernel.push_back(sdm_hog_fast_supported(lv) ? 1 : 0);
         }
         const int F = L * lv.P + 1;
@@ -610,7 +615,7 @@ int sdm_set_allreduce(sdm_ctx* c, sdm_allreduce_fn fn, void* user, int world_siz
 int sdm_allreduce_gram_rhs(sdm_ctx* c)
 {
     if (!c || c->g_level < 0) return fail(SDM_ERR_INVALID, "no Gram matrix to reduce");
-    if (!c->allreduce || c->world_size == 1) return SDM_OK;
+    if (!c->allreduce) return SDM_OK;
     Timer t(c, SDM_T_ALLREDUCE);
     // rows [0, Fp) hold every tile the solve reads (Gram upper tiles + RHS tile column)
     const size_t count = (size_t)c->g_fp * c->g_ncols;

@@ -30,6 +30,9 @@
 //    normalise-then-score arithmetic is used;
 //  * blockIdx is remapped so that the 22/68 patches of one face run on one XCD (its image is then fetched
 //    from HBM into one L2 instead of eight).
+#ifndef SDM_EXP
+#define SDM_EXP 0
+#endif
 #include "sdm_kernels.h"
 
 #pragma clang fp contract(off)
@@ -122,6 +125,28 @@ __device__ inline void bin_unnormalised(float gx, float gy, const HogLevelDev& l
     }
 }
 
+// Sector method: fold the gradient into the half plane gy > 0 (or gy == 0, gx > 0), count how many of the floor(O/2)
+// sector boundaries tan((2j+1)pi/2O) the slope |gy|/|gx| exceeds -> index m of the nearest orientation in the first
+// quadrant, then unfold (second quadrant: O - m; flipped half plane: + O).  ~3 instructions per boundary instead of
+// ~6 per orientation; used only after the exhaustive on-device comparison with the reference arithmetic.
+template <int TO>
+__device__ inline void bin_sector(float gx, float gy, const HogLevelDev& lv, int O, int& bin)
+{
+    const bool flip = (gy < 0.0f) || (gy == 0.0f && gx < 0.0f);
+    const float fx = flip ? -gx : gx;
+    const float a = __builtin_fabsf(gx), b = __builtin_fabsf(gy);
+    int m = 0;
+#pragma unroll
+    for (int j = 0; j < (TO ? TO / 2 : SDM_MAX_ORIENT / 2); ++j) {
+        if (TO == 0 && j >= lv.n_sector) break;
+        m += (b > a * lv.sector_t[j]) ? 1 : 0;
+    }
+    int d = (fx >= 0.0f) ? m : O - m;
+    d += flip ? O : 0;
+    d = d >= 2 * O ? d - 2 * O : d;
+    bin = (a == 0.0f && b == 0.0f) ? -1 : d;
+}
+
 // per-wave LDS layout.  Region A lives for the whole patch, region B is first the rolling private
 // accumulators of the row loop and afterwards the scratch of the normalisation phase.
 struct FastLds {
@@ -169,7 +194,7 @@ __device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ inline float lane_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 
 // TO / TC: compile-time orientation count / cell count (0 = take the run-time value from lv)
-template <int ACC, bool FASTBIN, int TO, int TC, bool PROF = false>
+template <int ACC, int FASTBIN, int TO, int TC, bool PROF = false>
 __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* __restrict__ xr, int L, int landmark,
                                const EyeIdxDev& eyes, const HogLevelDev& lv, unsigned char* lds_base,
                                float* __restrict__ out_desc, int* idx_row, int* status,
@@ -271,6 +296,9 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
     int cur_by = -2;
     auto flush_band = [&](int band) {
         const int slot = band & 1;
+#if SDM_EXP == 2
+        if (band != 12345) return;
+#endif
         for (int t = lane; t < 2 * O * PW; t += 64) {
             u64* cp = w.copies + (size_t)(slot * 2 * O * PW + t) * R;
             u64 sum = 0;
@@ -334,7 +362,9 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
             const float g2 = gx * gx + gy * gy;
             float g = FASTBIN ? sqrt_int_exact(g2) : sqrtf(g2);
             int bin;
-            if (FASTBIN) {
+            if (FASTBIN == 2) {
+                bin_sector<TO>(gx, gy, lv, O, bin);
+            } else if (FASTBIN == 1) {
                 float best = 0.0f;
                 bin = -1;
 #pragma unroll
@@ -381,10 +411,19 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
                 const int slot_stride = 2 * O * PW * R;
                 const int i0 = (int)(__umul24((unsigned)bin, (unsigned)(PW * R)) + (unsigned)(lane_off + (by & 1) * slot_stride));
                 const int i1 = (int)(__umul24((unsigned)bin, (unsigned)(PW * R)) + (unsigned)(lane_off + ((by + 1) & 1) * slot_stride));
+#if SDM_EXP == 1
+                { u64 q0 = fx(va), q1 = fx(vb), q2 = fx(vc), q3 = fx(vd); asm volatile("" :: "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(i0), "v"(i1)); }
+#elif SDM_EXP == 3
+                atomicAdd((unsigned*)(w.copies + i0 + R), (unsigned)fx(va));
+                atomicAdd((unsigned*)(w.copies + i0), (unsigned)fx(vb));
+                atomicAdd((unsigned*)(w.copies + i1 + R), (unsigned)fx(vc));
+                atomicAdd((unsigned*)(w.copies + i1), (unsigned)fx(vd));
+#else
                 atomicAdd(w.copies + i0 + R, fx(va));     // band by,   column bx+1
                 atomicAdd(w.copies + i0, fx(vb));         // band by,   column bx
                 atomicAdd(w.copies + i1 + R, fx(vc));     // band by+1, column bx+1
                 atomicAdd(w.copies + i1, fx(vd));         // band by+1, column bx
+#endif
             } else {
                 const int base = bin * PWW + (by + 1) * PW + hcol;
                 // reference order per accumulator: (bx+1,by) (bx,by) (bx+1,by+1) (bx,by+1), lanes ascending
@@ -484,7 +523,7 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
     mark(5);   // output stores
 }
 
-template <int ACC, bool FASTBIN, int TO, int TC, bool PROF = false>
+template <int ACC, int FASTBIN, int TO, int TC, bool PROF = false>
 __global__ void __launch_bounds__(HF_WAVES * 64)
 hog_fast_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float* __restrict__ x, int N, int L,
                 EyeIdxDev eyes, HogLevelDev lv, float* __restrict__ feat, long long ldf,
@@ -518,12 +557,14 @@ __global__ void verify_fast_bins_kernel(HogLevelDev lv, int* __restrict__ mismat
     if (i >= 511 * 511) return;
     const float gx = (float)(i % 511 - 255), gy = (float)(i / 511 - 255);
     const float g = sqrtf(gx * gx + gy * gy);
-    int a, b;
+    int a, b, c;
     bin_reference(gx, gy, g, lv, a);
     bin_unnormalised(gx, gy, lv, b);
+    bin_sector<0>(gx, gy, lv, lv.O, c);
     const float g2 = gx * gx + gy * gy;
     const bool sqrt_ok = __builtin_bit_cast(int, sqrt_int_exact(g2)) == __builtin_bit_cast(int, sqrtf(g2));
     if (a != b || !sqrt_ok) atomicAdd(mismatches, 1);
+    if (a != c || !sqrt_ok) atomicAdd(mismatches + 1, 1);
 }
 
 }  // namespace
@@ -551,17 +592,17 @@ static void launch_fast_oc(const ImageSetDev& imgs, const int* img_idx, const fl
     const size_t lds = per * HF_WAVES;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)hog_fast_kernel<ACC_EXACT_ORDER, true, TO, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)hog_fast_kernel<ACC_EXACT_ORDER, false, TO, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)hog_fast_kernel<ACC_FIXED64, true, TO, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)hog_fast_kernel<ACC_FIXED64, false, TO, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define HATTR(A, B) (void)hipFuncSetAttribute((const void*)hog_fast_kernel<A, B, TO, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+        HATTR(ACC_EXACT_ORDER, 0); HATTR(ACC_EXACT_ORDER, 1); HATTR(ACC_EXACT_ORDER, 2);
+        HATTR(ACC_FIXED64, 0); HATTR(ACC_FIXED64, 1); HATTR(ACC_FIXED64, 2);
+#undef HATTR
         attr_done = true;
     }
 #define LAUNCH(ACC, FB)                                                                                              \
     hipLaunchKernelGGL((hog_fast_kernel<ACC, FB, TO, TC>), g, b, lds, stream, imgs, img_idx, x, N, L, eyes, lv, feat, \
                        ldf, idx_out, status, per)
-    if (exact_order) { if (fast_bins) LAUNCH(ACC_EXACT_ORDER, true); else LAUNCH(ACC_EXACT_ORDER, false); }
-    else { if (fast_bins) LAUNCH(ACC_FIXED64, true); else LAUNCH(ACC_FIXED64, false); }
+    if (exact_order) { if (fast_bins == 2) LAUNCH(ACC_EXACT_ORDER, 2); else if (fast_bins == 1) LAUNCH(ACC_EXACT_ORDER, 1); else LAUNCH(ACC_EXACT_ORDER, 0); }
+    else { if (fast_bins == 2) LAUNCH(ACC_FIXED64, 2); else if (fast_bins == 1) LAUNCH(ACC_FIXED64, 1); else LAUNCH(ACC_FIXED64, 0); }
 #undef LAUNCH
 }
 
@@ -574,7 +615,7 @@ void sdm_launch_hog_fast_profile(const ImageSetDev& imgs, const int* img_idx, co
     if (total <= 0 || !(lv.O == 4 && lv.C == 5)) return;
     const size_t per = fast_lds_bytes(lv.cell, lv.C, lv.O, lv.D);
     const unsigned grid = (unsigned)((total + HF_WAVES - 1) / HF_WAVES);
-    hipLaunchKernelGGL((hog_fast_kernel<ACC_FIXED64, true, 4, 5, true>), dim3(grid), dim3(HF_WAVES * 64), per * HF_WAVES,
+    hipLaunchKernelGGL((hog_fast_kernel<ACC_FIXED64, 1, 4, 5, true>), dim3(grid), dim3(HF_WAVES * 64), per * HF_WAVES,
                        stream, imgs, img_idx, x, N, L, eyes, lv, feat, ldf, (int*)nullptr, status, per, prof_dev);
 }
 

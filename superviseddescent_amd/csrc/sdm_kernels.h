@@ -20,6 +20,8 @@ struct HogLevelDev {
     float rel;        // relative_patch_size
     float ox[SDM_MAX_ORIENT];  // (float)cos(k*pi/O)
     float oy[SDM_MAX_ORIENT];  // (float)sin(k*pi/O)
+    int n_sector;              // floor(O/2): sector boundaries inside the first quadrant
+    float sector_t[SDM_MAX_ORIENT / 2];   // (float)tan((2j+1)*pi/(2O))
 };
 
 struct EyeIdxDev {
@@ -54,8 +56,10 @@ void sdm_launch_hog(const ImageSetDev& imgs, const int* img_idx, const float* x,
 
 // Production kernel (sdm_hog_fast.hip), S <= 64.  exact_order: accumulate with ds_add_f32 in the reference's
 // raster order (bit-identical histogram) instead of the exact 2^-36 fixed-point sum; fast_bins: use the
-// un-normalised orientation arg-max (only when sdm_launch_verify_fast_bins counted 0 mismatches).
+// cheaper orientation binning (1 = un-normalised arg-max, 2 = first-quadrant sector count; each only when
+// sdm_launch_verify_fast_bins counted 0 mismatches for it; 0 = the reference arithmetic).
 bool sdm_hog_fast_supported(const HogLevelDev& lv);
+// mismatches_dev[0]: un-normalised arg-max (+ lean sqrt), mismatches_dev[1]: sector method (+ lean sqrt)
 void sdm_launch_verify_fast_bins(const HogLevelDev& lv, int* mismatches_dev, hipStream_t stream);
 void sdm_launch_hog_fast(const ImageSetDev& imgs, const int* img_idx, const float* x, int N, int L,
                          const EyeIdxDev& eyes, const HogLevelDev& lv, float* feat, long long ldf, int* idx_out,

@@ -101,7 +101,7 @@ class Context:
     def hog_info(self, level: int):
         fk, fb = ctypes.c_int(0), ctypes.c_int(0)
         check(self._lib.sdm_get_hog_info(self._h, level, ctypes.byref(fk), ctypes.byref(fb)))
-        return {"fast_kernel": bool(fk.value), "fast_bins": bool(fb.value)}
+        return {"fast_kernel": bool(fk.value), "fast_bins": int(fb.value)}
 
     def feature_dim(self, level: int) -> int:
         return check(self._lib.sdm_feature_dim(self._h, level))

@@ -1,0 +1,62 @@
+"""Worker of tests/test_gpu_distributed.py: launched by torch.distributed.run with one rank per visible GPU.
+Trains a small cascade (a) without a collective and (b) through parallel.make_torch_allreduce on the nccl (= RCCL)
+backend, the engine sharing torch's stream, and checks that (b) == (a) when WORLD_SIZE is 1, or that every rank
+ends with identical regressors when it is larger.  Prints RCCL_WORKER_OK on success."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from superviseddescent_amd import (HogTransform, HoGParam, LinearRegressor, Regulariser,  # noqa: E402
+                                   SupervisedDescentOptimiser, ibug, parallel, synth)
+
+
+def main():
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    ids = ibug.RCR22_IDS
+    params = [HoGParam(1, 3, 12, 4, 0.9), HoGParam(1, 3, 9, 4, 0.6)]
+    images, boxes, gt = synth.make_faces(48, seed=5)
+    xs, x0, idx = synth.make_samples(boxes, gt, ids, n_perturb=3, seed=6)
+    ra, rb = parallel.shard_range(xs.shape[0], rank, world)
+    reg = lambda: Regulariser(Regulariser.RegularisationType.MatrixNorm, 1.5, False)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def train(allreduce, rows):
+        sdo = SupervisedDescentOptimiser([LinearRegressor(reg()) for _ in params], device=local, stream=stream)
+        hog = HogTransform(images, params, ids, ibug.RIGHT_EYE_IDS, ibug.LEFT_EYE_IDS, idx[rows])
+        calls = []
+        fn = None
+        if allreduce is not None:
+            def fn(ptr, count, s):
+                calls.append(count)
+                return allreduce(ptr, count, s)
+        x = sdo.train(xs[rows], x0[rows], None, hog, allreduce=fn, world_size=world, n_train_global=xs.shape[0])
+        return [r.x.copy() for r in sdo.regressors], x, calls
+
+    R_dist, x_dist, calls = train(parallel.make_torch_allreduce(local), slice(ra, rb))
+    assert len(calls) == len(params) and all(c > 0 for c in calls), calls      # one exchange per cascade level
+    if world == 1:
+        R_solo, x_solo, _ = train(None, slice(0, xs.shape[0]))
+        for a, b in zip(R_dist, R_solo):
+            assert np.array_equal(a, b), float(np.abs(a - b).max())            # sum over one rank = identity
+        assert np.array_equal(x_dist, x_solo)
+    for R in R_dist:                                                           # every rank solved the same system
+        t = torch.from_numpy(R).cuda()
+        lo, hi = t.clone(), t.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert torch.equal(lo, hi)
+    assert parallel.global_row_count(rb - ra) == xs.shape[0]
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print("RCCL_WORKER_OK world=%d exchanges=%d floats=%d" % (world, len(calls), calls[0]))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,50 @@
+"""The N-GPU training path on the real backend: torch.distributed "nccl" (= RCCL) summing the engine's Gram/RHS buffer
+in place through the sdm_set_allreduce callback (zero-copy view of engine HBM on torch's stream).  One rank per
+visible GPU (the test box has one), launched exactly as the bench driver launches bench.py."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _torchrun(nproc, script, *args, timeout=600):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), script, *args]
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.gpu
+def test_rccl_allreduce_training(built):
+    import torch
+    n = torch.cuda.device_count()
+    assert n >= 1
+    r = _torchrun(min(n, 2), os.path.join(ROOT, "tests", "_rccl_worker.py"))
+    assert r.returncode == 0 and "RCCL_WORKER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun(built):
+    """bench.py launched the way the driver launches it for N > 1 (here N = visible GPUs, at most 2), reduced sizes."""
+    import json
+    import torch
+    n = min(torch.cuda.device_count(), 2)
+    r = _torchrun(n, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--batch", "256",
+                  "--train-rows", "400", "--no-cpu")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == n and out["value"] > 0 and out["scaling"] == "weak"
+    assert "RCCL" in out["train"]["collective"]

@@ -173,7 +173,7 @@ def test_fast_bins_shortcut_is_verified(gpu_ctx):
     """The un-normalised orientation arg-max is only enabled after an exhaustive on-device check."""
     gpu_ctx.set_model_geometry(len(IDS), RE, LE, SHIPPED)
     info = gpu_ctx.hog_info(0)
-    assert info["fast_kernel"] is True and isinstance(info["fast_bins"], bool)
+    assert info["fast_kernel"] is True and info["fast_bins"] in (0, 1, 2)
 
 
 def test_empty_patch_reports_error(gpu_ctx, faces):
