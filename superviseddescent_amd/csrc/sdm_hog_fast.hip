@@ -30,9 +30,6 @@
 //    normalise-then-score arithmetic is used;
 //  * blockIdx is remapped so that the 22/68 patches of one face run on one XCD (its image is then fetched
 //    from HBM into one L2 instead of eight).
-#ifndef SDM_EXP
-#define SDM_EXP 0
-#endif
 #include "sdm_kernels.h"
 
 #pragma clang fp contract(off)
@@ -44,6 +41,7 @@
 namespace {
 
 typedef unsigned long long u64;
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 
 __device__ inline double ied_of(const float* __restrict__ xr, int L, const EyeIdxDev& e)
 {
@@ -190,6 +188,22 @@ __device__ inline FastLds fast_carve(unsigned char* base, int C, int O, int D)
     return w;
 }
 
+// sum and clear 2*N2 private accumulator copies of one (band, bin, column)
+template <int N2>
+__device__ inline u64 fold_copies(u64x2* c2)
+{
+    u64x2 q[N2];
+#pragma unroll
+    for (int i = 0; i < N2; ++i) q[i] = c2[i];
+    const u64x2 z2 = {0ull, 0ull};
+#pragma unroll
+    for (int i = 0; i < N2; ++i) c2[i] = z2;
+    u64 sum = 0;
+#pragma unroll
+    for (int i = 0; i < N2; ++i) sum += q[i].x + q[i].y;
+    return sum;
+}
+
 __device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ inline float lane_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 
@@ -283,8 +297,10 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
 
     mark(0);   // geometry + per-coordinate tables
     if (ACC == ACC_FIXED64) {
-        for (int i = lane; i < 2 * 2 * O * PW * R; i += 64) w.copies[i] = 0ull;
-        for (int i = lane; i < 2 * O * CC; i += 64) hfin[i] = 0ull;
+        // (16-byte stores: both counts are even and both regions 16-byte aligned)
+        const u64x2 z2 = {0ull, 0ull};
+        for (int i = lane; i < 2 * O * PW * R; i += 64) ((u64x2*)w.copies)[i] = z2;
+        for (int i = lane; i < O * CC; i += 64) ((u64x2*)hfin)[i] = z2;
     } else {
         for (int i = lane; i < 2 * O * PWW; i += 64) histf[i] = 0.0f;
     }
@@ -296,13 +312,14 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
     int cur_by = -2;
     auto flush_band = [&](int band) {
         const int slot = band & 1;
-#if SDM_EXP == 2
-        if (band != 12345) return;
-#endif
         for (int t = lane; t < 2 * O * PW; t += 64) {
             u64* cp = w.copies + (size_t)(slot * 2 * O * PW + t) * R;
             u64 sum = 0;
-            for (int r = 0; r < R; ++r) { sum += cp[r]; cp[r] = 0ull; }
+            // all 16-byte reads in flight, then the clears (integer sum: any order)
+            if (R == 8) sum = fold_copies<4>((u64x2*)cp);
+            else if (R == 6) sum = fold_copies<3>((u64x2*)cp);
+            else if (R == 4) sum = fold_copies<2>((u64x2*)cp);
+            else for (int r = 0; r < R; ++r) { sum += cp[r]; cp[r] = 0ull; }
             const int kbin = t / PW, hc = t - kbin * PW;
             if (band >= 0 && band < C && hc >= 1 && hc <= C) hfin[kbin * CC + band * C + (hc - 1)] = sum;
         }
@@ -411,19 +428,10 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
                 const int slot_stride = 2 * O * PW * R;
                 const int i0 = (int)(__umul24((unsigned)bin, (unsigned)(PW * R)) + (unsigned)(lane_off + (by & 1) * slot_stride));
                 const int i1 = (int)(__umul24((unsigned)bin, (unsigned)(PW * R)) + (unsigned)(lane_off + ((by + 1) & 1) * slot_stride));
-#if SDM_EXP == 1
-                { u64 q0 = fx(va), q1 = fx(vb), q2 = fx(vc), q3 = fx(vd); asm volatile("" :: "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(i0), "v"(i1)); }
-#elif SDM_EXP == 3
-                atomicAdd((unsigned*)(w.copies + i0 + R), (unsigned)fx(va));
-                atomicAdd((unsigned*)(w.copies + i0), (unsigned)fx(vb));
-                atomicAdd((unsigned*)(w.copies + i1 + R), (unsigned)fx(vc));
-                atomicAdd((unsigned*)(w.copies + i1), (unsigned)fx(vd));
-#else
                 atomicAdd(w.copies + i0 + R, fx(va));     // band by,   column bx+1
                 atomicAdd(w.copies + i0, fx(vb));         // band by,   column bx
                 atomicAdd(w.copies + i1 + R, fx(vc));     // band by+1, column bx+1
                 atomicAdd(w.copies + i1, fx(vd));         // band by+1, column bx
-#endif
             } else {
                 const int base = bin * PWW + (by + 1) * PW + hcol;
                 // reference order per accumulator: (bx+1,by) (bx,by) (bx+1,by+1) (bx,by+1), lanes ascending
