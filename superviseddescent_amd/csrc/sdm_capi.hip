@@ -100,6 +100,7 @@ struct sdm_ctx {
 
     // normal equations
     DevBuf<float> G;       // [ncols][ncols]
+    DevBuf<float> gpack;   // data-parallel exchange buffer: upper Gram tiles + RHS tiles, packed
     int g_ncols = 0;
     int g_fp = 0;
     int g_level = -1;
@@ -290,7 +291,7 @@ void sdm_destroy(sdm_ctx* c)
     c->img_owned.release(); c->img_off.release(); c->img_w.release(); c->img_h.release();
     c->img_stride.release(); c->img_idx.release(); c->x[0].release(); c->x[1].release();
     c->xstar.release(); c->feat.release(); c->patch_idx.release(); c->status.release();
-    c->partial.release(); c->G.release(); c->fro.release(); c->Rsol.release(); c->winv.release(); c->lambda_dev.release();
+    c->partial.release(); c->G.release(); c->gpack.release(); c->fro.release(); c->Rsol.release(); c->winv.release(); c->lambda_dev.release();
     for (auto& r : c->Rt) r.release();
     if (c->own_stream) e = hipStreamDestroy(c->stream);
     delete c;
@@ -617,10 +618,18 @@ int sdm_allreduce_gram_rhs(sdm_ctx* c)
     if (!c || c->g_level < 0) return fail(SDM_ERR_INVALID, "no Gram matrix to reduce");
     if (!c->allreduce) return SDM_OK;
     Timer t(c, SDM_T_ALLREDUCE);
-    // rows [0, Fp) hold every tile the solve reads (Gram upper tiles + RHS tile column)
-    const size_t count = (size_t)c->g_fp * c->g_ncols;
-    if (c->allreduce(c->G.p, count, (void*)c->stream, c->allreduce_user) != 0)
+    // only the tiles the solve reads travel: upper Gram tiles + RHS tile columns, packed back to back
+    HIP_TRY(hipSetDevice(c->device));
+    const int F = level_F(c, c->g_level);
+    const size_t count = sdm_packed_tiles_count(F, c->rhs_tiles);
+    int rc = c->gpack.ensure(count);
+    if (rc) return rc;
+    sdm_launch_tiles_pack(c->G.p, c->g_ncols, F, c->rhs_tiles, c->gpack.p, 0, c->stream);
+    HIP_TRY(hipGetLastError());
+    if (c->allreduce(c->gpack.p, count, (void*)c->stream, c->allreduce_user) != 0)
         return fail(SDM_ERR_COMM, "all-reduce callback reported failure");
+    sdm_launch_tiles_pack(c->G.p, c->g_ncols, F, c->rhs_tiles, c->gpack.p, 1, c->stream);
+    HIP_TRY(hipGetLastError());
     return SDM_OK;
 }
 

@@ -98,6 +98,9 @@ void sdm_launch_syrk_tn(const float* A, long long lda, int rows, int ncols, floa
 
 // Frobenius norm^2 (double) of the symmetric matrix whose upper triangle (incl. diagonal) of the
 // leading F x F block is stored in G; result accumulated into *out (must be zeroed).
+// upper Gram tiles + RHS tile columns <-> one contiguous exchange buffer of sdm_packed_tiles_count() floats
+size_t sdm_packed_tiles_count(int F, int rhs_tiles);
+void sdm_launch_tiles_pack(float* G, long long ldg, int F, int rhs_tiles, float* P, int unpack, hipStream_t stream);
 void sdm_launch_fro2_upper(const float* G, long long ldg, int F, double* out, hipStream_t stream);
 void sdm_launch_add_diag(float* G, long long ldg, int F, const double* fro2, int reg_type, float param,
                          int n_train, int regularise_last_row, float* lambda_out, hipStream_t stream);

@@ -459,6 +459,35 @@ void sdm_launch_syrk_tn(const float* A, long long lda, int rows, int ncols, floa
                        accumulate, tile_i0);
 }
 
+// ---- packed exchange buffer ----------------------------------------------------------------------------------------
+// Only the upper 128x128 tiles of the Gram matrix and the RHS tile columns carry data; the data-parallel exchange
+// sums exactly those: tile row ti keeps tiles tj >= ti and the TR right-hand-side tiles, stored back to back
+// (tile-major, each tile row-major).  Halves the bytes on the xGMI ring compared with the padded square.
+__global__ __launch_bounds__(256) void tiles_pack_kernel(float* G, long long ldg, int T, int TR, float* P, int unpack)
+{
+    const int tj = blockIdx.x, ti = blockIdx.y;
+    if (tj < T && tj < ti) return;
+    const long long tile = (long long)ti * (T + TR) - (long long)ti * (ti - 1) / 2 + (tj - ti);
+    float4* p = (float4*)(P + tile * TILE * TILE);
+    for (int e = threadIdx.x; e < TILE * TILE / 4; e += 256) {
+        const int r = e / (TILE / 4), c4 = e % (TILE / 4);
+        float4* g = (float4*)(G + (long long)(ti * TILE + r) * ldg + (long long)tj * TILE) + c4;
+        if (unpack) *g = p[e]; else p[e] = *g;
+    }
+}
+
+size_t sdm_packed_tiles_count(int F, int rhs_tiles)
+{
+    const size_t T = (size_t)(F + TILE - 1) / TILE;
+    return (T * (T + 1) / 2 + T * (size_t)rhs_tiles) * TILE * TILE;
+}
+
+void sdm_launch_tiles_pack(float* G, long long ldg, int F, int rhs_tiles, float* P, int unpack, hipStream_t stream)
+{
+    const int T = (F + TILE - 1) / TILE;
+    hipLaunchKernelGGL(tiles_pack_kernel, dim3(T + rhs_tiles, T), dim3(256), 0, stream, G, ldg, T, rhs_tiles, P, unpack);
+}
+
 void sdm_launch_fro2_upper(const float* G, long long ldg, int F, double* part_and_out, hipStream_t stream)
 {
     // part_and_out: [F + 1] doubles; result in part_and_out[F]
