@@ -26,13 +26,32 @@ with open(out+"/summary.txt","w") as fh:
     fh.write("%-28s %7s %13s %11s %7s\n" % ("kernel","calls","total_us","avg_us","%"))
     for r in list(csv.DictReader(open(out+"/kernel_stats.csv")))[:14]:
         fh.write("%-28s %7s %13.1f %11.2f %7.2f\n" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"])/1e3, float(r["AverageNs"])/1e3, float(r["Percentage"])))
+    # the same kernels per launch geometry (training rows / detect batch are different problem sizes)
+    geo=collections.defaultdict(list)
+    for f in glob.glob(out+"/trace/*kernel_trace.csv"):
+        for r in csv.DictReader(open(f)):
+            k=short(r["Kernel_Name"])
+            if k in ("hog_fast_kernel","apply_partial_kernel","apply_reduce_kernel","syrk_tn_kernel"):
+                geo[(k,"x".join(r.get(c,"?") for c in ("Grid_Size_X","Grid_Size_Y","Grid_Size_Z")))].append((float(r["End_Timestamp"])-float(r["Start_Timestamp"]))/1e3)
+    fh.write("\n== kernel trace by launch geometry (avg over dispatches; the detect steps of bench.py are the rows with the most calls) ==\n")
+    fh.write("%-28s %12s %7s %11s\n" % ("kernel","grid","calls","avg_us"))
+    for (k,g),v in sorted(geo.items(), key=lambda kv:(kv[0][0],-len(kv[1]))):
+        if len(v)>=4: fh.write("%-28s %12s %7d %11.2f\n" % (k,g,len(v),sum(v)/len(v)))
     rows=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter()
     for f in glob.glob(out+"/p*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             k=short(r["Kernel_Name"])
             if k not in ("hog_fast_kernel","apply_partial_kernel","syrk_tn_kernel"): continue
+            k="%s grid=%s" % (k, r.get("Grid_Size","?"))
             rows[k][r["Counter_Name"]]+=float(r["Counter_Value"]); cnt[(k,r["Counter_Name"])]+=1
-    fh.write("\n== PMC (separate passes), per-dispatch averages ==\n")
+    # one kernel is launched with several problem sizes (training rows, detect batch, parity sample): keep, per kernel,
+    # the launch geometry with the most dispatches = the timed detect steps (hog/apply) / the training Gram (syrk)
+    best={}
+    for k in rows:
+        base=k.split(" grid=")[0]; n=max(cnt[(k,c)] for c in rows[k])
+        if base not in best or n>best[base][0]: best[base]=(n,k)
+    rows={k:v for k,v in rows.items() if best[k.split(" grid=")[0]][1]==k}
+    fh.write("\n== PMC (separate passes), per-dispatch averages over the most frequent launch geometry of each kernel ==\n")
     for k,v in sorted(rows.items()):
         fh.write(k+"\n")
         for c,val in sorted(v.items()):
@@ -40,5 +59,12 @@ with open(out+"/summary.txt","w") as fh:
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             fs=v["FETCH_SIZE"]/cnt[(k,"FETCH_SIZE")]; ws=v["WRITE_SIZE"]/cnt[(k,"WRITE_SIZE")]
             fh.write("   -> HBM traffic per launch: FETCH_SIZE %.1f KB x2 (gfx950 half-count correction, MI355X_MICROARCH.md HBM) + WRITE_SIZE %.1f KB = %.1f MB\n" % (fs, ws, (2*fs+ws)/1024))
+import json
+hbm={}
+for k,v in rows.items():
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        hbm[k.split(" grid=")[0]]={"bytes_per_launch": (2*v["FETCH_SIZE"]/cnt[(k,"FETCH_SIZE")]+v["WRITE_SIZE"]/cnt[(k,"WRITE_SIZE")])*1024.0,
+                                   "launch_geometry": k.split(" grid=")[1], "dispatches": cnt[(k,"FETCH_SIZE")]}
+json.dump({"source": "scripts/profile_bench.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of python bench.py --steps 10 --warmup 2 --no-cpu; FETCH_SIZE x2 (gfx950), KB units", "kernels": hbm}, open(out+"/hbm_traffic.json","w"), indent=1)
 print(open(out+"/summary.txt").read())
 PY

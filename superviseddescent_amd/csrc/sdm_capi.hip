@@ -420,9 +420,17 @@ int sdm_upload_images_u8(sdm_ctx* c, const uint8_t* const* images, const int* w,
     if ((rc = c->img_owned.ensure((size_t)total))) return rc;
     if ((rc = c->img_off.ensure(n)) || (rc = c->img_w.ensure(n)) || (rc = c->img_h.ensure(n)) || (rc = c->img_stride.ensure(n)))
         return rc;
-    for (int i = 0; i < n; ++i)
-        HIP_TRY(hipMemcpy2DAsync(c->img_owned.p + off[i], w[i], images[i], stride[i], w[i], h[i],
-                                 hipMemcpyHostToDevice, c->stream));
+    // a dense, contiguous stack (one ndarray / one allocation) goes over in a single transfer
+    bool contiguous = true;
+    for (int i = 0; i < n && contiguous; ++i)
+        contiguous = stride[i] == w[i] && images[i] == images[0] + off[i];
+    if (contiguous) {
+        HIP_TRY(hipMemcpyAsync(c->img_owned.p, images[0], (size_t)total, hipMemcpyHostToDevice, c->stream));
+    } else {
+        for (int i = 0; i < n; ++i)
+            HIP_TRY(hipMemcpy2DAsync(c->img_owned.p + off[i], w[i], images[i], stride[i], w[i], h[i],
+                                     hipMemcpyHostToDevice, c->stream));
+    }
     std::vector<int> dense(w, w + n);
     HIP_TRY(hipMemcpyAsync(c->img_off.p, off.data(), n * sizeof(long long), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->img_w.p, w, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
