@@ -133,6 +133,19 @@ int sdm_apply(sdm_ctx* ctx, int level);
  * template, = rcr::detection_model::detect (model.hpp:132-157) for a batch.  x_host may be NULL. */
 int sdm_detect_batch(sdm_ctx* ctx, float* x_host);
 
+/* The step before the path: x_n = rcr::align_mean(mean, box_n) (include/rcr/model.hpp:64-76), or
+ * align_mean(mean, perturb(box_n, t_n)) (apps/rcr/rcr-train.cpp:130-146, 421-431) when `perturbations` is given,
+ * evaluated on the device straight into the state x (replaces sdm_set_x).  mean: 2L floats in the unit box;
+ * boxes: N x {x, y, width, height} ints (cv::Rect); perturbations: NULL or N x {translation_x, translation_y, scaling}
+ * (the caller draws them: the reference uses N(0, 0.04), N(0, 0.04), N(1, 0.04) from an unseeded std::mt19937).
+ * x_host may be NULL. */
+int sdm_init_from_boxes(sdm_ctx* ctx, const float* mean, const int* boxes, const float* perturbations, int n_samples,
+                        float* x_host);
+/* The evaluation after a level: calculate_normalised_landmark_errors (apps/rcr/rcr-train.cpp:200-212) of the
+ * current x against the targets of sdm_set_targets: errors[n][i] = ||x_i - x*_i||_2 / IED(x_n); *mean_out = cv::mean
+ * of that matrix (what rcr-train prints per cascade level, :457-459).  errors_host (N x L) may be NULL. */
+int sdm_normalised_errors(sdm_ctx* ctx, float* errors_host, double* mean_out);
+
 /* Training, one level (superviseddescent.hpp:170-218 with templates.empty()):
  *   sdm_hog_features -> sdm_gram_rhs -> [sdm_allreduce_gram_rhs] -> sdm_solve -> sdm_apply */
 int sdm_set_targets(sdm_ctx* ctx, const float* xstar_host, int n_samples);   /* `parameters`, :165 */

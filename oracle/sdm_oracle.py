@@ -416,6 +416,23 @@ def align_mean(mean: np.ndarray, box, scaling_x=1.0, scaling_y=1.0, translation_
     return out.astype(np.float32)
 
 
+def normalised_landmark_errors(predictions: np.ndarray, groundtruth: np.ndarray, right_eye: Sequence[int],
+                               left_eye: Sequence[int]) -> np.ndarray:
+    """calculate_normalised_landmark_errors, apps/rcr/rcr-train.cpp:200-212: row n, landmark i ->
+    (float)||pred_i - gt_i||_2 (f32 differences, double accumulate/sqrt: cv::norm, :155-158,173) times the f32 scalar
+    1.0f / get_ied(pred) (:208; Mat::mul with a scalar works in the matrix depth [ocv])."""
+    p = np.atleast_2d(np.asarray(predictions, np.float32))
+    g = np.atleast_2d(np.asarray(groundtruth, np.float32))
+    L = p.shape[1] // 2
+    out = np.empty((p.shape[0], L), np.float32)
+    for n in range(p.shape[0]):
+        d = (p[n] - g[n]).astype(np.float32).astype(np.float64)
+        e = np.sqrt(d[:L] * d[:L] + d[L:] * d[L:]).astype(np.float32)
+        inv = np.float32(1.0 / get_ied(p[n], right_eye, left_eye))
+        out[n] = e * inv
+    return out
+
+
 def perturb(box, tx: float, ty: float, s: float = 1.0):
     """apps/rcr/rcr-train.cpp:130-146 (float arithmetic, truncation into cv::Rect ints)."""
     x, y, w, h = box

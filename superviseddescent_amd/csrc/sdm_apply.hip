@@ -170,7 +170,90 @@ __global__ void targets_kernel(const float* __restrict__ x, const float* __restr
     feat[(long long)row * ldf + bcol0 + col] = (xr[col] - xstar[t]) * n;
 }
 
+// ---- the step before the path: initialisation from face boxes (apps/rcr/rcr-train.cpp:130-146, model.hpp:64-76) ----
+__global__ void init_boxes_kernel(const float* __restrict__ mean, const int* __restrict__ boxes,
+                                  const float* __restrict__ pert, int N, int L, float* __restrict__ x)
+{
+    const int M = 2 * L;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)N * M) return;
+    const int row = (int)(t / M), col = (int)(t - (long long)row * M);
+    int bx = boxes[4 * row], by = boxes[4 * row + 1], bw = boxes[4 * row + 2], bh = boxes[4 * row + 3];
+    if (pert) {
+        // rcr-train.cpp:133-143: float arithmetic, the cv::Rect constructor truncates towards zero
+        const float tx = pert[3 * row], ty = pert[3 * row + 1], sc = pert[3 * row + 2];
+        const float tx_pixel = tx * (float)bw, ty_pixel = ty * (float)bh;
+        const float pw = (float)bw * sc, ph = (float)bh * sc;
+        const float nx = (float)bx + ((float)bw - pw) / 2.0f + tx_pixel;
+        const float ny = (float)by + ((float)bh - ph) / 2.0f + ty_pixel;
+        bx = (int)nx; by = (int)ny; bw = (int)pw; bh = (int)ph;
+    }
+    // model.hpp:73-74 with unit scaling / zero translation: (m * 1 + 0.5 + 0) * extent + origin, f32
+    const float m = mean[col];
+    x[t] = col < L ? (m * 1.0f + 0.5f + 0.0f) * (float)bw + (float)bx
+                   : (m * 1.0f + 0.5f + 0.0f) * (float)bh + (float)by;
+}
+
+// ---- evaluation for the training callback: calculate_normalised_landmark_errors (rcr-train.cpp:200-212) -------
+__global__ void landmark_errors_kernel(const float* __restrict__ x, const float* __restrict__ xstar, int N, int L,
+                                       EyeIdxDev eyes, float* __restrict__ err)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)N * L) return;
+    const int row = (int)(t / L), i = (int)(t - (long long)row * L);
+    const float* xr = x + (long long)row * 2 * L;
+    const float* gr = xstar + (long long)row * 2 * L;
+    // cv::norm(Vec2f, Vec2f, NORM_L2): f32 differences, squares accumulated and rooted in double (:155-158)
+    const double dx = (double)(xr[i] - gr[i]), dy = (double)(xr[i + L] - gr[i + L]);
+    const float e = (float)sqrt(dx * dx + dy * dy);                     // result.at<float>(i) = norm(...), :173
+    const float inv = (float)(1.0f / device_ied_rows(xr, L, eyes));      // .mul(1.0f / get_ied(pred)), :208 (f32 scalar)
+    err[t] = e * inv;
+}
+
+// deterministic sum of n floats in double: fixed block/lane assignment, fixed tree
+__global__ __launch_bounds__(256) void sum_partial_kernel(const float* __restrict__ v, long long n, double* __restrict__ part)
+{
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += (double)v[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+
+__global__ void sum_final_kernel(const double* __restrict__ part, int nparts, long long n, double* __restrict__ out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < nparts; ++i) s += part[i];
+        out[0] = s;
+        out[1] = n > 0 ? s / (double)n : 0.0;   // cv::mean
+    }
+}
+
 }  // namespace
+
+void sdm_launch_init_boxes(const float* mean, const int* boxes, const float* pert, int N, int L, float* x, hipStream_t stream)
+{
+    const long long total = (long long)N * 2 * L;
+    if (total <= 0) return;
+    hipLaunchKernelGGL(init_boxes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, mean, boxes, pert, N, L, x);
+}
+
+void sdm_launch_landmark_errors(const float* x, const float* xstar, int N, int L, const EyeIdxDev& eyes, float* err,
+                                double* work, hipStream_t stream)
+{
+    const long long total = (long long)N * L;
+    if (total <= 0) return;
+    hipLaunchKernelGGL(landmark_errors_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, xstar, N, L, eyes, err);
+    // work: [SDM_SUM_PARTS + 2] doubles; work[SDM_SUM_PARTS] = sum, work[SDM_SUM_PARTS + 1] = mean
+    hipLaunchKernelGGL(sum_partial_kernel, dim3(SDM_SUM_PARTS), dim3(256), 0, stream, err, total, work);
+    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(64), 0, stream, work, SDM_SUM_PARTS, total, work + SDM_SUM_PARTS);
+}
 
 int sdm_apply_splits(int N, int F)
 {

@@ -495,6 +495,54 @@ static int set_x_common(sdm_ctx* c, const float* x, int N, hipMemcpyKind kind)
 int sdm_set_x(sdm_ctx* c, const float* x, int N) { return set_x_common(c, x, N, hipMemcpyHostToDevice); }
 int sdm_set_x_device(sdm_ctx* c, const float* x, int N) { return set_x_common(c, x, N, hipMemcpyDeviceToDevice); }
 
+int sdm_init_from_boxes(sdm_ctx* c, const float* mean, const int* boxes, const float* perturbations, int N, float* x_host)
+{
+    if (!c || !mean || !boxes || N <= 0) return fail(SDM_ERR_INVALID, "bad initialisation arguments");
+    if (c->L <= 0) return fail(SDM_ERR_INVALID, "geometry not set");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_sample_buffers(c, N);
+    if (rc) return rc;
+    DevBuf<float> d_mean, d_pert;
+    DevBuf<int> d_box;
+    if ((rc = d_mean.ensure(c->M)) || (rc = d_box.ensure((size_t)4 * N))) return rc;
+    if (perturbations && (rc = d_pert.ensure((size_t)3 * N))) return rc;
+    HIP_TRY(hipMemcpyAsync(d_mean.p, mean, c->M * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_box.p, boxes, (size_t)4 * N * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    if (perturbations)
+        HIP_TRY(hipMemcpyAsync(d_pert.p, perturbations, (size_t)3 * N * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (N != c->N) { c->have_targets = false; c->feat_level = -1; }
+    c->N = N; c->cur = 0;
+    sdm_launch_init_boxes(d_mean.p, d_box.p, perturbations ? d_pert.p : nullptr, N, c->L, c->x[0].p, c->stream);
+    HIP_TRY(hipGetLastError());
+    if (x_host)
+        HIP_TRY(hipMemcpyAsync(x_host, c->x[0].p, (size_t)N * c->M * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    d_mean.release(); d_box.release(); d_pert.release();
+    return SDM_OK;
+}
+
+int sdm_normalised_errors(sdm_ctx* c, float* errors_host, double* mean_out)
+{
+    if (!c || c->N <= 0) return fail(SDM_ERR_INVALID, "no x to evaluate");
+    if (!c->have_targets) return fail(SDM_ERR_INVALID, "sdm_normalised_errors: no targets set");
+    if (c->eyes.nre <= 0 || c->eyes.nle <= 0) return fail(SDM_ERR_INVALID, "sdm_normalised_errors: no eye landmarks");
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf<float> d_err;
+    DevBuf<double> d_work;
+    int rc;
+    if ((rc = d_err.ensure((size_t)c->N * c->L)) || (rc = d_work.ensure(SDM_SUM_PARTS + 2))) return rc;
+    sdm_launch_landmark_errors(c->x[c->cur].p, c->xstar.p, c->N, c->L, c->eyes, d_err.p, d_work.p, c->stream);
+    HIP_TRY(hipGetLastError());
+    double res[2] = {0.0, 0.0};
+    HIP_TRY(hipMemcpyAsync(res, d_work.p + SDM_SUM_PARTS, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (errors_host)
+        HIP_TRY(hipMemcpyAsync(errors_host, d_err.p, (size_t)c->N * c->L * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    d_err.release(); d_work.release();
+    if (mean_out) *mean_out = res[1];
+    return SDM_OK;
+}
+
 int sdm_get_x(sdm_ctx* c, float* x)
 {
     if (!c || !x || c->N <= 0) return fail(SDM_ERR_INVALID, "no x to get");

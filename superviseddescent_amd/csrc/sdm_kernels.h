@@ -85,6 +85,14 @@ void sdm_launch_apply(const float* feat, long long ldf, int N, int F, const floa
                       int M, const float* x_in, float* x_out, int L, const EyeIdxDev& eyes,
                       float* partial, int splits, hipStream_t stream);
 
+// ---- before / after the path ----------------------------------------------------
+// x[n] = align_mean(mean, perturb(box[n], pert[n]))   (model.hpp:64-76, rcr-train.cpp:130-146); pert may be null
+void sdm_launch_init_boxes(const float* mean, const int* boxes, const float* pert, int N, int L, float* x, hipStream_t stream);
+// err[n][i] = ||x_i - xstar_i|| / IED(x[n]) (rcr-train.cpp:200-212) and its sum / mean in work[SDM_SUM_PARTS..+1]
+#define SDM_SUM_PARTS 256
+void sdm_launch_landmark_errors(const float* x, const float* xstar, int N, int L, const EyeIdxDev& eyes, float* err,
+                                double* work, hipStream_t stream);
+
 // ---- training -----------------------------------------------------------------------------------
 // b = (x - xstar) * (float)(1/IED(x)) written into feat[:, bcol0 : bcol0+2L]
 void sdm_launch_targets(const float* x, const float* xstar, int N, int L, const EyeIdxDev& eyes,

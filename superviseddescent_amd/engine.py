@@ -136,6 +136,34 @@ class Context:
         check(self._lib.sdm_set_x(self._h, _fp(x), x.shape[0]))
         self.N = x.shape[0]
 
+    def init_from_boxes(self, mean: np.ndarray, boxes: np.ndarray, perturbations: Optional[np.ndarray] = None,
+                        fetch: bool = False) -> Optional[np.ndarray]:
+        """x_n = rcr::align_mean(mean, box_n) (model.hpp:64-76) -- or align_mean(mean, perturb(box_n, t_n))
+        (rcr-train.cpp:130-146) -- evaluated on the device into the state x.  boxes: N x (x, y, w, h) ints;
+        perturbations: N x (translation_x, translation_y, scaling)."""
+        m = np.ascontiguousarray(mean, np.float32).reshape(-1)
+        b = np.ascontiguousarray(boxes, np.int32)
+        if m.size != 2 * self.L or b.ndim != 2 or b.shape[1] != 4:
+            raise ValueError("mean must have 2L entries, boxes must be N x 4")
+        p = None
+        if perturbations is not None:
+            p = np.ascontiguousarray(perturbations, np.float32)
+            if p.shape != (b.shape[0], 3):
+                raise ValueError("perturbations must be N x 3")
+        out = np.empty((b.shape[0], 2 * self.L), np.float32) if fetch else None
+        check(self._lib.sdm_init_from_boxes(self._h, m.ctypes.data, b.ctypes.data, p.ctypes.data if p is not None else None,
+                                            b.shape[0], out.ctypes.data if fetch else None))
+        self.N = b.shape[0]
+        return out
+
+    def normalised_errors(self, fetch: bool = True):
+        """calculate_normalised_landmark_errors (rcr-train.cpp:200-212) of the current x against the targets:
+        returns (N x L matrix of ||x_i - x*_i|| / IED(x) or None, its mean)."""
+        out = np.empty((self.N, self.L), np.float32) if fetch else None
+        mean = ctypes.c_double(0.0)
+        check(self._lib.sdm_normalised_errors(self._h, out.ctypes.data if fetch else None, ctypes.byref(mean)))
+        return out, float(mean.value)
+
     def set_x_device(self, dev_ptr: int, n: int):
         check(self._lib.sdm_set_x_device(self._h, ctypes.c_void_p(dev_ptr), n))
         self.N = n

@@ -392,3 +392,37 @@ def test_rcr68_shapes(faces):
     ref = (x0 - u * (np.float32(1.0) / orc.InterEyeDistanceNormalisation(re, le)(x0))).astype(np.float32)
     assert rel_l2(ctx.get_x(), ref) < 1e-6
     ctx.close()
+
+
+# ------------------------------------------------------------------------------------------ f-2: before / after the path
+def test_init_from_boxes_bitwise(gpu_ctx):
+    """align_mean (model.hpp:64-76) and perturb + align_mean (rcr-train.cpp:130-146, 425-428) on the device:
+    f32 arithmetic and the cv::Rect truncation are bit-identical to the oracle."""
+    rng = np.random.default_rng(31)
+    N = 1000
+    mean = ibug.select_mean(IDS)
+    boxes = np.stack([rng.integers(-40, 200, N), rng.integers(-40, 200, N), rng.integers(1, 260, N), rng.integers(1, 260, N)],
+                     axis=1).astype(np.int32)
+    pert = np.stack([rng.normal(0, 0.04, N), rng.normal(0, 0.04, N), rng.normal(1, 0.04, N)], axis=1).astype(np.float32)
+    gpu_ctx.set_model_geometry(len(IDS), RE, LE, SHIPPED)
+    got = gpu_ctx.init_from_boxes(mean, boxes, fetch=True)
+    want = np.stack([orc.align_mean(mean, tuple(int(v) for v in b)) for b in boxes])
+    assert np.array_equal(bits(got), bits(want))
+    got = gpu_ctx.init_from_boxes(mean, boxes, pert, fetch=True)
+    want = np.stack([orc.align_mean(mean, orc.perturb(tuple(int(v) for v in b), *p)) for b, p in zip(boxes, pert)])
+    assert np.array_equal(bits(got), bits(want))
+    assert np.array_equal(bits(gpu_ctx.get_x()), bits(want))          # it IS the state x of the cascade
+
+
+def test_normalised_errors(gpu_ctx, faces):
+    """calculate_normalised_landmark_errors (rcr-train.cpp:200-212) as a device reduction."""
+    images, boxes, gt, x_star, x0 = faces
+    gpu_ctx.set_model_geometry(len(IDS), RE, LE, SHIPPED)
+    gpu_ctx.set_x(x0)
+    gpu_ctx.set_targets(x_star)
+    err, mean = gpu_ctx.normalised_errors()
+    want = orc.normalised_landmark_errors(x0, x_star, RE, LE)
+    assert np.array_equal(bits(err), bits(want))
+    assert abs(mean - float(want.astype(np.float64).mean())) <= 1e-12 * abs(mean)
+    _, mean2 = gpu_ctx.normalised_errors(fetch=False)
+    assert mean2 == mean                                               # deterministic reduction

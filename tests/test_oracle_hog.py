@@ -79,3 +79,15 @@ def test_empty_patch_is_an_error():
     p = orc.HoGParam(1, 5, 6, 4, 0.01)  # IED * 0.01 / 2 rounds to 0 -> cv::resize would throw
     with pytest.raises(ValueError):
         orc.hog_features_batch(GOLD["tr_images"], None, GOLD["tr_x"], [1], [3], p)
+
+
+def test_normalised_landmark_errors_restatement():
+    """rcr-train.cpp:200-212 on a case that can be done by hand: IED = 10, errors 3-4-5."""
+    from oracle import sdm_oracle as orc
+    pred = np.array([[0, 10, 0, 10, 0, 0, 3, 3]], np.float32)     # x: 0 10 0 10   y: 0 0 3 3
+    gt = pred.copy()
+    gt[0, 2] += 3                                                  # landmark 2: dx = -3
+    gt[0, 6] += 4                                                  #             dy = -4
+    err = orc.normalised_landmark_errors(pred, gt, [0], [1])
+    assert err.shape == (1, 4) and err.dtype == np.float32
+    np.testing.assert_array_equal(err[0], np.array([0, 0, 5, 0], np.float32) * np.float32(1.0 / 10.0))
