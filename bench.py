@@ -183,13 +183,18 @@ def main():
 
     # HBM bytes per launch from the PMC passes (rocprofv3 --pmc cannot run inside this process): the committed
     # measurement of this same command, valid for the launch geometry it was taken at
-    traffic, traffic_src = None, None
+    traffic, traffic_src, valu_issue = None, None, None
     try:
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")) as fh:
             tj = json.load(fh)
         ent = tj["kernels"]["hog_fast_kernel"]
         if int(ent["launch_geometry"]) == args.batch * L * 64:
             traffic, traffic_src = float(ent["bytes_per_launch"]), "profiles/hbm_traffic.json (" + tj["source"] + ")"
+            # the bound that actually limits this kernel: VALU issue, one wave instruction per 4 cycles per SIMD
+            peak_ginst = 256 * 4 * 2.4 / 4.0
+            ach = float(ent["SQ_INSTS_VALU"]) / (hog_avg_ms * 1e-3) / 1e9
+            valu_issue = {"insts_per_launch": float(ent["SQ_INSTS_VALU"]), "achieved": ach, "peak": peak_ginst,
+                          "unit": "G wave-instructions/s", "frac": ach / peak_ginst}
     except (OSError, KeyError, ValueError):
         pass
 
@@ -224,6 +229,7 @@ def main():
             "frac": achieved_gbs / HBM_PEAK_GBS,
             "traffic": traffic,
             "traffic_source": traffic_src,
+            "valu_issue": valu_issue,
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "note": "the kernel is VALU-issue bound (about 4.5 k VALU instructions per patch, SQ_ACTIVE_INST_VALU / "
                     "SQ_BUSY_CYCLES in profiles/), not HBM bound: HBM traffic is within 15 % of the algorithmic bytes",

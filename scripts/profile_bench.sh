@@ -65,6 +65,8 @@ for k,v in rows.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         hbm[k.split(" grid=")[0]]={"bytes_per_launch": (2*v["FETCH_SIZE"]/cnt[(k,"FETCH_SIZE")]+v["WRITE_SIZE"]/cnt[(k,"WRITE_SIZE")])*1024.0,
                                    "launch_geometry": k.split(" grid=")[1], "dispatches": cnt[(k,"FETCH_SIZE")]}
+        for c in ("SQ_INSTS_VALU","SQ_INSTS_SALU","SQ_INSTS_LDS","SQ_WAVES"):
+            if c in v: hbm[k.split(" grid=")[0]][c]=v[c]/cnt[(k,c)]
 json.dump({"source": "scripts/profile_bench.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of python bench.py --steps 10 --warmup 2 --no-cpu; FETCH_SIZE x2 (gfx950), KB units", "kernels": hbm}, open(out+"/hbm_traffic.json","w"), indent=1)
 print(open(out+"/summary.txt").read())
 PY
