@@ -42,6 +42,7 @@ namespace {
 
 typedef unsigned long long u64;
 typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ inline double ied_of(const float* __restrict__ xr, int L, const EyeIdxDev& e)
 {
@@ -94,6 +95,17 @@ __device__ inline float sqrt_int_exact(float x)
     return y;
 }
 
+// One-sided form: on gfx950 v_sqrt_f32 is never above the correctly rounded root for these inputs (it is exact or one
+// ulp low: scripts/ubench/sqrt_domain.hip), so only the upper neighbour is tested.  Like everything else here it is
+// used only after the exhaustive on-device comparison with sqrtf.
+__device__ inline float sqrt_int_up(float x)
+{
+    const float r = __builtin_amdgcn_sqrtf(x);
+    const float rp = __builtin_bit_cast(float, __builtin_bit_cast(int, r) + 1);
+    const float ep = __builtin_fmaf(-rp, r, x);
+    return (ep > 0.0f) ? rp : r;
+}
+
 // reference arithmetic, hog.c:637-672 (identical to sdm_hog.hip::gradient_bin)
 __device__ inline void bin_reference(float gx, float gy, float g, const HogLevelDev& lv, int& bin)
 {
@@ -130,7 +142,9 @@ __device__ inline void bin_unnormalised(float gx, float gy, const HogLevelDev& l
 template <int TO>
 __device__ inline void bin_sector(float gx, float gy, const HogLevelDev& lv, int O, int& bin)
 {
-    const bool flip = (gy < 0.0f) || (gy == 0.0f && gx < 0.0f);
+    // (gy == 0, gx < 0) needs no fold: m = 0 and the second-quadrant rule already yields O.  A zero gradient yields
+    // bin 0 here where the reference selects nothing: its magnitude is 0, so it contributes exact zeros either way.
+    const bool flip = gy < 0.0f;
     const float fx = flip ? -gx : gx;
     const float a = __builtin_fabsf(gx), b = __builtin_fabsf(gy);
     int m = 0;
@@ -141,8 +155,7 @@ __device__ inline void bin_sector(float gx, float gy, const HogLevelDev& lv, int
     }
     int d = (fx >= 0.0f) ? m : O - m;
     d += flip ? O : 0;
-    d = d >= 2 * O ? d - 2 * O : d;
-    bin = (a == 0.0f && b == 0.0f) ? -1 : d;
+    bin = d >= 2 * O ? d - 2 * O : d;
 }
 
 // per-wave LDS layout.  Region A lives for the whole patch, region B is first the rolling private
@@ -158,7 +171,11 @@ struct FastLds {
 };
 
 __host__ __device__ inline size_t al16(size_t v) { return (v + 15) & ~(size_t)15; }
-__host__ __device__ inline int copies_R(int cell) { return cell < 8 ? cell : 8; }
+// private accumulator copies per (band, bin, column): lane x uses copy x % 8, so no two lanes of one instruction that
+// fall into the same cell column share an address (8 is also the 64-byte stride that lets the two column
+// neighbours of a contribution sit in the immediate offset of the LDS instruction)
+#define HF_COPIES 8
+__host__ __device__ inline int copies_R(int) { return HF_COPIES; }
 
 __host__ __device__ inline size_t fast_lds_bytes(int cell, int C, int O, int D)
 {
@@ -230,7 +247,8 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
     FastLds w = fast_carve(lds_base, C, O, D);
     float* histf = (float*)w.hfin;     // exact order: padded f32 histogram
     u64* hfin = (u64*)w.hfin;          // fixed point: finished histogram [2O][CC]
-    const int R = copies_R(cell);      // private accumulator copies per (band, bin, column): lane x uses copy x % R
+    constexpr int R = HF_COPIES;
+    constexpr bool NOMASK = (TC == 5);   // 5 cells and S <= 64: cell <= 12 (checked again by the launcher)
 
     // ---- patch geometry (wave-uniform, moved to scalar registers; adaptive_vlhog.hpp:123,132-133) ------
     const double ied = ied_of(xr, L, eyes);
@@ -316,10 +334,7 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
             u64* cp = w.copies + (size_t)(slot * 2 * O * PW + t) * R;
             u64 sum = 0;
             // all 16-byte reads in flight, then the clears (integer sum: any order)
-            if (R == 8) sum = fold_copies<4>((u64x2*)cp);
-            else if (R == 6) sum = fold_copies<3>((u64x2*)cp);
-            else if (R == 4) sum = fold_copies<2>((u64x2*)cp);
-            else for (int r = 0; r < R; ++r) { sum += cp[r]; cp[r] = 0ull; }
+            sum = fold_copies<HF_COPIES / 2>((u64x2*)cp) & 0xfffffffffffffull;   // (see fx: bits >= 52 are not data)
             const int kbin = t / PW, hc = t - kbin * PW;
             if (band >= 0 && band < C && hc >= 1 && hc <= C) hfin[kbin * CC + band * C + (hc - 1)] = sum;
         }
@@ -377,7 +392,7 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
             const float gx = from_right(rm1) - from_left(rm1);
             const float gy = r0 - rm2;
             const float g2 = gx * gx + gy * gy;
-            float g = FASTBIN ? sqrt_int_exact(g2) : sqrtf(g2);
+            float g = FASTBIN == 2 ? sqrt_int_up(g2) : (FASTBIN == 1 ? sqrt_int_exact(g2) : sqrtf(g2));
             int bin;
             if (FASTBIN == 2) {
                 bin_sector<TO>(gx, gy, lv, O, bin);
@@ -406,32 +421,41 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
                     if (sc > best) { best = sc; bin = bsel; }
                 }
             }
-            if (!col_active || bin < 0) { g = 0.0f; bin = 0; }
+            // lanes outside the ROI carry wx1 = wx2 = 0 and the sector form always yields a valid bin: nothing to mask
+            if (FASTBIN != 2 && (!col_active || bin < 0)) { g = 0.0f; bin = 0; }
             const int by = __builtin_amdgcn_readlane(row_cell, yy);
             const float wy1 = lane_f(row_w1, yy), wy2 = lane_f(row_w2, yy);
-            const float t1 = g * wx1, t2 = g * wx2;             // (grad * wx) * wy, hog.c:714-723
-            const float va = t2 * wy1, vb = t1 * wy1, vc = t2 * wy2, vd = t1 * wy2;
+            // (grad * wx) * wy, hog.c:714-723: six f32 products as three packed multiplies
+            const f32x2 t = (f32x2){wx2, wx1} * g;
+            const f32x2 ab = t * wy1, cd = t * wy2;
+            const float va = ab.x, vb = ab.y, vc = cd.x, vd = cd.y;
             if (ACC == ACC_FIXED64) {
                 if (by != cur_by) {          // wave-uniform: the rows entered the next cell-row band
                     if (cur_by != -2) flush_band(cur_by);
                     cur_by = by;
                 }
                 // exact f32 -> 2^-36 fixed point: fma(v, 2^36, 2^52) leaves the integer in the low 52 mantissa bits
+                // The high dword keeps the exponent bits of 2^52 when a histogram entry cannot reach 2^52 anyway (NOMASK):
+                // a cell collects at most cell^2 * 255*sqrt(2) * 2^36 < 2^52 for cell <= 13, so the low 52 bits of the
+                // wrapped u64 sums are the exact sums and one mask in the fold replaces four per pixel.
                 auto fx = [&](float v) -> u64 {
                     double yv;
                     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(yv) : "v"((double)v), "s"(68719476736.0), "v"(two52));
+                    if (NOMASK) return (u64)__builtin_bit_cast(long long, yv);
                     const unsigned hi = (unsigned)__double2hiint(yv) & 0xfffffu, lo = (unsigned)__double2loint(yv);
                     return ((u64)hi << 32) | lo;
                 };
-                // private copy index ((slot*2O + bin)*PW + hcol)*R + (x % R), split into a per-lane constant, a scalar
-                // band-slot offset and one 24-bit multiply-add on the bin (no 64-bit or full 32-bit multiplies per row)
-                const int slot_stride = 2 * O * PW * R;
-                const int i0 = (int)(__umul24((unsigned)bin, (unsigned)(PW * R)) + (unsigned)(lane_off + (by & 1) * slot_stride));
-                const int i1 = (int)(__umul24((unsigned)bin, (unsigned)(PW * R)) + (unsigned)(lane_off + ((by + 1) & 1) * slot_stride));
-                atomicAdd(w.copies + i0 + R, fx(va));     // band by,   column bx+1
-                atomicAdd(w.copies + i0, fx(vb));         // band by,   column bx
-                atomicAdd(w.copies + i1 + R, fx(vc));     // band by+1, column bx+1
-                atomicAdd(w.copies + i1, fx(vd));         // band by+1, column bx
+                // private copy ((slot*2O + bin)*PW + hcol)*R + (x % R): one 24-bit multiply-add on the bin + a per-lane
+                // constant, a scalar band-slot offset each for by / by+1, the column neighbour in the immediate offset
+                const unsigned base = __umul24((unsigned)bin, (unsigned)(PW * R * 8)) + (unsigned)lane_off * 8u;
+                const unsigned slot_bytes = (unsigned)(2 * O * PW * R * 8);
+                unsigned char* cb = (unsigned char*)w.copies;
+                u64* p0 = (u64*)(cb + (base + (unsigned)(by & 1) * slot_bytes));
+                u64* p1 = (u64*)(cb + (base + (unsigned)((by + 1) & 1) * slot_bytes));
+                atomicAdd(p0 + R, fx(va));     // band by,   column bx+1
+                atomicAdd(p0, fx(vb));         // band by,   column bx
+                atomicAdd(p1 + R, fx(vc));     // band by+1, column bx+1
+                atomicAdd(p1, fx(vd));         // band by+1, column bx
             } else {
                 const int base = bin * PWW + (by + 1) * PW + hcol;
                 // reference order per accumulator: (bx+1,by) (bx,by) (bx+1,by+1) (bx,by+1), lanes ascending
@@ -570,9 +594,14 @@ __global__ void verify_fast_bins_kernel(HogLevelDev lv, int* __restrict__ mismat
     bin_unnormalised(gx, gy, lv, b);
     bin_sector<0>(gx, gy, lv, lv.O, c);
     const float g2 = gx * gx + gy * gy;
-    const bool sqrt_ok = __builtin_bit_cast(int, sqrt_int_exact(g2)) == __builtin_bit_cast(int, sqrtf(g2));
-    if (a != b || !sqrt_ok) atomicAdd(mismatches, 1);
-    if (a != c || !sqrt_ok) atomicAdd(mismatches + 1, 1);
+    const int want = __builtin_bit_cast(int, sqrtf(g2));
+    const bool sqrt2_ok = __builtin_bit_cast(int, sqrt_int_exact(g2)) == want;
+    const bool sqrt1_ok = __builtin_bit_cast(int, sqrt_int_up(g2)) == want;
+    // mode 1: un-normalised arg-max + two-sided sqrt;  mode 2: sector count + one-sided sqrt, where a pixel the
+    // reference skips (a == -1) may carry any valid bin as long as its magnitude is exactly 0
+    const bool sector_ok = (a == c) || (a == -1 && g == 0.0f && c >= 0 && c < 2 * lv.O);
+    if (a != b || !sqrt2_ok) atomicAdd(mismatches, 1);
+    if (!sector_ok || !sqrt1_ok) atomicAdd(mismatches + 1, 1);
 }
 
 }  // namespace
@@ -633,9 +662,10 @@ void sdm_launch_hog_fast(const ImageSetDev& imgs, const int* img_idx, const floa
 {
     if ((long long)N * L <= 0) return;
     // specialised instances for the shipped (4 orientations) and the "31-bin" (9 orientations) 5x5-cell geometry
-    if (lv.O == 4 && lv.C == 5)
+    const bool small_cell = lv.cell <= 13;   // the specialised instances rely on cell^2 * 361 < 2^16 (see fx)
+    if (lv.O == 4 && lv.C == 5 && small_cell)
         launch_fast_oc<4, 5>(imgs, img_idx, x, N, L, eyes, lv, feat, ldf, idx_out, status, exact_order, fast_bins, stream);
-    else if (lv.O == 9 && lv.C == 5)
+    else if (lv.O == 9 && lv.C == 5 && small_cell)
         launch_fast_oc<9, 5>(imgs, img_idx, x, N, L, eyes, lv, feat, ldf, idx_out, status, exact_order, fast_bins, stream);
     else
         launch_fast_oc<0, 0>(imgs, img_idx, x, N, L, eyes, lv, feat, ldf, idx_out, status, exact_order, fast_bins, stream);
