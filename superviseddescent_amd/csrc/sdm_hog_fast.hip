@@ -175,6 +175,7 @@ __host__ __device__ inline size_t al16(size_t v) { return (v + 15) & ~(size_t)15
 // fall into the same cell column share an address (8 is also the 64-byte stride that lets the two column
 // neighbours of a contribution sit in the immediate offset of the LDS instruction)
 #define HF_COPIES 8
+#define HF_TWO52_BITS 0x4330000000000000ull
 __host__ __device__ inline int copies_R(int) { return HF_COPIES; }
 
 __host__ __device__ inline size_t fast_lds_bytes(int cell, int C, int O, int D)
@@ -219,6 +220,16 @@ __device__ inline u64 fold_copies(u64x2* c2)
 #pragma unroll
     for (int i = 0; i < N2; ++i) sum += q[i].x + q[i].y;
     return sum;
+}
+
+// Every LDS region belongs to one wave, and the LDS unit executes one wave's instructions in issue order, so the
+// phases of a patch only need the compiler to keep that order: a wavefront-scope fence, no workgroup barrier (the
+// four waves of a workgroup never wait for each other).
+__device__ inline void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 __device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -318,11 +329,12 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
         // (16-byte stores: both counts are even and both regions 16-byte aligned)
         const u64x2 z2 = {0ull, 0ull};
         for (int i = lane; i < 2 * O * PW * R; i += 64) ((u64x2*)w.copies)[i] = z2;
-        for (int i = lane; i < O * CC; i += 64) ((u64x2*)hfin)[i] = z2;
+        const u64x2 b2 = {HF_TWO52_BITS, HF_TWO52_BITS};   // = 0.0 in the biased form the fold stores (see flush_band)
+        for (int i = lane; i < O * CC; i += 64) ((u64x2*)hfin)[i] = b2;
     } else {
         for (int i = lane; i < 2 * O * PWW; i += 64) histf[i] = 0.0f;
     }
-    __syncthreads();
+    wave_sync();
     mark(1);   // histogram clear + barrier
     // fixed point: the two cell-row bands (by, by+1) a pixel row feeds are accumulated in private copies (no two
     // lanes of one instruction share an address); a band is folded into hfin when the rows have moved past it
@@ -336,7 +348,9 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
             // all 16-byte reads in flight, then the clears (integer sum: any order)
             sum = fold_copies<HF_COPIES / 2>((u64x2*)cp) & 0xfffffffffffffull;   // (see fx: bits >= 52 are not data)
             const int kbin = t / PW, hc = t - kbin * PW;
-            if (band >= 0 && band < C && hc >= 1 && hc <= C) hfin[kbin * CC + band * C + (hc - 1)] = sum;
+            // stored as the bit pattern of the double 2^52 + sum (sum < 2^52), which makes the final u64 -> f32 conversion
+            // one f64 subtraction and one (single) rounding
+            if (band >= 0 && band < C && hc >= 1 && hc <= C) hfin[kbin * CC + band * C + (hc - 1)] = sum | HF_TWO52_BITS;
         }
     };
 
@@ -469,7 +483,7 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
     }
     if (ACC == ACC_FIXED64 && cur_by != -2) { flush_band(cur_by); flush_band(cur_by + 1); }
     mark(2);   // row loop
-    __syncthreads();
+    wave_sync();
     mark(3);   // barrier after the row loop
 
     // ---- histogram -> f32 [2O][CC] (one conversion per accumulator; region B, dead since the last flush,
@@ -478,10 +492,11 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
         const int k = t / CC, c = t - k * CC;
         const int cyy = c / C, cxx = c - cyy * C;
         // fixed point: exact sum, ONE rounding (u64 -> f32), then the exact scale 2^-36
-        w.histv[t] = (ACC == ACC_FIXED64) ? (float)hfin[t] * 1.4551915228366852e-11f
-                                           : histf[k * PWW + (cyy + 1) * PW + (cxx + 1)];
+        w.histv[t] = (ACC == ACC_FIXED64)
+                         ? (float)(__builtin_bit_cast(double, hfin[t]) - 4503599627370496.0) * 1.4551915228366852e-11f
+                         : histf[k * PWW + (cyy + 1) * PW + (cxx + 1)];
     }
-    __syncthreads();
+    wave_sync();
 
     // ---- cell norms (hog.c:875-890) ---------------------------------------------------------------------------
     for (int c = lane; c < CC; c += 64) {
@@ -492,66 +507,67 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
         }
         w.nrm[c] = n;
     }
-    __syncthreads();
-    // ---- the four block factors of every cell (hog.c:930-981), one lane per (cell, block) ---------------------
-    for (int t = lane; t < 4 * CC; t += 64) {
-        const int j = t / CC, c = t - j * CC;
-        const int y = c / C, x = c - y * C;
-        const int xm = x - 1 > 0 ? x - 1 : 0, xp = x + 1 < C - 1 ? x + 1 : C - 1;
-        const int ym = y - 1 > 0 ? y - 1 : 0, yp = y + 1 < C - 1 ? y + 1 : C - 1;
-        // j=0: n1+n2+n4+n5  j=1: n2+n3+n5+n6  j=2: n4+n5+n7+n8  j=3: n5+n6+n8+n9   (left-to-right, + 1e-4 last)
-        const int xa = (j & 1) ? x : xm, xb = (j & 1) ? xp : x;
-        const int ya = (j & 2) ? y : ym, yb = (j & 2) ? yp : y;
+    wave_sync();
+    // ---- block factors (hog.c:930-981).  The four factors of a cell are those of the 2x2-cell blocks around its four
+    //      corners, clamped at the border; a block is shared by up to four cells, so the (C+1)^2 distinct ones are
+    //      computed once: block (bx, by) sums cells (xa,ya) (xb,ya) (xa,yb) (xb,yb), left to right, + 1e-4 last, with
+    //      xa = max(bx-1, 0), xb = min(bx, C-1) -- the same operands in the same order as the reference's n1..n9 ----
+    const int CB = C + 1;
+    for (int t = lane; t < CB * CB; t += 64) {
+        const int byb = t / CB, bxb = t - byb * CB;
+        const int xa = bxb - 1 > 0 ? bxb - 1 : 0, xb = bxb < C - 1 ? bxb : C - 1;
+        const int ya = byb - 1 > 0 ? byb - 1 : 0, yb = byb < C - 1 ? byb : C - 1;
         const double na = w.nrm[xa + ya * C], nb = w.nrm[xb + ya * C];
         const double nc = w.nrm[xa + yb * C], nd = w.nrm[xb + yb * C];
-        w.fac[j * CC + c] = 1.0 / sqrt(na + nb + nc + nd + 1e-4);
+        w.fac[t] = 1.0 / sqrt(na + nb + nc + nd + 1e-4);
     }
-    __syncthreads();
+    wave_sync();
     // ---- normalise, clamp, emit the 3 (UoCTTI) or 4 (Dalal-Triggs) outputs of every (cell, orientation) ------
+    //      desc is written in the Matlab order of the feature row (adaptive_vlhog.hpp:166-175): [dim][x][y]
     for (int t = lane; t < O * CC; t += 64) {
         const int k = t / CC, c = t - k * CC;
+        const int y = c / C, x = c - y * C, ct = x * C + y;
         const double ha = w.histv[c + k * CC], hb = w.histv[c + (k + O) * CC];
-        const double f1 = w.fac[c], f2 = w.fac[CC + c], f3 = w.fac[2 * CC + c], f4 = w.fac[3 * CC + c];
+        // j=0: n1+n2+n4+n5  j=1: n2+n3+n5+n6  j=2: n4+n5+n7+n8  j=3: n5+n6+n8+n9
+        const double f1 = w.fac[x + y * CB], f2 = w.fac[x + 1 + y * CB];
+        const double f3 = w.fac[x + (y + 1) * CB], f4 = w.fac[x + 1 + (y + 1) * CB];
         double ha1 = f1 * ha, ha2 = f2 * ha, ha3 = f3 * ha, ha4 = f4 * ha;
         double hb1 = f1 * hb, hb2 = f2 * hb, hb3 = f3 * hb, hb4 = f4 * hb;
         double hc1 = ha1 + hb1, hc2 = ha2 + hb2, hc3 = ha3 + hb3, hc4 = ha4 + hb4;
-#define CL02(v) ((0.2 < (v)) ? 0.2 : (v))
+#define CL02(v) __builtin_fmin(0.2, (v))          /* VL_MIN(0.2, v): the values are finite and non-negative */
         ha1 = CL02(ha1); ha2 = CL02(ha2); ha3 = CL02(ha3); ha4 = CL02(ha4);
         hb1 = CL02(hb1); hb2 = CL02(hb2); hb3 = CL02(hb3); hb4 = CL02(hb4);
         hc1 = CL02(hc1); hc2 = CL02(hc2); hc3 = CL02(hc3); hc4 = CL02(hc4);
 #undef CL02
         if (lv.variant == 1) {
-            w.desc[c + k * CC] = (float)(0.5 * (ha1 + ha2 + ha3 + ha4));
-            w.desc[c + (k + O) * CC] = (float)(0.5 * (hb1 + hb2 + hb3 + hb4));
-            w.desc[c + (k + 2 * O) * CC] = (float)(0.5 * (hc1 + hc2 + hc3 + hc4));
+            w.desc[ct + k * CC] = (float)(0.5 * (ha1 + ha2 + ha3 + ha4));
+            w.desc[ct + (k + O) * CC] = (float)(0.5 * (hb1 + hb2 + hb3 + hb4));
+            w.desc[ct + (k + 2 * O) * CC] = (float)(0.5 * (hc1 + hc2 + hc3 + hc4));
             double* q = w.hcc + (size_t)(k * CC + c) * 4;
             q[0] = hc1; q[1] = hc2; q[2] = hc3; q[3] = hc4;
         } else {
-            w.desc[c + k * CC] = (float)hc1;
-            w.desc[c + (k + O) * CC] = (float)hc2;
-            w.desc[c + (k + 2 * O) * CC] = (float)hc3;
-            w.desc[c + (k + 3 * O) * CC] = (float)hc4;
+            w.desc[ct + k * CC] = (float)hc1;
+            w.desc[ct + (k + O) * CC] = (float)hc2;
+            w.desc[ct + (k + 2 * O) * CC] = (float)hc3;
+            w.desc[ct + (k + 3 * O) * CC] = (float)hc4;
         }
     }
-    __syncthreads();
+    wave_sync();
     // ---- texture features: t_j = sum over k (in order) of the clamped hc_j (hog.c:1020-1023, 1047-1052) ------
     if (lv.variant == 1) {
         const float tex = 1.0f / sqrtf(18.0f);
         for (int t = lane; t < 4 * CC; t += 64) {
             const int j = t / CC, c = t - j * CC;
+            const int y = c / C, x = c - y * C, ct = x * C + y;
             double acc = 0.0;
             for (int k = 0; k < O; ++k) acc += w.hcc[(size_t)(k * CC + c) * 4 + j];
-            w.desc[c + (3 * O + j) * CC] = (float)(tex * acc);
+            w.desc[ct + (3 * O + j) * CC] = (float)(tex * acc);
         }
-        __syncthreads();
+        wave_sync();
     }
     mark(4);   // normalisation / extraction
-    // ---- Matlab-order flatten (adaptive_vlhog.hpp:166-175): out[j*CC + xx*C + yy] = desc[j][yy][xx] ----------
-    for (int o = lane; o < lv.P; o += 64) {
-        const int j = o / CC, r = o - j * CC;
-        const int xx = r / C, yy = r - xx * C;
-        out_desc[o] = w.desc[j * CC + yy * C + xx];
-    }
+    // ---- the feature row segment of this landmark: desc is already in its order -------------------------------
+    for (int o = lane; o < lv.P; o += 64) out_desc[o] = w.desc[o];
     mark(5);   // output stores
 }
 
@@ -570,7 +586,7 @@ hog_fast_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float* 
     const unsigned blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
     long long p = (long long)blk * HF_WAVES + wave;
     const long long total = (long long)N * L;
-    if (p >= total) p = total - 1;   // tail waves redo the last patch (identical values) to keep barriers uniform
+    if (p >= total) return;          // (no workgroup barriers anywhere: tail waves simply leave)
     const int s = (int)(p / L), i = (int)(p - (long long)s * L);
     const int im = img_idx ? img_idx[s] : s;
     const float* xr = x + (long long)s * 2 * L;
@@ -652,7 +668,7 @@ void sdm_launch_hog_fast_profile(const ImageSetDev& imgs, const int* img_idx, co
     if (total <= 0 || !(lv.O == 4 && lv.C == 5)) return;
     const size_t per = fast_lds_bytes(lv.cell, lv.C, lv.O, lv.D);
     const unsigned grid = (unsigned)((total + HF_WAVES - 1) / HF_WAVES);
-    hipLaunchKernelGGL((hog_fast_kernel<ACC_FIXED64, 1, 4, 5, true>), dim3(grid), dim3(HF_WAVES * 64), per * HF_WAVES,
+    hipLaunchKernelGGL((hog_fast_kernel<ACC_FIXED64, 2, 4, 5, true>), dim3(grid), dim3(HF_WAVES * 64), per * HF_WAVES,
                        stream, imgs, img_idx, x, N, L, eyes, lv, feat, ldf, (int*)nullptr, status, per, prof_dev);
 }
 
