@@ -26,6 +26,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define TILE 128
 #define SYRK_BK 16
+#define SYRK_CHUNK 16     // slabs per inner accumulation chunk (256 rows)
 
 // C[ti][tj] (+)= alpha * sum_n A[n][ti*128 + i] * A[n][tj*128 + j]
 // 256 threads = 4 waves in a 2x2 arrangement, each wave a 64x64 sub-tile = 2x2 MFMA 32x32 tiles.
@@ -43,13 +44,17 @@ syrk_tn_kernel(const float* __restrict__ A, long long lda, int rows, float* __re
     const float* Ai = A + (long long)ti * TILE;
     const float* Aj = A + (long long)tj * TILE;
 
-    f32x16 acc[2][2];
+    // Two-level summation over the rows: the MFMA accumulators run over SYRK_CHUNK slabs (256 rows) and are then
+    // folded into `tot`.  One f32 accumulator chain over all N rows loses ~1e-4 of the entry at N = 40 000 (small terms
+    // added to a large running sum), enough to make the regularised Gram matrix indefinite in its unregularised bias
+    // direction; chunked, the error stays near 1e-6 at N = 100 000 (as a blocked CPU GEMM's does).
+    f32x16 acc[2][2], tot[2][2];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.0f;
+            for (int e = 0; e < 16; ++e) { acc[m][n][e] = 0.0f; tot[m][n][e] = 0.0f; }
 
     // staging: thread t loads rows (t/32) and (t/32 + 8) of the 16-row slab, 4 floats at column 4*(t%32)
     const int lrow = t >> 5, lcol = (t & 31) * 4;
@@ -77,26 +82,36 @@ syrk_tn_kernel(const float* __restrict__ A, long long lda, int rows, float* __re
 
     const int nslabs = (rows + SYRK_BK - 1) / SYRK_BK;
     load_slab(0);
-    for (int s = 0; s < nslabs; ++s) {
-        __syncthreads();          // previous slab fully consumed
-        store_slab();
-        __syncthreads();
-        if (s + 1 < nslabs) load_slab((s + 1) * SYRK_BK);   // prefetch under the MFMAs
-        const float (*Bp)[TILE] = diag ? As : Bs;
+    for (int s0 = 0; s0 < nslabs; s0 += SYRK_CHUNK) {
+        const int s1 = s0 + SYRK_CHUNK < nslabs ? s0 + SYRK_CHUNK : nslabs;
+        for (int s = s0; s < s1; ++s) {
+            __syncthreads();          // previous slab fully consumed
+            store_slab();
+            __syncthreads();
+            if (s + 1 < nslabs) load_slab((s + 1) * SYRK_BK);   // prefetch under the MFMAs
+            const float (*Bp)[TILE] = diag ? As : Bs;
 #pragma unroll
-        for (int kk = 0; kk < SYRK_BK; kk += 2) {
-            const int k = kk + (lane >> 5);
-            float a[2], b[2];
+            for (int kk = 0; kk < SYRK_BK; kk += 2) {
+                const int k = kk + (lane >> 5);
+                float a[2], b[2];
 #pragma unroll
-            for (int m = 0; m < 2; ++m) a[m] = As[k][wr * 64 + m * 32 + (lane & 31)];
+                for (int m = 0; m < 2; ++m) a[m] = As[k][wr * 64 + m * 32 + (lane & 31)];
 #pragma unroll
-            for (int n = 0; n < 2; ++n) b[n] = Bp[k][wc * 64 + n * 32 + (lane & 31)];
+                for (int n = 0; n < 2; ++n) b[n] = Bp[k][wc * 64 + n * 32 + (lane & 31)];
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
+                    for (int n = 0; n < 2; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
+            }
         }
+        // fold the chunk
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { tot[m][n][e] += acc[m][n][e]; acc[m][n][e] = 0.0f; }
     }
 
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
@@ -110,7 +125,7 @@ syrk_tn_kernel(const float* __restrict__ A, long long lda, int rows, float* __re
                 const long long gi = (long long)ti * TILE + wr * 64 + m * 32 + r;
                 const long long gj = (long long)tj * TILE + wc * 64 + n * 32 + (lane & 31);
                 float* p = C + gi * ldc + gj;
-                float v = alpha * acc[m][n][e];
+                float v = alpha * tot[m][n][e];
                 if (accumulate) v += *p;
                 *p = v;
             }

@@ -41,39 +41,66 @@ def perturb(box, tx: float, ty: float, s: float = 1.0):
     return (int(nx), int(ny), int(pw), int(ph))
 
 
-def make_faces(n_images: int, seed: int = SEED, size: int = IMAGE_SIZE, chunk: int = 256):
-    """Returns (images uint8 [n,size,size], boxes int32 [n,4] (x,y,w,h), gt68 float32 [n,136])."""
-    rng = np.random.default_rng(seed)
+def _face_chunk(rng, n: int, size: int):
+    """One chunk of make_faces: (images [n,size,size] u8, boxes [n,4], gt68 [n,136]) drawn from ``rng``."""
+    coords = np.arange(size, dtype=np.float32)
+    wh = rng.integers(160, 209, size=n)
+    bx = (rng.random(n) * (size - wh)).astype(np.int32)
+    by = (rng.random(n) * (size - wh)).astype(np.int32)
+    boxes = np.stack([bx, by, wh, wh], 1).astype(np.int32)
+    # smooth background: 6 Gaussians (sigma 12..40 px), amplitude +-48
+    gcx = rng.random((n, 6)).astype(np.float32) * size
+    gcy = rng.random((n, 6)).astype(np.float32) * size
+    gsig = (12 + 28 * rng.random((n, 6))).astype(np.float32)
+    gamp = (48 * (2 * rng.random((n, 6)) - 1)).astype(np.float32)
+    ex = np.exp(-0.5 * ((coords[None, None, :] - gcx[:, :, None]) / gsig[:, :, None]) ** 2)
+    ey = np.exp(-0.5 * ((coords[None, None, :] - gcy[:, :, None]) / gsig[:, :, None]) ** 2)
+    field = np.matmul((ey * gamp[:, :, None]).transpose(0, 2, 1), ex)          # [n, y, x]
+    # landmark blobs at the ground-truth shape (rigid mean + 1.5 px jitter)
+    gt68 = np.empty((n, 136), np.float32)
+    for i in range(n):
+        gt68[i] = align_mean(ibug.MEAN_IBUG_LFPW_68, boxes[i])
+    gt68 += (1.5 * rng.standard_normal((n, 136))).astype(np.float32)
+    lx, ly = gt68[:, :68], gt68[:, 68:]
+    lamp = np.where(np.arange(68) % 2 == 0, 70.0, -70.0).astype(np.float32)
+    bxk = np.exp(-0.5 * ((coords[None, None, :] - lx[:, :, None]) / 3.0) ** 2).astype(np.float32)
+    byk = np.exp(-0.5 * ((coords[None, None, :] - ly[:, :, None]) / 3.0) ** 2).astype(np.float32)
+    field += np.matmul((byk * lamp[None, :, None]).transpose(0, 2, 1), bxk)
+    noise = (24 * (2 * rng.random((n, size, size), dtype=np.float32) - 1))
+    return np.clip(128 + field + noise, 0, 255).astype(np.uint8), boxes, gt68
+
+
+def make_faces(n_images: int, seed: int = SEED, size: int = IMAGE_SIZE, chunk: int = 256, workers: int = 0):
+    """Returns (images uint8 [n,size,size], boxes int32 [n,4] (x,y,w,h), gt68 float32 [n,136]).
+
+    ``workers <= 1``: one random stream, chunk after chunk (the stream every fixture and test of this repo uses).
+    ``workers > 1``: the chunks are drawn from independent streams ``default_rng([seed, chunk_index])`` in a pool of
+    forked worker processes -- a different (equally deterministic) data set, meant for the large training sets of bench.py."""
     images = np.empty((n_images, size, size), np.uint8)
     boxes = np.empty((n_images, 4), np.int32)
     gt68 = np.empty((n_images, 136), np.float32)
-    coords = np.arange(size, dtype=np.float32)
-    for c0 in range(0, n_images, chunk):
-        n = min(chunk, n_images - c0)
-        wh = rng.integers(160, 209, size=n)
-        bx = (rng.random(n) * (size - wh)).astype(np.int32)
-        by = (rng.random(n) * (size - wh)).astype(np.int32)
-        boxes[c0:c0 + n] = np.stack([bx, by, wh, wh], 1)
-        # smooth background: 6 Gaussians (sigma 12..40 px), amplitude +-48
-        gcx = rng.random((n, 6)).astype(np.float32) * size
-        gcy = rng.random((n, 6)).astype(np.float32) * size
-        gsig = (12 + 28 * rng.random((n, 6))).astype(np.float32)
-        gamp = (48 * (2 * rng.random((n, 6)) - 1)).astype(np.float32)
-        ex = np.exp(-0.5 * ((coords[None, None, :] - gcx[:, :, None]) / gsig[:, :, None]) ** 2)
-        ey = np.exp(-0.5 * ((coords[None, None, :] - gcy[:, :, None]) / gsig[:, :, None]) ** 2)
-        field = np.matmul((ey * gamp[:, :, None]).transpose(0, 2, 1), ex)          # [n, y, x]
-        # landmark blobs at the ground-truth shape (rigid mean + 1.5 px jitter)
-        for i in range(n):
-            gt68[c0 + i] = align_mean(ibug.MEAN_IBUG_LFPW_68, boxes[c0 + i])
-        gt68[c0:c0 + n] += (1.5 * rng.standard_normal((n, 136))).astype(np.float32)
-        lx, ly = gt68[c0:c0 + n, :68], gt68[c0:c0 + n, 68:]
-        lamp = np.where(np.arange(68) % 2 == 0, 70.0, -70.0).astype(np.float32)
-        bxk = np.exp(-0.5 * ((coords[None, None, :] - lx[:, :, None]) / 3.0) ** 2).astype(np.float32)
-        byk = np.exp(-0.5 * ((coords[None, None, :] - ly[:, :, None]) / 3.0) ** 2).astype(np.float32)
-        field += np.matmul((byk * lamp[None, :, None]).transpose(0, 2, 1), bxk)
-        noise = (24 * (2 * rng.random((n, size, size), dtype=np.float32) - 1))
-        images[c0:c0 + n] = np.clip(128 + field + noise, 0, 255).astype(np.uint8)
+    starts = list(range(0, n_images, chunk))
+    if workers <= 1:
+        rng = np.random.default_rng(seed)
+        for c0 in starts:
+            n = min(chunk, n_images - c0)
+            images[c0:c0 + n], boxes[c0:c0 + n], gt68[c0:c0 + n] = _face_chunk(rng, n, size)
+        return images, boxes, gt68
+    import multiprocessing
+    from concurrent.futures import ProcessPoolExecutor
+
+    jobs = [(seed, ci, min(chunk, n_images - c0), size) for ci, c0 in enumerate(starts)]
+    # fork: the workers only run numpy; call this before the process initialises HIP / torch.cuda
+    with ProcessPoolExecutor(max_workers=workers, mp_context=multiprocessing.get_context("fork")) as pool:
+        for (_, ci, n, _), (im, bx, gt) in zip(jobs, pool.map(_face_chunk_job, jobs)):
+            c0 = starts[ci]
+            images[c0:c0 + n], boxes[c0:c0 + n], gt68[c0:c0 + n] = im, bx, gt
     return images, boxes, gt68
+
+
+def _face_chunk_job(job):
+    seed, ci, n, size = job
+    return _face_chunk(np.random.default_rng([seed, ci]), n, size)
 
 
 def make_samples(boxes: np.ndarray, gt68: np.ndarray, landmark_ids, n_perturb: int = 0,

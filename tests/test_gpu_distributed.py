@@ -42,7 +42,7 @@ def test_bench_under_torchrun(built):
     import torch
     n = min(torch.cuda.device_count(), 2)
     r = _torchrun(n, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--batch", "256",
-                  "--train-rows", "400", "--no-cpu")
+                  "--train-rows", "800", "--no-cpu")
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
