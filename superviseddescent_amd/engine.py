@@ -278,6 +278,12 @@ class Context:
         check(self._lib.sdm_gram_device_ptr(self._h, ctypes.byref(p), ctypes.byref(c)))
         return p.value, c.value
 
+    def features_device_ptr(self):
+        """(device pointer, row stride in floats, rows) of the feature matrix of the last sdm_hog_features call."""
+        p, ld, n = ctypes.c_void_p(), ctypes.c_longlong(), ctypes.c_int()
+        check(self._lib.sdm_features_device_ptr(self._h, ctypes.byref(p), ctypes.byref(ld), ctypes.byref(n)))
+        return p.value, ld.value, n.value
+
     def x_device_ptr(self):
         p, c = ctypes.c_void_p(), ctypes.c_size_t()
         check(self._lib.sdm_x_device_ptr(self._h, ctypes.byref(p), ctypes.byref(c)))

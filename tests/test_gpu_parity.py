@@ -426,3 +426,34 @@ def test_normalised_errors(gpu_ctx, faces):
     assert abs(mean - float(want.astype(np.float64).mean())) <= 1e-12 * abs(mean)
     _, mean2 = gpu_ctx.normalised_errors(fetch=False)
     assert mean2 == mean                                               # deterministic reduction
+
+
+def test_gram_accumulation_stays_accurate_at_40k_rows(gpu_ctx):
+    """A single f32 accumulator chain over 40 000 rows loses ~1e-4 of a Gram entry, which makes G + lambda*I
+    indefinite in the unregularised bias direction (regressors.hpp:143-146 with regularise_last_row = false).
+    The kernel folds 256-row chunks instead: the factorisation must succeed and a Gram block must match float64."""
+    import torch
+    from superviseddescent_amd import parallel
+    n = 40000
+    images, boxes, gt = synth.make_faces(n // 10, seed=3, chunk=32, workers=8)
+    xs, x0, idx = synth.make_samples(boxes, gt, IDS, 9, seed=4)
+    gpu_ctx.set_model_geometry(len(IDS), RE, LE, SHIPPED)
+    gpu_ctx.upload_images(images)
+    gpu_ctx.set_sample_image_index(idx)
+    gpu_ctx.set_x(x0)
+    gpu_ctx.set_targets(xs)
+    gpu_ctx.hog_features(0)
+    gpu_ctx.gram_rhs(0)
+    gpu_ctx.synchronize()                               # torch reads the engine's buffers on its own stream
+    p, cnt = gpu_ctx.gram_device_ptr()
+    F = gpu_ctx.feature_dim(0)
+    ncols = (F + 127) // 128 * 128 + 128
+    G = torch.as_tensor(parallel._DeviceSpan(p, cnt), device="cuda")[: 256 * ncols].cpu().numpy().reshape(256, ncols)
+    pf, ldf, _ = gpu_ctx.features_device_ptr()
+    A = torch.as_tensor(parallel._DeviceSpan(pf, n * ldf), device="cuda").reshape(n, ldf)[:, :256].double()
+    want = np.triu((A.T @ A).cpu().numpy())
+    assert np.abs(np.triu(G[:, :256]) - want).max() <= 5e-6 * np.abs(want).max()
+    R, lam = gpu_ctx.solve(0, 1, 1.5, False, n)          # raises SdmError(-5) if the matrix lost positive definiteness
+    assert np.isfinite(R).all() and lam > 0
+    gpu_ctx.apply(0)
+    assert rel_l2(gpu_ctx.get_x(), xs) < rel_l2(x0, xs)
