@@ -10,7 +10,7 @@ params = [HoGParam(*p) for p in ibug.SHIPPED_HOG_PARAMS]
 n_img = int(sys.argv[1]) if len(sys.argv) > 1 else 1250
 n_pert = int(sys.argv[2]) if len(sys.argv) > 2 else 9
 n_det = int(sys.argv[3]) if len(sys.argv) > 3 else 8192
-t = time.time(); images, boxes, gt = synth.make_faces(max(n_img, n_det), seed=3); print("gen s", round(time.time() - t, 1))
+t = time.time(); images, boxes, gt = synth.make_faces(max(n_img, n_det), seed=3, chunk=32, workers=16); print("gen s", round(time.time() - t, 1))
 xs, x0, idx = synth.make_samples(boxes[:n_img], gt[:n_img], ids, n_perturb=n_pert, seed=4)
 print("train rows", xs.shape[0], "F", 68 * 400 + 1)
 reg = lambda: Regulariser(Regulariser.RegularisationType.MatrixNorm, 1.5, False)

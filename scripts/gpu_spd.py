@@ -6,7 +6,7 @@ from superviseddescent_amd import Context, HoGParam, ibug, synth, SdmError
 ids = ibug.RCR22_IDS; re, le = ibug.eye_indices(ids)
 params = [HoGParam(*p) for p in ibug.SHIPPED_HOG_PARAMS]
 nimg = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
-images, boxes, gt = synth.make_faces(nimg, seed=3, chunk=32, workers=16)
+images, boxes, gt = synth.make_faces(nimg, seed=3, chunk=32, workers=16)  # before the Context: fork
 xs, x0, idx = synth.make_samples(boxes, gt, ids, 9, seed=4)
 ctx = Context(0); ctx.set_model_geometry(len(ids), re, le, params); ctx.upload_images(images)
 for n in (10000, 20000, 40000, 70000, 100000):

@@ -52,6 +52,29 @@ class SdmError(RuntimeError):
         self.code = code
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """PyTorch-ROCm ships its own libamdhip64.so.7 next to libtorch; libsdm_hip.so is linked against the ROCm
+    installation's copy of the same soname.  Whichever is mapped first serves both.  Mapping the ROCm copy first leaves
+    a later ``import torch`` with a runtime it cannot initialise ("No HIP GPUs are available"), so -- when torch is
+    installed but not imported yet -- its copy is mapped first; the engine is happy with either."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib() -> ctypes.CDLL:
     global _LIB
     if _LIB is None:
@@ -59,6 +82,7 @@ def lib() -> ctypes.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        _share_hip_runtime_with_torch()
         L = ctypes.CDLL(LIB_PATH)
         c_int, c_void_p, c_float_p = ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)
         c_int_p = ctypes.POINTER(ctypes.c_int)

@@ -60,6 +60,7 @@ struct sdm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    SolveAux solve_aux = {nullptr, nullptr, nullptr};   // second queue of the Cholesky look-ahead
 
     // geometry
     int L = 0, M = 0;
@@ -277,6 +278,11 @@ sdm_ctx* sdm_create(int device)
         fail(SDM_ERR_HIP, "hipStreamCreate failed"); delete c; return nullptr;
     }
     c->own_stream = true;
+    if (hipStreamCreateWithFlags(&c->solve_aux.stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->solve_aux.chain_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->solve_aux.tail_done, hipEventDisableTiming) != hipSuccess) {
+        fail(SDM_ERR_HIP, "hipStreamCreate failed"); delete c; return nullptr;
+    }
     if (c->status.ensure(1, true, c->stream) || c->lambda_dev.ensure(1, true, c->stream)) { delete c; return nullptr; }
     return c;
 }
@@ -286,6 +292,11 @@ void sdm_destroy(sdm_ctx* c)
     if (!c) return;
     hipError_t e = hipSetDevice(c->device); (void)e;
     e = hipStreamSynchronize(c->stream);
+    if (c->solve_aux.stream) {
+        e = hipStreamSynchronize(c->solve_aux.stream);
+        e = hipEventDestroy(c->solve_aux.chain_done); e = hipEventDestroy(c->solve_aux.tail_done);
+        e = hipStreamDestroy(c->solve_aux.stream);
+    }
     drain_timing(c);
     for (auto ev : c->pool) { e = hipEventDestroy(ev); }
     c->img_owned.release(); c->img_off.release(); c->img_w.release(); c->img_h.release();
@@ -713,7 +724,7 @@ int sdm_solve(sdm_ctx* c, int level, int reg_type, float reg_param, int regulari
     {
         Timer t(c, SDM_T_FACTOR);
         // factor + forward substitution (the back substitution is part of the same launcher)
-        sdm_launch_cholesky_solve(c->G.p, ncols, F, Fp, Mp, c->Rsol.p, Mp, c->winv.p, c->status.p, c->stream);
+        sdm_launch_cholesky_solve(c->G.p, ncols, F, Fp, Mp, c->Rsol.p, Mp, c->winv.p, c->status.p, c->stream, &c->solve_aux);
     }
     HIP_TRY(hipGetLastError());
     // R (Fp x Mp) -> Rt (Mp x ldf), zero padded
@@ -762,7 +773,7 @@ int sdm_solve_normal_equations(sdm_ctx* c, const float* A, int N, int F, const f
         if (reg_type == SDM_REG_MATRIX_NORM) sdm_launch_fro2_upper(dG.p, ncols, F, dfro.p, c->stream);
         sdm_launch_add_diag(dG.p, ncols, F, dfro.p + F, reg_type, reg_param, N, regularise_last_row, c->lambda_dev.p, c->stream);
     }
-    { Timer t(c, SDM_T_FACTOR); sdm_launch_cholesky_solve(dG.p, ncols, F, Fp, Mp, dR.p, Mp, dW.p, c->status.p, c->stream); }
+    { Timer t(c, SDM_T_FACTOR); sdm_launch_cholesky_solve(dG.p, ncols, F, Fp, Mp, dR.p, Mp, dW.p, c->status.p, c->stream, &c->solve_aux); }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy2DAsync(R_host, (size_t)M * sizeof(float), dR.p, (size_t)Mp * sizeof(float), (size_t)M * sizeof(float), F,
                              hipMemcpyDeviceToHost, c->stream));

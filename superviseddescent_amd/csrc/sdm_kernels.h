@@ -116,5 +116,7 @@ void sdm_launch_add_diag(float* G, long long ldg, int F, const double* fro2, int
 // Blocked Cholesky G = U^T U on the upper triangle of the leading F x F block, with the
 // forward substitution fused into the panel updates for the extra columns [rhs0, rhs0+nrhs),
 // then back substitution; R_out [F][ldr].  work: >= 2*NB*NB floats.
+// second queue + two events for the look-ahead of the blocked Cholesky (optional)
+struct SolveAux { hipStream_t stream; hipEvent_t chain_done, tail_done; };
 void sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs, float* R_out,
-                               long long ldr, float* work, int* status, hipStream_t stream);
+                               long long ldr, float* work, int* status, hipStream_t stream, const SolveAux* aux = nullptr);

@@ -30,6 +30,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // C[ti][tj] (+)= alpha * sum_n A[n][ti*128 + i] * A[n][tj*128 + j]
 // 256 threads = 4 waves in a 2x2 arrangement, each wave a 64x64 sub-tile = 2x2 MFMA 32x32 tiles.
+// CHUNKED: two-level summation for long row ranges (the Gram matrix); the Cholesky trailing updates (<= 512 rows)
+// use the plain single-chain instance, which needs 64 registers less and runs at a higher occupancy.
+template <bool CHUNKED>
 __global__ void __launch_bounds__(256)
 syrk_tn_kernel(const float* __restrict__ A, long long lda, int rows, float* __restrict__ C, long long ldc,
                float alpha, int accumulate, int tile_i0)
@@ -82,8 +85,9 @@ syrk_tn_kernel(const float* __restrict__ A, long long lda, int rows, float* __re
 
     const int nslabs = (rows + SYRK_BK - 1) / SYRK_BK;
     load_slab(0);
-    for (int s0 = 0; s0 < nslabs; s0 += SYRK_CHUNK) {
-        const int s1 = s0 + SYRK_CHUNK < nslabs ? s0 + SYRK_CHUNK : nslabs;
+    const int chunk = CHUNKED ? SYRK_CHUNK : nslabs;
+    for (int s0 = 0; s0 < nslabs; s0 += chunk) {
+        const int s1 = s0 + chunk < nslabs ? s0 + chunk : nslabs;
         for (int s = s0; s < s1; ++s) {
             __syncthreads();          // previous slab fully consumed
             store_slab();
@@ -105,13 +109,14 @@ syrk_tn_kernel(const float* __restrict__ A, long long lda, int rows, float* __re
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
             }
         }
-        // fold the chunk
+        if (CHUNKED) {   // fold the chunk
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
+                for (int n = 0; n < 2; ++n)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) { tot[m][n][e] += acc[m][n][e]; acc[m][n][e] = 0.0f; }
+                    for (int e = 0; e < 16; ++e) { tot[m][n][e] += acc[m][n][e]; acc[m][n][e] = 0.0f; }
+        }
     }
 
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
@@ -125,7 +130,7 @@ syrk_tn_kernel(const float* __restrict__ A, long long lda, int rows, float* __re
                 const long long gi = (long long)ti * TILE + wr * 64 + m * 32 + r;
                 const long long gj = (long long)tj * TILE + wc * 64 + n * 32 + (lane & 31);
                 float* p = C + gi * ldc + gj;
-                float v = alpha * tot[m][n][e];
+                float v = alpha * (CHUNKED ? tot[m][n][e] : acc[m][n][e]);
                 if (accumulate) v += *p;
                 *p = v;
             }
@@ -470,8 +475,12 @@ void sdm_launch_syrk_tn(const float* A, long long lda, int rows, int ncols, floa
     const int T = ncols / TILE - tile_i0;
     if (T <= 0 || rows <= 0) return;
     const int Ty = (tile_rows > 0 && tile_rows < T) ? tile_rows : T;
-    hipLaunchKernelGGL(syrk_tn_kernel, dim3(T, Ty), dim3(256), 0, stream, A, lda, rows, C, ldc, alpha,
-                       accumulate, tile_i0);
+    if (rows > SYRK_CHUNK * SYRK_BK * 4)
+        hipLaunchKernelGGL(syrk_tn_kernel<true>, dim3(T, Ty), dim3(256), 0, stream, A, lda, rows, C, ldc, alpha,
+                           accumulate, tile_i0);
+    else
+        hipLaunchKernelGGL(syrk_tn_kernel<false>, dim3(T, Ty), dim3(256), 0, stream, A, lda, rows, C, ldc, alpha,
+                           accumulate, tile_i0);
 }
 
 // ---- packed exchange buffer ----------------------------------------------------------------------------------------
@@ -519,7 +528,7 @@ void sdm_launch_add_diag(float* G, long long ldg, int F, const double* fro2, int
 }
 
 void sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs, float* R_out,
-                               long long ldr, float* work, int* status, hipStream_t stream)
+                               long long ldr, float* work, int* status, hipStream_t stream, const SolveAux* aux)
 {
     // work: Tf * 128 * 128 floats, receives the transposed inverses U_kk^-T of the diagonal factor tiles
     const int Tf = (F + TILE - 1) / TILE;          // factor tiles
@@ -539,7 +548,13 @@ void sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrh
     // Panels are processed in groups of LAZY: inside a group only the NEXT tile row receives the pending rank-128
     // updates (a thin launch); the whole trailing matrix is updated once per group with K = 128*LAZY.  That is 1/LAZY of
     // the passes over the (up to 3 GB) trailing matrix of the plain right-looking scheme and a 4x deeper MFMA K-loop.
+    // Look-ahead over two queues (aux): the group-end update is split into the tile rows of the NEXT group (head, on
+    // `stream`, the critical path) and everything below them (tail, on aux->stream).  The next group's potrf / trsm /
+    // row updates -- single-workgroup latency chains -- are then issued while the tail, which carries almost all the
+    // flops, is still in flight; the two only meet again at the next head (same tile rows), which waits for the tail.
     const int LAZY = 4;
+    const bool overlap = aux && aux->stream && Tf > 2 * LAZY;
+    bool tail_pending = false;
     for (int k = 0; k < Tf; ++k) {
         const int k0 = k * TILE;
         const int g0 = (k / LAZY) * LAZY;                 // first panel of this group
@@ -551,9 +566,25 @@ void sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrh
         hipLaunchKernelGGL(trsm_tile_kernel, dim3(ntr + 1), dim3(TILE * PQ), lds_trsm, stream, G, ldg, k0, k + 1, ntr,
                            work + (size_t)k * TILE * TILE);
         const bool group_end = (k + 1) % LAZY == 0 || k == Tf - 1;
-        if (group_end && ntr > 0)   // trailing update of all tiles (ti >= k+1, tj >= ti) from the group's panel rows
-            sdm_launch_syrk_tn(G + (long long)g0 * TILE * ldg, ldg, (k + 1 - g0) * TILE, ncols, G, ldg, -1.0f, 1, k + 1, stream, 0);
+        if (group_end && ntr > 0) {   // trailing update of all tiles (ti >= k+1, tj >= ti) from the group's panel rows
+            const float* panels = G + (long long)g0 * TILE * ldg;
+            const int prow = (k + 1 - g0) * TILE;
+            if (!overlap) {
+                sdm_launch_syrk_tn(panels, ldg, prow, ncols, G, ldg, -1.0f, 1, k + 1, stream, 0);
+            } else {
+                (void)hipEventRecord(aux->chain_done, stream);
+                if (tail_pending) (void)hipStreamWaitEvent(stream, aux->tail_done, 0);   // head rows were tail rows of the last group
+                sdm_launch_syrk_tn(panels, ldg, prow, ncols, G, ldg, -1.0f, 1, k + 1, stream, LAZY);
+                if (k + 1 + LAZY < T) {
+                    (void)hipStreamWaitEvent(aux->stream, aux->chain_done, 0);
+                    sdm_launch_syrk_tn(panels, ldg, prow, ncols, G, ldg, -1.0f, 1, k + 1 + LAZY, aux->stream, 0);
+                    (void)hipEventRecord(aux->tail_done, aux->stream);
+                    tail_pending = true;
+                }
+            }
+        }
     }
+    if (tail_pending) (void)hipStreamWaitEvent(stream, aux->tail_done, 0);
     const int nj = nrhs / 16;   // nrhs is a multiple of 16, <= 144
     for (int k = Tf - 1; k >= 0; --k) {
         float* wk = work + (size_t)k * TILE * TILE;

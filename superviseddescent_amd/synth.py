@@ -90,7 +90,8 @@ def make_faces(n_images: int, seed: int = SEED, size: int = IMAGE_SIZE, chunk: i
     from concurrent.futures import ProcessPoolExecutor
 
     jobs = [(seed, ci, min(chunk, n_images - c0), size) for ci, c0 in enumerate(starts)]
-    # fork: the workers only run numpy; call this before the process initialises HIP / torch.cuda
+    # fork: the workers only run numpy.  Call this BEFORE the process initialises HIP / torch.cuda: forking an
+    # initialised ROCm process leaves a later torch.cuda initialisation without devices
     with ProcessPoolExecutor(max_workers=workers, mp_context=multiprocessing.get_context("fork")) as pool:
         for (_, ci, n, _), (im, bx, gt) in zip(jobs, pool.map(_face_chunk_job, jobs)):
             c0 = starts[ci]
