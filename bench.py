@@ -241,8 +241,9 @@ def main():
             "traffic_source": traffic_src,
             "valu_issue": valu_issue,
             "algorithmic_bytes_per_launch": bytes_per_launch,
-            "note": "the kernel is VALU-issue bound (about 4.5 k VALU instructions per patch, SQ_ACTIVE_INST_VALU / "
-                    "SQ_BUSY_CYCLES in profiles/), not HBM bound: HBM traffic is within 15 % of the algorithmic bytes",
+            "note": "the kernel is VALU-issue bound, not HBM bound: see valu_issue (SQ_INSTS_VALU of the committed PMC pass over "
+                    "this launch's duration; %s VALU instructions per patch); HBM traffic is below the algorithmic bytes"
+                    % (int(valu_issue["insts_per_launch"] / (args.batch * L)) if valu_issue else "n/a"),
             "avg_launch_ms": hog_avg_ms,
             "launches": hog_n,
         },

@@ -7,7 +7,7 @@ REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/profile_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu"
+CMD="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu --train-rows 20000"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $CMD > $OUT/bench_under_trace.json 2> $OUT/trace_stderr.log
 cp $OUT/trace/t_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 i=0
@@ -22,7 +22,7 @@ out="$OUT"
 def short(n):
     m=re.search(r'(\w+_kernel)', n); return m.group(1) if m else n.split("(")[0][:40]
 with open(out+"/summary.txt","w") as fh:
-    fh.write("== rocprofv3 --kernel-trace --stats : python bench.py --steps 10 --warmup 2 --no-cpu ==\n")
+    fh.write("== rocprofv3 --kernel-trace --stats : python bench.py --steps 10 --warmup 2 --no-cpu --train-rows 20000 ==\n")
     fh.write("%-28s %7s %13s %11s %7s\n" % ("kernel","calls","total_us","avg_us","%"))
     for r in list(csv.DictReader(open(out+"/kernel_stats.csv")))[:14]:
         fh.write("%-28s %7s %13.1f %11.2f %7.2f\n" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"])/1e3, float(r["AverageNs"])/1e3, float(r["Percentage"])))
@@ -67,6 +67,6 @@ for k,v in rows.items():
                                    "launch_geometry": k.split(" grid=")[1], "dispatches": cnt[(k,"FETCH_SIZE")]}
         for c in ("SQ_INSTS_VALU","SQ_INSTS_SALU","SQ_INSTS_LDS","SQ_WAVES"):
             if c in v: hbm[k.split(" grid=")[0]][c]=v[c]/cnt[(k,c)]
-json.dump({"source": "scripts/profile_bench.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of python bench.py --steps 10 --warmup 2 --no-cpu; FETCH_SIZE x2 (gfx950), KB units", "kernels": hbm}, open(out+"/hbm_traffic.json","w"), indent=1)
+json.dump({"source": "scripts/profile_bench.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of python bench.py --steps 10 --warmup 2 --no-cpu --train-rows 20000; FETCH_SIZE x2 (gfx950), KB units", "kernels": hbm}, open(out+"/hbm_traffic.json","w"), indent=1)
 print(open(out+"/summary.txt").read())
 PY
