@@ -133,6 +133,11 @@ int sdm_apply(sdm_ctx* ctx, int level);
  * template, = rcr::detection_model::detect (model.hpp:132-157) for a batch.  x_host may be NULL. */
 int sdm_detect_batch(sdm_ctx* ctx, float* x_host);
 
+/* Known-template mode (superviseddescent.hpp:195-197, 287-289): when `templates` (n_samples x
+ * feature_dim, row n = the known y of sample n) is set, every sdm_hog_features call stores features - templates, which
+ * is what sdm_gram_rhs / sdm_apply / sdm_detect_batch then see.  NULL clears it (the RCR case: templates.empty()). */
+int sdm_set_templates(sdm_ctx* ctx, const float* templates, int n_samples, int feature_dim);
+
 /* The step before the path: x_n = rcr::align_mean(mean, box_n) (include/rcr/model.hpp:64-76), or
  * align_mean(mean, perturb(box_n, t_n)) (apps/rcr/rcr-train.cpp:130-146, 421-431) when `perturbations` is given,
  * evaluated on the device straight into the state x (replaces sdm_set_x).  mean: 2L floats in the unit box;

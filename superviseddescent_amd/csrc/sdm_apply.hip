@@ -170,6 +170,15 @@ __global__ void targets_kernel(const float* __restrict__ x, const float* __restr
     feat[(long long)row * ldf + bcol0 + col] = (xr[col] - xstar[t]) * n;
 }
 
+// ---- known-template mode: observed = features - templates (superviseddescent.hpp:195-197, 287-289) ---------------------
+__global__ void subtract_templates_kernel(float* __restrict__ feat, long long ldf, const float* __restrict__ tmpl, int N, int F)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)N * F) return;
+    const int row = (int)(t / F), col = (int)(t - (long long)row * F);
+    feat[(long long)row * ldf + col] -= tmpl[t];
+}
+
 // ---- the step before the path: initialisation from face boxes (apps/rcr/rcr-train.cpp:130-146, model.hpp:64-76) ----
 __global__ void init_boxes_kernel(const float* __restrict__ mean, const int* __restrict__ boxes,
                                   const float* __restrict__ pert, int N, int L, float* __restrict__ x)
@@ -236,6 +245,13 @@ __global__ void sum_final_kernel(const double* __restrict__ part, int nparts, lo
 }
 
 }  // namespace
+
+void sdm_launch_subtract_templates(float* feat, long long ldf, const float* tmpl, int N, int F, hipStream_t stream)
+{
+    const long long total = (long long)N * F;
+    if (total <= 0) return;
+    hipLaunchKernelGGL(subtract_templates_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, feat, ldf, tmpl, N, F);
+}
 
 void sdm_launch_init_boxes(const float* mean, const int* boxes, const float* pert, int N, int L, float* x, hipStream_t stream)
 {

@@ -88,6 +88,8 @@ struct sdm_ctx {
     DevBuf<float> x[2];
     int cur = 0;
     DevBuf<float> xstar;
+    DevBuf<float> tmpl;     // known-template mode: N x tmpl_F templates subtracted from the features of every level
+    int tmpl_F = 0, tmpl_N = 0;
     bool have_targets = false;
     DevBuf<float> feat;
     int feat_level = -1;
@@ -221,6 +223,11 @@ int do_hog(sdm_ctx* c, int level)
             sdm_launch_hog(image_set(c), c->idx_identity ? nullptr : c->img_idx.p, c->x[c->cur].p, c->N, c->L,
                            c->eyes, c->levels[level], c->feat.p, c->ldf, c->patch_idx.p, c->status.p, c->stream);
     }
+    if (c->tmpl_N > 0) {   // known-template mode: the regressors see features - templates (superviseddescent.hpp:195-197)
+        if (c->tmpl_N != c->N || c->tmpl_F != level_F(c, level))
+            return fail(SDM_ERR_INVALID, "templates do not match the sample count / feature dimension of this level");
+        sdm_launch_subtract_templates(c->feat.p, c->ldf, c->tmpl.p, c->N, c->tmpl_F, c->stream);
+    }
     HIP_TRY(hipGetLastError());
     c->feat_level = level;
     return SDM_OK;
@@ -301,7 +308,7 @@ void sdm_destroy(sdm_ctx* c)
     for (auto ev : c->pool) { e = hipEventDestroy(ev); }
     c->img_owned.release(); c->img_off.release(); c->img_w.release(); c->img_h.release();
     c->img_stride.release(); c->img_idx.release(); c->x[0].release(); c->x[1].release();
-    c->xstar.release(); c->feat.release(); c->patch_idx.release(); c->status.release();
+    c->xstar.release(); c->tmpl.release(); c->feat.release(); c->patch_idx.release(); c->status.release();
     c->partial.release(); c->G.release(); c->gpack.release(); c->fro.release(); c->Rsol.release(); c->winv.release(); c->lambda_dev.release();
     for (auto& r : c->Rt) r.release();
     if (c->own_stream) e = hipStreamDestroy(c->stream);
@@ -505,6 +512,20 @@ static int set_x_common(sdm_ctx* c, const float* x, int N, hipMemcpyKind kind)
 
 int sdm_set_x(sdm_ctx* c, const float* x, int N) { return set_x_common(c, x, N, hipMemcpyHostToDevice); }
 int sdm_set_x_device(sdm_ctx* c, const float* x, int N) { return set_x_common(c, x, N, hipMemcpyDeviceToDevice); }
+
+int sdm_set_templates(sdm_ctx* c, const float* templates, int n_samples, int feature_dim)
+{
+    if (!c) return fail(SDM_ERR_INVALID, "null context");
+    if (!templates) { c->tmpl_N = 0; c->tmpl_F = 0; return SDM_OK; }
+    if (n_samples <= 0 || feature_dim <= 0) return fail(SDM_ERR_INVALID, "bad template matrix");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = c->tmpl.ensure((size_t)n_samples * feature_dim);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->tmpl.p, templates, (size_t)n_samples * feature_dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->tmpl_N = n_samples; c->tmpl_F = feature_dim;
+    return SDM_OK;
+}
 
 int sdm_init_from_boxes(sdm_ctx* c, const float* mean, const int* boxes, const float* perturbations, int N, float* x_host)
 {

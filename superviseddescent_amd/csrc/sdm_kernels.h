@@ -85,6 +85,9 @@ void sdm_launch_apply(const float* feat, long long ldf, int N, int F, const floa
                       int M, const float* x_in, float* x_out, int L, const EyeIdxDev& eyes,
                       float* partial, int splits, hipStream_t stream);
 
+// feat[n][0:F] -= tmpl[n][0:F]  (known-template mode, superviseddescent.hpp:195-197)
+void sdm_launch_subtract_templates(float* feat, long long ldf, const float* tmpl, int N, int F, hipStream_t stream);
+
 // ---- before / after the path ----------------------------------------------------
 // x[n] = align_mean(mean, perturb(box[n], pert[n]))   (model.hpp:64-76, rcr-train.cpp:130-146); pert may be null
 void sdm_launch_init_boxes(const float* mean, const int* boxes, const float* pert, int N, int L, float* x, hipStream_t stream);

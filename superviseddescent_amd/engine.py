@@ -210,6 +210,14 @@ class Context:
         return None
 
     # -- training ----------------------------------------------------------------------------------
+    def set_templates(self, templates: Optional[np.ndarray]):
+        """Known-template mode: features - templates from now on (None / empty clears it)."""
+        if templates is None or np.size(templates) == 0:
+            check(self._lib.sdm_set_templates(self._h, None, 0, 0))
+            return
+        t = np.ascontiguousarray(templates, np.float32)
+        check(self._lib.sdm_set_templates(self._h, t.ctypes.data, t.shape[0], t.shape[1]))
+
     def set_targets(self, xstar: np.ndarray):
         xs = np.ascontiguousarray(xstar, np.float32)
         check(self._lib.sdm_set_targets(self._h, _fp(xs), xs.shape[0]))
@@ -404,10 +412,9 @@ class SupervisedDescentOptimiser:
     def train(self, parameters, initialisations, templates, projection: HogTransform,
               on_training_epoch_callback: Optional[Callable[[np.ndarray], None]] = None,
               allreduce=None, world_size: int = 1, n_train_global: int = 0):
-        if templates is not None and np.size(templates) != 0:
-            raise NotImplementedError("known-template training is served by the C++ header layer")
         self._bind(projection)
         c = self.ctx
+        c.set_templates(templates)                                           # superviseddescent.hpp:195-197
         c.set_x(np.asarray(initialisations, np.float32))
         c.set_targets(np.asarray(parameters, np.float32))
         c.set_allreduce(allreduce, world_size)
@@ -432,11 +439,10 @@ class SupervisedDescentOptimiser:
 
     def test(self, initialisations, templates, projection: HogTransform,
              on_regressor_iteration_callback: Optional[Callable[[np.ndarray], None]] = None) -> np.ndarray:
-        if templates is not None and np.size(templates) != 0:
-            raise NotImplementedError("known-template testing is served by the C++ header layer")
         self._bind(projection)
         self._load_regressors()
         c = self.ctx
+        c.set_templates(templates)                                           # superviseddescent.hpp:287-289
         c.set_x(np.atleast_2d(np.asarray(initialisations, np.float32)))
         if on_regressor_iteration_callback is None:
             return c.detect_batch()                                           # :262-306

@@ -96,10 +96,19 @@ struct BatchedBackend<rcr::HogTransform, LinearRegressor<Solver>, rcr::InterEyeD
         }
     }
 
-    /** reference superviseddescent.hpp:165-219 with templates.empty(): per level HOG -> targets/Gram/RHS -> solve -> apply. */
+    /** known-template mode (superviseddescent.hpp:195-197, 287-289): the device subtracts the rows after every HOG call */
+    static void set_templates(sdm_ctx* c, const cv::Mat& templates, int n_rows)
+    {
+        if (templates.empty()) { hip::check(sdm_set_templates(c, nullptr, 0, 0), "sdm_set_templates"); return; }
+        if (templates.rows != n_rows) throw std::runtime_error("templates: one row per sample expected");
+        cv::Mat t = templates.isContinuous() ? templates : templates.clone();
+        hip::check(sdm_set_templates(c, t.ptr<float>(0), t.rows, t.cols), "sdm_set_templates");
+    }
+
+    /** reference superviseddescent.hpp:165-219: per level HOG -> targets/Gram/RHS -> solve -> apply. */
     template <class Callback>
     static void train(Regressors& regressors, rcr::InterEyeDistanceNormalisation&, cv::Mat parameters, cv::Mat initialisations,
-                      rcr::HogTransform& hog, Callback on_training_epoch_callback)
+                      cv::Mat templates, rcr::HogTransform& hog, Callback on_training_epoch_callback)
     {
         if (hog.get_hog_params().size() != regressors.size()) throw std::runtime_error("one HoGParam per regressor level expected");
         hip::Handle h(0);
@@ -107,6 +116,7 @@ struct BatchedBackend<rcr::HogTransform, LinearRegressor<Solver>, rcr::InterEyeD
         cv::Mat x0 = initialisations.isContinuous() ? initialisations : initialisations.clone();
         cv::Mat xs = parameters.isContinuous() ? parameters : parameters.clone();
         bind(h, hog, x0.rows);
+        set_templates(c, templates, x0.rows);
         hip::check(sdm_set_x(c, x0.ptr<float>(0), x0.rows), "sdm_set_x");
         hip::check(sdm_set_targets(c, xs.ptr<float>(0), xs.rows), "sdm_set_targets");
         for (size_t level = 0; level < regressors.size(); ++level) {
@@ -124,10 +134,10 @@ struct BatchedBackend<rcr::HogTransform, LinearRegressor<Solver>, rcr::InterEyeD
         }
     }
 
-    /** reference superviseddescent.hpp:262-306 / 323-344 with templates.empty(). */
+    /** reference superviseddescent.hpp:262-306 / 323-344. */
     template <class Callback>
-    static cv::Mat test(Regressors& regressors, rcr::InterEyeDistanceNormalisation&, cv::Mat initialisations, rcr::HogTransform& hog,
-                        Callback on_regressor_iteration_callback)
+    static cv::Mat test(Regressors& regressors, rcr::InterEyeDistanceNormalisation&, cv::Mat initialisations, cv::Mat templates,
+                        rcr::HogTransform& hog, Callback on_regressor_iteration_callback)
     {
         if (hog.get_hog_params().size() != regressors.size()) throw std::runtime_error("one HoGParam per regressor level expected");
         hip::Handle h(0);
@@ -139,6 +149,7 @@ struct BatchedBackend<rcr::HogTransform, LinearRegressor<Solver>, rcr::InterEyeD
             if (R.rows != sdm_feature_dim(c, (int)level) || R.cols != x0.cols) throw std::runtime_error("regressor does not match the HOG geometry");
             hip::check(sdm_set_regressor(c, (int)level, R.ptr<float>(0)), "sdm_set_regressor");
         }
+        set_templates(c, templates, x0.rows);
         hip::check(sdm_set_x(c, x0.ptr<float>(0), x0.rows), "sdm_set_x");
         // the default callback (the free function no_eval) needs no device->host copy of the intermediate x
         constexpr bool has_callback = !std::is_same<typename std::decay<Callback>::type, void (*)(const cv::Mat&)>::value;

@@ -7,7 +7,7 @@
 //
 //  * batched MI355X path -- taken when a specialisation of detail::BatchedBackend exists for the
 //    (ProjectionFunction, RegressorType, NormalisationStrategy) triple, i.e. for rcr::HogTransform +
-//    LinearRegressor<...> + rcr::InterEyeDistanceNormalisation (see rcr/model.hpp).  One cascade level is
+//    LinearRegressor<...> + rcr::InterEyeDistanceNormalisation (see rcr/model.hpp), with or without a template matrix.  One cascade level is
 //    then a handful of kernel launches over the whole batch (HOG extraction, Gram/RHS, Cholesky solve,
 //    regressor apply) behind the C-ABI of include/sdm.h; features never leave HBM.  This replaces the
 //    reference's thread pool of per-sample tasks and its serial push_back/predict loops
@@ -126,11 +126,9 @@ public:
     {
         using Backend = detail::BatchedBackend<ProjectionFunction, RegressorType, NormalisationStrategy>;
         if constexpr (Backend::available) {
-            if (templates.empty()) {
-                Backend::train(regressors, normalisation_strategy, parameters, initialisations, projection,
-                               on_training_epoch_callback);
-                return;
-            }
+            Backend::train(regressors, normalisation_strategy, parameters, initialisations, templates, projection,
+                           on_training_epoch_callback);
+            return;
         }
         using cv::Mat;
         Mat current_x = initialisations;
@@ -167,9 +165,8 @@ public:
     {
         using Backend = detail::BatchedBackend<ProjectionFunction, RegressorType, NormalisationStrategy>;
         if constexpr (Backend::available) {
-            if (templates.empty())
-                return Backend::test(regressors, normalisation_strategy, initialisations, projection,
-                                     on_regressor_iteration_callback);
+            return Backend::test(regressors, normalisation_strategy, initialisations, templates, projection,
+                                 on_regressor_iteration_callback);
         }
         using cv::Mat;
         Mat current_x = initialisations;
@@ -188,8 +185,7 @@ public:
     {
         using Backend = detail::BatchedBackend<ProjectionFunction, RegressorType, NormalisationStrategy>;
         if constexpr (Backend::available) {
-            if (templates.empty())
-                return Backend::test(regressors, normalisation_strategy, initialisations, projection, no_eval);
+            return Backend::test(regressors, normalisation_strategy, initialisations, templates, projection, no_eval);
         }
         using cv::Mat;
         Mat current_x = initialisations;

@@ -39,6 +39,7 @@ class OracleContext:
     def set_sample_image_index(self, idx): self.idx = idx
     def set_x(self, x): self.x = np.asarray(x, np.float32).copy(); self.N = self.x.shape[0]
     def set_targets(self, xs): self.xs = np.asarray(xs, np.float32)
+    def set_templates(self, t): assert t is None or np.size(t) == 0
     def get_x(self): return self.x.copy()
     def set_allreduce(self, fn, world): self.allreduce, self.world = fn, world
 

@@ -457,3 +457,38 @@ def test_gram_accumulation_stays_accurate_at_40k_rows(gpu_ctx):
     assert np.isfinite(R).all() and lam > 0
     gpu_ctx.apply(0)
     assert rel_l2(gpu_ctx.get_x(), xs) < rel_l2(x0, xs)
+
+
+def test_known_template_mode_matches_oracle(faces):
+    """superviseddescent.hpp:195-197, 287-289: with a template matrix y the regressors see h(x) - y.  Templates here are
+    the HOG features at the ground-truth landmarks (the 'known template' of each sample), same feature layout on all
+    levels; train and test against the oracle."""
+    images, boxes, gt, _, _ = faces
+    x_star, x0, idx = synth.make_samples(boxes[:128], gt[:128], IDS, n_perturb=2, seed=15)   # N = 384
+    params = [(1, 3, 12, 4, 0.9), (1, 3, 12, 4, 0.6)]            # same F on both levels, as one template matrix requires
+    ohog = orc.HogTransform(images[:128], [orc.HoGParam(*p) for p in params], RE, LE, idx, n_threads=os.cpu_count() or 1)
+    templates = ohog(x_star, 0).copy()        # (the oracle functor reuses its output buffer)
+    reg = (1, 1.5, True)    # (the bias column of features - templates is 0: it must be regularised, in the reference too)
+    sdo = SupervisedDescentOptimiser([LinearRegressor(Regulariser(*reg)) for _ in params])
+    hog = HogTransform(images[:128], [HoGParam(*p) for p in params], IDS, ibug.RIGHT_EYE_IDS, ibug.LEFT_EYE_IDS, idx)
+    x_gpu = sdo.train(x_star, x0, templates, hog)
+    osdo = orc.SupervisedDescentOptimiser([orc.LinearRegressor(orc.Regulariser(*reg)) for _ in params],
+                                          orc.InterEyeDistanceNormalisation(RE, LE))
+    x_orc = osdo.train(x_star, x0, templates, ohog)
+    assert rel_l2(x_gpu, x_orc) < 1e-4
+    # observed values really are features - templates
+    sdo.ctx.set_x(x0)
+    got = sdo.ctx.hog_features(0, fetch=True)
+    want = ohog(x0, 0) - templates
+    assert np.abs(got - want).max() <= 2e-6
+    for lvl, r in enumerate(sdo.regressors):
+        osdo.regressors[lvl].x = r.x
+    assert rel_l2(sdo.test(x0, templates, hog), osdo.test(x0, templates, ohog)) < 1e-4
+    # and the mode is switched off again by an empty template matrix
+    sdo.ctx.set_templates(None)
+    sdo.ctx.set_x(x0)
+    assert np.abs(sdo.ctx.hog_features(0, fetch=True) - ohog(x0, 0)).max() <= 2e-6
+    with pytest.raises(SdmError):
+        sdo.ctx.set_templates(templates[:10])
+        sdo.ctx.hog_features(0)
+    sdo.ctx.set_templates(None)
