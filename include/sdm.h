@@ -40,7 +40,11 @@ extern "C" {
 #define SDM_REG_MANUAL 0           /* Regulariser::RegularisationType::Manual,     regressors.hpp:96 */
 #define SDM_REG_MATRIX_NORM 1      /* Regulariser::RegularisationType::MatrixNorm, regressors.hpp:97 */
 
-/* rcr::HoGParam, include/rcr/adaptive_vlhog.hpp:41-60 (same field order as its cereal serialisation) */
+/* rcr::HoGParam, include/rcr/adaptive_vlhog.hpp:41-60 (same field order as its cereal serialisation).
+ * relative_patch_size > 0: the IED-adaptive rcr::HogTransform (adaptive_vlhog.hpp:109-185), feature row = L patches + bias.
+ * relative_patch_size == 0: the non-adaptive HogTransform of examples/landmark_detection.cpp:158-269 -- patch_width_half =
+ *   num_cells * (cell_size / 2) pixels, ROI not resized (cell_size must be even), NO bias column; the eye index lists
+ *   may then be empty (NoNormalisation, superviseddescent.hpp:60-74). */
 typedef struct sdm_hog_param {
     int variant;
     int num_cells;

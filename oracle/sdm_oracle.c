@@ -377,15 +377,20 @@ int orc_hog_transform(const uint8_t *gray, int iw, int ih, int istride,
     int S = C * c;                                        /* adaptive_vlhog.hpp:154 */
     int D = orc_hog_dimension(hp->variant, O);
     int P = C * C * D;
-    double ied = orc_get_ied(x, L, re, nre, le, nle);
+    /* relative_patch_size == 0 selects the NON-adaptive transform of examples/landmark_detection.cpp:158-269:
+     * patch_width_half = num_cells * (cell_size / 2) (:205), the 2h x 2h ROI goes to VLFeat unresized (an identity
+     * resize here; cell sizes must be even so that 2h == S) and no bias column is appended (:254-262). */
+    int adaptive = hp->relative_patch_size > 0.0f;
+    double ied = adaptive ? orc_get_ied(x, L, re, nre, le, nle) : 0.0;
     /* adaptive_vlhog.hpp:123: float * double / 2 -> std::round (half away from zero) -> int */
-    int h = (int)round((double)hp->relative_patch_size * ied / 2);
+    int h = adaptive ? (int)round((double)hp->relative_patch_size * ied / 2) : C * (c / 2);
     uint8_t *roi, *rsz;
     float *fimg, *hog;
     int i, j, u, v;
 
     if (idx_out) idx_out[0] = h;
     if (h <= 0) return -2;
+    if (!adaptive && 2 * h != S) return -3;               /* odd cell size: not the same cell grid, unsupported */
 
     roi = (uint8_t *)malloc((size_t)4 * h * h);
     rsz = (uint8_t *)malloc((size_t)S * S);
@@ -419,7 +424,7 @@ int orc_hog_transform(const uint8_t *gray, int iw, int ih, int istride,
                         d[j * C * C + xx * C + yy] = hog[j * C * C + yy * C + xx];
         }
     }
-    feat[(size_t)L * P] = 1.0f;                           /* :182-183 bias */
+    if (adaptive) feat[(size_t)L * P] = 1.0f;             /* adaptive_vlhog.hpp:182-183 bias */
     free(roi); free(rsz); free(fimg); free(hog);
     return 0;
 }

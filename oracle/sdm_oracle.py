@@ -199,7 +199,9 @@ def gradient_table(O: int):
 
 
 def feature_dim(L: int, hp: HoGParam) -> int:
-    return L * hp.patch_dim + 1
+    """adaptive transform: L*P + bias (adaptive_vlhog.hpp:176-183); relative_patch_size == 0 = the non-adaptive
+    transform of examples/landmark_detection.cpp:158-269, which has no bias column."""
+    return L * hp.patch_dim + (1 if hp.relative_patch_size > 0 else 0)
 
 
 def hog_features_batch(images: np.ndarray, img_index: Optional[np.ndarray], x: np.ndarray,

@@ -175,7 +175,8 @@ int check_status(sdm_ctx* c)
     return SDM_OK;
 }
 
-int level_F(const sdm_ctx* c, int level) { return c->L * c->levels[level].P + 1; }
+// feature row length: L patches + the bias of the adaptive transform (the non-adaptive example transform has none)
+int level_F(const sdm_ctx* c, int level) { return c->L * c->levels[level].P + (c->levels[level].fixed_h > 0 ? 0 : 1); }
 
 ImageSetDev image_set(const sdm_ctx* c)
 {
@@ -205,7 +206,7 @@ int do_hog(sdm_ctx* c, int level)
 {
     if (!c->img_base) return fail(SDM_ERR_INVALID, "no images set");
     if (c->N <= 0) return fail(SDM_ERR_INVALID, "no samples set (sdm_set_x)");
-    if (c->eyes.nre <= 0 || c->eyes.nle <= 0)
+    if (c->levels[level].fixed_h == 0 && (c->eyes.nre <= 0 || c->eyes.nle <= 0))
         return fail(SDM_ERR_INVALID, "HOG features need eye landmark indices (IED-adaptive patch size)");
     if (c->idx_identity && c->N > c->n_images)
         return fail(SDM_ERR_INVALID, "more samples than images and no sample->image index set");
@@ -357,7 +358,12 @@ int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int*
         if (p.num_cells < 1 || p.cell_size < 1 || p.num_bins < 1 || p.num_bins > SDM_MAX_ORIENT)
             return fail(SDM_ERR_INVALID, "HOG parameters out of range (num_bins <= 16)");
         if (p.num_cells * p.cell_size <= 3) return fail(SDM_ERR_INVALID, "resized ROI must exceed 3 px (hog.c:545-546)");
-        if (!(p.relative_patch_size > 0.0f)) return fail(SDM_ERR_INVALID, "relative_patch_size must be positive");
+        // relative_patch_size == 0 selects the non-adaptive transform of examples/landmark_detection.cpp:158-269
+        if (!(p.relative_patch_size >= 0.0f)) return fail(SDM_ERR_INVALID, "relative_patch_size must be >= 0");
+        if (p.relative_patch_size == 0.0f && (p.cell_size & 1))
+            return fail(SDM_ERR_INVALID, "the non-adaptive transform needs an even cell_size (its 2h x 2h ROI is not resized)");
+        if (p.relative_patch_size > 0.0f && nre == 0)
+            return fail(SDM_ERR_INVALID, "the IED-adaptive transform needs eye landmark indices");
         HogLevelDev lv;
         memset(&lv, 0, sizeof(lv));
         lv.variant = p.variant; lv.C = p.num_cells; lv.cell = p.cell_size; lv.O = p.num_bins;
@@ -365,6 +371,7 @@ int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int*
         lv.D = p.variant == SDM_VARIANT_UOCTTI ? 3 * lv.O + 4 : 4 * lv.O;   // hog.c:212-219
         lv.P = lv.C * lv.C * lv.D;
         lv.rel = p.relative_patch_size;
+        lv.fixed_h = p.relative_patch_size == 0.0f ? p.num_cells * (p.cell_size / 2) : 0;   // landmark_detection.cpp:205
         for (int k = 0; k < lv.O; ++k) {            // hog.c:195-199, evaluated with the host libm
             const double angle = k * 3.141592653589793 / lv.O;
             lv.ox[k] = (float)cos(angle);
@@ -388,7 +395,7 @@ int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int*
             c->fast_bins.push_back(mism[1] == 0 ? 2 : (mism[0] == 0 ? 1 : 0));
             c->fast_kernel.push_back(sdm_hog_fast_supported(lv) ? 1 : 0);
         }
-        const int F = L * lv.P + 1;
+        const int F = L * lv.P + (lv.fixed_h > 0 ? 0 : 1);
         if (F > c->Fmax) c->Fmax = F;
     }
     c->rhs_tiles = (round_up(c->M, 16) + 127) / 128;

@@ -134,9 +134,9 @@ __device__ void hog_patch_wave(const ImageSetDev& imgs, int im, const float* __r
     WaveLds w = carve(lds_base, S, C, O, D);
 
     // ---- scalar geometry (every lane computes the same values) ---------------------------------
-    const double ied = device_ied(xr, L, eyes);
+    const double ied = lv.fixed_h > 0 ? 0.0 : device_ied(xr, L, eyes);
     // adaptive_vlhog.hpp:123: float * double / 2 -> std::round (half away from zero) -> int
-    const int h = (int)round((double)lv.rel * ied / 2);
+    const int h = lv.fixed_h > 0 ? lv.fixed_h : (int)round((double)lv.rel * ied / 2);
     const int cx = __float2int_rn(xr[landmark]);        // cvRound, adaptive_vlhog.hpp:132
     const int cy = __float2int_rn(xr[landmark + L]);    // :133
     if (idx_row && lane == 0) {
@@ -329,7 +329,7 @@ hog_batch_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float*
     hog_patch_wave<false>(imgs, im, xr, L, i, eyes, lv, smem + (size_t)wave * lds_per_wave,
                           row + (long long)i * lv.P, idx_out ? idx_out + (long long)s * (1 + 2 * L) : nullptr,
                           status, nullptr, nullptr, nullptr);
-    if (i == L - 1 && (threadIdx.x & 63) == 0) row[(long long)L * lv.P] = 1.0f;  // bias, adaptive_vlhog.hpp:182-183
+    if (lv.fixed_h == 0 && i == L - 1 && (threadIdx.x & 63) == 0) row[(long long)L * lv.P] = 1.0f;  // bias, adaptive_vlhog.hpp:182-183
 }
 
 __global__ void __launch_bounds__(64)

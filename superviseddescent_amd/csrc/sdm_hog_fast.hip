@@ -262,8 +262,7 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
     constexpr bool NOMASK = (TC == 5);   // 5 cells and S <= 64: cell <= 12 (checked again by the launcher)
 
     // ---- patch geometry (wave-uniform, moved to scalar registers; adaptive_vlhog.hpp:123,132-133) ------
-    const double ied = ied_of(xr, L, eyes);
-    const int h = uni((int)round((double)lv.rel * ied / 2));
+    const int h = lv.fixed_h > 0 ? lv.fixed_h : uni((int)round((double)lv.rel * ied_of(xr, L, eyes) / 2));
     const int cx = uni(__float2int_rn(xr[landmark]));
     const int cy = uni(__float2int_rn(xr[landmark + L]));
     if (idx_row && lane == 0) {
@@ -595,7 +594,8 @@ hog_fast_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float* 
                                                row + (long long)i * lv.P,
                                                idx_out ? idx_out + (long long)s * (1 + 2 * L) : nullptr, status, prof);
     if (PROF && (threadIdx.x & 63) == 0) atomicAdd(&prof[7], 1ull);
-    if (i == L - 1 && (threadIdx.x & 63) == 0) row[(long long)L * lv.P] = 1.0f;   // bias, adaptive_vlhog.hpp:182-183
+    // bias, adaptive_vlhog.hpp:182-183 (the non-adaptive example transform has none)
+    if (lv.fixed_h == 0 && i == L - 1 && (threadIdx.x & 63) == 0) row[(long long)L * lv.P] = 1.0f;
 }
 
 // count the (gx, gy) pairs for which the un-normalised arg-max disagrees with the reference arithmetic

@@ -17,7 +17,9 @@ struct HogLevelDev {
     int S;            // C*cell, the fixed resized ROI edge  (adaptive_vlhog.hpp:154)
     int D;            // per-cell dimension 3O+4 | 4O        (hog.c:212-219)
     int P;            // C*C*D floats per landmark
-    float rel;        // relative_patch_size
+    float rel;        // relative_patch_size (adaptive transform)
+    int fixed_h;      // > 0: the non-adaptive transform of examples/landmark_detection.cpp:205, patch_width_half =
+                      // num_cells * (cell_size / 2), no bias column; 0: IED-adaptive (adaptive_vlhog.hpp:123) + bias
     float ox[SDM_MAX_ORIENT];  // (float)cos(k*pi/O)
     float oy[SDM_MAX_ORIENT];  // (float)sin(k*pi/O)
     int n_sector;              // floor(O/2): sector boundaries inside the first quadrant

@@ -492,3 +492,43 @@ def test_known_template_mode_matches_oracle(faces):
         sdo.ctx.set_templates(templates[:10])
         sdo.ctx.hog_features(0)
     sdo.ctx.set_templates(None)
+
+
+def test_non_adaptive_example_transform(gpu_ctx, faces):
+    """The HogTransform of examples/landmark_detection.cpp:158-269 (relative_patch_size == 0): patch_width_half =
+    num_cells * (cell_size / 2), ROI not resized, no bias column, NoNormalisation (no eye landmarks)."""
+    images, boxes, gt, x_star, x0 = faces
+    params = [(1, 3, 12, 4, 0.0), (1, 5, 6, 9, 0.0)]
+    oparams = [orc.HoGParam(*p) for p in params]
+    for mode in (SDM_HOG_EXACT_ORDER, SDM_HOG_FAST):
+        gpu_ctx.set_model_geometry(len(IDS), [], [], [HoGParam(*p) for p in params])
+        gpu_ctx.set_hog_mode(mode)
+        gpu_ctx.upload_images(images)
+        gpu_ctx.set_sample_image_index(None)
+        gpu_ctx.set_x(x0)
+        for lvl, op in enumerate(oparams):
+            F = len(IDS) * op.patch_dim                              # no bias column
+            assert gpu_ctx.feature_dim(lvl) == F
+            want, widx = orc.hog_features_batch(images, None, x0, [], [], op, n_threads=os.cpu_count() or 1, want_idx=True)
+            got = gpu_ctx.hog_features(lvl, fetch=True)
+            assert got.shape == (x0.shape[0], F)
+            gidx = gpu_ctx.patch_indices()
+            assert np.array_equal(gidx, widx) and (gidx[:, 0] == op.num_cells * (op.cell_size // 2)).all()
+            check_features(mode, got, want)
+    gpu_ctx.set_hog_mode(SDM_HOG_FAST)
+    with pytest.raises(SdmError):                                    # odd cell size: the unresized ROI has another cell grid
+        gpu_ctx.set_model_geometry(len(IDS), [], [], [HoGParam(1, 3, 11, 4, 0.0)])
+    with pytest.raises(SdmError):                                    # the adaptive transform needs the eyes
+        gpu_ctx.set_model_geometry(len(IDS), [], [], [HoGParam(1, 3, 12, 4, 0.9)])
+    # cascade with NoNormalisation (landmark_detection.cpp:339-352 trains SupervisedDescentOptimiser<LinearRegressor<>>)
+    xs, x0t, idx = synth.make_samples(boxes[:128], gt[:128], IDS, n_perturb=2, seed=25)
+    reg = (0, 1.0, True)
+    cparams = [(1, 3, 12, 4, 0.0), (1, 3, 8, 4, 0.0)]
+    sdo = SupervisedDescentOptimiser([LinearRegressor(Regulariser(*reg)) for _ in cparams])
+    hog = HogTransform(images[:128], [HoGParam(*p) for p in cparams], IDS, [], [], idx)
+    x_gpu = sdo.train(xs, x0t, None, hog)
+    ohog = orc.HogTransform(images[:128], [orc.HoGParam(*p) for p in cparams], [], [], idx, n_threads=os.cpu_count() or 1)
+    osdo = orc.SupervisedDescentOptimiser([orc.LinearRegressor(orc.Regulariser(*reg)) for _ in cparams])
+    x_orc = osdo.train(xs, x0t, None, ohog)
+    assert rel_l2(x_gpu, x_orc) < 1e-4
+    assert rel_l2(x_gpu, xs) < rel_l2(x0t, xs)
