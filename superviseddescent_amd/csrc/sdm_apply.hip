@@ -137,6 +137,116 @@ apply_partial_kernel(const float* __restrict__ feat, long long ldf, int N, int k
     }
 }
 
+// ---- LDS-staged variant for narrow outputs on large batches (RCR-22 detect) -----------------------------------------
+// 64 rows x (NT*16) columns per workgroup, K in slabs of 64: every wave load instruction fetches 256 contiguous bytes
+// of four feature rows (the direct-to-register kernel above fetches 64-byte pieces of sixteen rows), the slab is
+// staged in LDS (row stride 68 floats: 16-byte fragment reads of 16 consecutive lanes fall into 16 different bank
+// groups) and wave w multiplies rows 16w..16w+15.  Same split-K / partial layout / fixed summation order.
+#define AT_BM 64
+#define AT_BK 64
+#define AT_LD (AT_BK + 4)
+#define AT_LPR (AT_BK / 4)            // lanes (float4) per staged row
+#define AT_RPP (256 / AT_LPR)         // rows staged per pass of the 256 threads
+#define AT_APASS (AT_BM / AT_RPP)
+template <int NT>
+__global__ void __launch_bounds__(256)
+apply_tiled_kernel(const float* __restrict__ feat, long long ldf, int N, int kslabs,
+                   const float* __restrict__ Rt, long long ldr, float* __restrict__ partial, int splits)
+{
+    constexpr int BPASS = (NT * 16 + AT_RPP - 1) / AT_RPP;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* As = lds;                                 // [2][AT_BM][AT_LD]
+    float* Bs = lds + 2 * AT_BM * AT_LD;             // [2][NT*16][AT_LD]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int row0 = blockIdx.x * AT_BM;
+    const int split = blockIdx.y;
+    const int s0 = (int)(((long long)kslabs * split) / splits), s1 = (int)(((long long)kslabs * (split + 1)) / splits);
+    // staging: thread t moves float4 number (t % AT_LPR) of rows t / AT_LPR + AT_RPP * p
+    const int lrow = t / AT_LPR, lc4 = (t % AT_LPR) * 4;
+    const float* ap[AT_APASS];
+#pragma unroll
+    for (int p = 0; p < AT_APASS; ++p) {
+        int row = row0 + lrow + AT_RPP * p;
+        if (row > N - 1) row = N - 1;                // clamp: duplicates are never stored
+        ap[p] = feat + (long long)row * ldf + lc4;
+    }
+    const float* bp[BPASS];
+    bool bok[BPASS];
+#pragma unroll
+    for (int c = 0; c < BPASS; ++c) {
+        const int r = lrow + AT_RPP * c;
+        bok[c] = r < NT * 16;
+        bp[c] = Rt + (long long)(bok[c] ? r : 0) * ldr + lc4;
+    }
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // global -> registers two slabs ahead, registers -> LDS one slab ahead
+    f32x4 ra0[AT_APASS], rb0[BPASS], ra1[AT_APASS], rb1[BPASS];
+    auto fetch = [&](int s, f32x4 (&ra)[AT_APASS], f32x4 (&rb)[BPASS]) {
+        if (s >= s1) return;
+        const long long k0 = (long long)s * AT_BK;
+#pragma unroll
+        for (int p = 0; p < AT_APASS; ++p) ra[p] = *(const f32x4*)(ap[p] + k0);
+#pragma unroll
+        for (int c = 0; c < BPASS; ++c) rb[c] = *(const f32x4*)(bp[c] + k0);
+    };
+    auto stage = [&](int buf, const f32x4 (&ra)[AT_APASS], const f32x4 (&rb)[BPASS]) {
+        float* a = As + buf * AT_BM * AT_LD;
+        float* b = Bs + buf * NT * 16 * AT_LD;
+#pragma unroll
+        for (int p = 0; p < AT_APASS; ++p) *(f32x4*)(a + (lrow + AT_RPP * p) * AT_LD + lc4) = ra[p];
+#pragma unroll
+        for (int c = 0; c < BPASS; ++c)
+            if (bok[c]) *(f32x4*)(b + (lrow + AT_RPP * c) * AT_LD + lc4) = rb[c];
+    };
+    auto compute = [&](int buf) {
+        const float* a = As + buf * AT_BM * AT_LD + (16 * wave + li) * AT_LD + 4 * lq;
+        const float* b = Bs + buf * NT * 16 * AT_LD + li * AT_LD + 4 * lq;
+#pragma unroll
+        for (int kg = 0; kg < AT_BK / 16; ++kg) {
+            const f32x4 av = *(const f32x4*)(a + 16 * kg);
+            f32x4 bv[NT];
+#pragma unroll
+            for (int c = 0; c < NT; ++c) bv[c] = *(const f32x4*)(b + 16 * c * AT_LD + 16 * kg);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int c = 0; c < NT; ++c)
+                    acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[c][e], acc[c], 0, 0, 0);
+        }
+    };
+    if (s0 < s1) {
+        fetch(s0, ra0, rb0);
+        fetch(s0 + 1, ra1, rb1);
+        stage(0, ra0, rb0);
+    }
+    __syncthreads();
+    for (int s = s0; s < s1; s += 2) {
+        // slab s is in LDS buffer 0, slab s+1 in register set 1
+        fetch(s + 2, ra0, rb0);
+        compute(0);
+        if (s + 1 < s1) stage(1, ra1, rb1);
+        __syncthreads();
+        if (s + 1 >= s1) break;
+        fetch(s + 3, ra1, rb1);
+        compute(1);
+        if (s + 2 < s1) stage(0, ra0, rb0);
+        __syncthreads();
+    }
+    // C/D layout of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + e
+    const int Mp = NT * 16;
+#pragma unroll
+    for (int c = 0; c < NT; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = row0 + 16 * wave + lq * 4 + e;
+            if (row < N) partial[((long long)split * N + row) * Mp + 16 * c + li] = acc[c][e];
+        }
+}
+
 __global__ void apply_reduce_kernel(const float* __restrict__ partial, int splits, int N, int Mp, int M,
                                     const float* __restrict__ x_in, float* __restrict__ x_out, int L,
                                     EyeIdxDev eyes)
@@ -271,8 +381,17 @@ void sdm_launch_landmark_errors(const float* x, const float* xstar, int N, int L
     hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(64), 0, stream, work, SDM_SUM_PARTS, total, work + SDM_SUM_PARTS);
 }
 
-int sdm_apply_splits(int N, int F)
+// the LDS-staged kernel serves narrow outputs (<= 3 column tiles) on batches that fill the chip
+static bool apply_use_tiled(int N, int M) { return (M + 15) / 16 <= 3 && N >= 2048; }
+
+int sdm_apply_splits(int N, int F, int M)
 {
+    if (apply_use_tiled(N, M)) {
+        const int row_blocks = (N + AT_BM - 1) / AT_BM, kslabs = (F + AT_BK - 1) / AT_BK;
+        int splits = (512 + row_blocks - 1) / row_blocks;     // two 61 KB workgroups per CU
+        if (splits > kslabs / 4) splits = kslabs / 4;
+        return splits < 1 ? 1 : (splits > 64 ? 64 : splits);
+    }
     // enough workgroups to cover 256 CUs a few times over, but at least 4 k-groups per wave
     const int row_blocks = (N + 31) / 32;
     int splits = (1024 + row_blocks - 1) / row_blocks;
@@ -301,6 +420,22 @@ void sdm_launch_apply(const float* feat, long long ldf, int N, int F, const floa
     if (N <= 0) return;
     const int kgroups = (F + 15) / 16;   // feat/Rt are zero padded to a multiple of 16 columns
     const int NT = (M + 15) / 16;
+    if (apply_use_tiled(N, M)) {
+        // (feat / Rt rows are zero padded up to ldf >= round_up(F, 128): whole 64-wide slabs are readable)
+        const int kslabs = (F + AT_BK - 1) / AT_BK;
+        const dim3 grid((N + AT_BM - 1) / AT_BM, splits);
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)apply_tiled_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)apply_tiled_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)apply_tiled_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_done = true;
+        }
+        const size_t lds = (size_t)2 * (AT_BM + NT * 16) * AT_LD * sizeof(float);
+        if (NT == 1) hipLaunchKernelGGL(apply_tiled_kernel<1>, grid, dim3(256), lds, stream, feat, ldf, N, kslabs, Rt, ldr, partial, splits);
+        else if (NT == 2) hipLaunchKernelGGL(apply_tiled_kernel<2>, grid, dim3(256), lds, stream, feat, ldf, N, kslabs, Rt, ldr, partial, splits);
+        else hipLaunchKernelGGL(apply_tiled_kernel<3>, grid, dim3(256), lds, stream, feat, ldf, N, kslabs, Rt, ldr, partial, splits);
+    } else
     switch (NT) {
         case 1: launch_partial<2, 1>(feat, ldf, N, kgroups, Rt, ldr, partial, splits, stream); break;
         case 2: launch_partial<2, 2>(feat, ldf, N, kgroups, Rt, ldr, partial, splits, stream); break;

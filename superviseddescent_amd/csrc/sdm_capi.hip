@@ -239,7 +239,7 @@ int do_apply(sdm_ctx* c, int level)
     if (c->feat_level != level) return fail(SDM_ERR_INVALID, "sdm_apply: features of this level not extracted");
     if (!c->have_R[level]) return fail(SDM_ERR_INVALID, "sdm_apply: no regressor set for this level");
     const int F = level_F(c, level);
-    const int splits = sdm_apply_splits(c->N, F);
+    const int splits = sdm_apply_splits(c->N, F, c->M);
     int rc = c->partial.ensure((size_t)splits * c->N * Mp_of(c->M));
     if (rc) return rc;
     {

@@ -82,7 +82,7 @@ void sdm_launch_gradient_table(const HogLevelDev& lv, float* g_out, int* bin_out
 
 // ---- regressor apply: u = feat[N x F] * R[F x M]; x_out = x - u * IED(x) ----------------------
 // Rt is the regressor transposed and padded: [Mp][ldr] f32 (row j = column j of R), Mp = 16*ceil(M/16)
-int sdm_apply_splits(int N, int F);
+int sdm_apply_splits(int N, int F, int M);
 void sdm_launch_apply(const float* feat, long long ldf, int N, int F, const float* Rt, long long ldr,
                       int M, const float* x_in, float* x_out, int L, const EyeIdxDev& eyes,
                       float* partial, int splits, hipStream_t stream);

@@ -188,12 +188,19 @@ def test_empty_patch_reports_error(gpu_ctx, faces):
 
 
 # ------------------------------------------------------------------------------------------ apply
-@pytest.mark.parametrize("n", [1, 33, 192])
+@pytest.mark.parametrize("n", [1, 33, 192, 2100])
 def test_apply_update(gpu_ctx, faces, n):
+    """n <= 192: the direct-to-register GEMM; n = 2100 (rows of the 192 faces repeated with a pixel offset, ragged last
+    row block): the LDS-staged GEMM that serves narrow outputs on large batches."""
     images, _, _, _, x0 = faces
     gpu_ctx.set_model_geometry(len(IDS), RE, LE, SHIPPED)
     gpu_ctx.upload_images(images)
-    gpu_ctx.set_sample_image_index(None)
+    if n > x0.shape[0]:
+        idx = (np.arange(n) % x0.shape[0]).astype(np.int32)
+        x0 = (x0[idx] + (np.arange(n)[:, None] // x0.shape[0]).astype(np.float32) * 0.37).astype(np.float32)
+        gpu_ctx.set_sample_image_index(idx)
+    else:
+        gpu_ctx.set_sample_image_index(None)
     gpu_ctx.set_x(x0[:n])
     feat = gpu_ctx.hog_features(0, fetch=True)
     rng = np.random.default_rng(n)
