@@ -248,7 +248,7 @@ def main():
             "launches": hog_n,
         },
         "apply_gemm": {
-            "kernel": "apply_partial_kernel+apply_reduce_kernel",
+            "kernel": "apply_tiled_kernel+apply_reduce_kernel",
             "bound": "mfma",
             "achieved": apply_tf,
             "peak": MFMA_F32_PEAK_TF,
