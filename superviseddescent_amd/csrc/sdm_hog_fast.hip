@@ -176,27 +176,40 @@ __host__ __device__ inline size_t al16(size_t v) { return (v + 15) & ~(size_t)15
 // neighbours of a contribution sit in the immediate offset of the LDS instruction)
 #define HF_COPIES 8
 #define HF_TWO52_BITS 0x4330000000000000ull
-__host__ __device__ inline int copies_R(int) { return HF_COPIES; }
+// PAIR mode (two patches of one sample side by side in the two 32-lane halves of a wave, S <= 32) keeps 4 copies per
+// half: half as many lanes map to a cell column
+#define HF_COPIES_PAIR 4
+__host__ __device__ inline int copies_R(bool pair) { return pair ? HF_COPIES_PAIR : HF_COPIES; }
 
-__host__ __device__ inline size_t fast_lds_bytes(int cell, int C, int O, int D)
+__host__ __device__ inline size_t fast_region_a(int C, int O)
 {
     const int CC = C * C, PW = C + 2;
     const size_t a_fixed = al16((size_t)2 * O * CC * 8), a_exact = al16((size_t)2 * O * PW * PW * 4);
-    const size_t A = a_fixed > a_exact ? a_fixed : a_exact;
-    const size_t b_rows = al16((size_t)2 * 2 * O * PW * copies_R(cell) * 8);
-    const size_t b_norm = al16((size_t)2 * O * CC * 4) + al16((size_t)CC * 4) + al16((size_t)4 * CC * 8) +
-                          al16((size_t)O * CC * 4 * 8) + al16((size_t)D * CC * 4);
-    return A + (b_rows > b_norm ? b_rows : b_norm);
+    return a_fixed > a_exact ? a_fixed : a_exact;
+}
+__host__ __device__ inline size_t fast_copies_bytes(int C, int O, bool pair)
+{
+    return al16((size_t)2 * 2 * O * (C + 2) * copies_R(pair) * 8);
 }
 
-__device__ inline FastLds fast_carve(unsigned char* base, int C, int O, int D)
+// region A (per patch: the finished histogram) x patches, then region B = max(accumulator copies x patches,
+// normalisation scratch of ONE patch: the patches of a pair are normalised one after the other)
+__host__ __device__ inline size_t fast_lds_bytes(int cell, int C, int O, int D, bool pair = false)
 {
-    const int CC = C * C, PW = C + 2;
-    const size_t a_fixed = al16((size_t)2 * O * CC * 8), a_exact = al16((size_t)2 * O * PW * PW * 4);
-    const size_t A = a_fixed > a_exact ? a_fixed : a_exact;
+    (void)cell;
+    const int CC = C * C, np = pair ? 2 : 1;
+    const size_t b_rows = np * fast_copies_bytes(C, O, pair);
+    const size_t b_norm = al16((size_t)2 * O * CC * 4) + al16((size_t)CC * 4) + al16((size_t)4 * CC * 8) +
+                          al16((size_t)O * CC * 4 * 8) + al16((size_t)D * CC * 4);
+    return np * fast_region_a(C, O) + (b_rows > b_norm ? b_rows : b_norm);
+}
+
+__device__ inline FastLds fast_carve(unsigned char* base, int C, int O, int D, bool pair = false)
+{
+    const int CC = C * C;
     FastLds w;
     w.hfin = (void*)base;
-    size_t o = A;
+    size_t o = (pair ? 2 : 1) * fast_region_a(C, O);
     w.copies = (u64*)(base + o);
     w.histv = (float*)(base + o); o += al16((size_t)2 * O * CC * 4);
     w.nrm = (float*)(base + o); o += al16((size_t)CC * 4);
@@ -236,10 +249,14 @@ __device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ inline float lane_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 
 // TO / TC: compile-time orientation count / cell count (0 = take the run-time value from lv)
-template <int ACC, int FASTBIN, int TO, int TC, bool PROF = false>
+// PAIR: landmarks `landmark` and `landmark + 1` of the same sample side by side in lanes 0-31 / 32-63 (S <= 32).  They
+// share the image, the IED, hence h, the scale and every per-coordinate table; only the patch centre differs, which
+// turns the row addresses and the vertical border masks into per-lane values.  `second_valid` is false for the last,
+// single landmark of an odd count (its half then carries zero weights and stores nothing).
+template <int ACC, int FASTBIN, int TO, int TC, bool PAIR, bool PROF = false>
 __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* __restrict__ xr, int L, int landmark,
-                               const EyeIdxDev& eyes, const HogLevelDev& lv, unsigned char* lds_base,
-                               float* __restrict__ out_desc, int* idx_row, int* status,
+                               bool second_valid, const EyeIdxDev& eyes, const HogLevelDev& lv, unsigned char* lds_base,
+                               float* __restrict__ out_row, int* idx_row, int* status,
                                unsigned long long* prof = nullptr)
 {
     long long tprev = PROF ? clock64() : 0;
@@ -255,21 +272,26 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
     const int O = TO ? TO : lv.O;
     const int C = TC ? TC : lv.C;
     const int CC = C * C, PW = C + 2, PWW = PW * PW;
-    FastLds w = fast_carve(lds_base, C, O, D);
-    float* histf = (float*)w.hfin;     // exact order: padded f32 histogram
-    u64* hfin = (u64*)w.hfin;          // fixed point: finished histogram [2O][CC]
-    constexpr int R = HF_COPIES;
+    constexpr int NP = PAIR ? 2 : 1;
+    const int half = PAIR ? (lane >> 5) : 0, col = PAIR ? (lane & 31) : lane;
+    FastLds w = fast_carve(lds_base, C, O, D, PAIR);
+    const size_t a_bytes = fast_region_a(C, O);                 // per patch: finished histogram
+    const size_t copies_u64 = fast_copies_bytes(C, O, PAIR) / 8;   // per patch: accumulator copies
+    float* histf = (float*)((unsigned char*)w.hfin + (size_t)half * a_bytes);   // exact order: this lane's padded f32 histogram
+    constexpr int R = PAIR ? HF_COPIES_PAIR : HF_COPIES;
     constexpr bool NOMASK = (TC == 5);   // 5 cells and S <= 64: cell <= 12 (checked again by the launcher)
 
     // ---- patch geometry (wave-uniform, moved to scalar registers; adaptive_vlhog.hpp:123,132-133) ------
     const int h = lv.fixed_h > 0 ? lv.fixed_h : uni((int)round((double)lv.rel * ied_of(xr, L, eyes) / 2));
-    const int cx = uni(__float2int_rn(xr[landmark]));
-    const int cy = uni(__float2int_rn(xr[landmark + L]));
+    const int lmB = (PAIR && second_valid) ? landmark + 1 : landmark;
+    const int cxA = uni(__float2int_rn(xr[landmark])), cyA = uni(__float2int_rn(xr[landmark + L]));
+    const int cxB = uni(__float2int_rn(xr[lmB])), cyB = uni(__float2int_rn(xr[lmB + L]));
     if (idx_row && lane == 0) {
         if (landmark == 0) idx_row[0] = h;
-        idx_row[1 + landmark] = cx;
-        idx_row[1 + L + landmark] = cy;
+        idx_row[1 + landmark] = cxA; idx_row[1 + L + landmark] = cyA;
+        if (PAIR && second_valid) { idx_row[1 + lmB] = cxB; idx_row[1 + L + lmB] = cyB; }
     }
+    const int cx = half ? cxB : cxA, cy = half ? cyB : cyA;     // (per lane in PAIR mode, scalar otherwise)
     const bool empty = h <= 0;
     if (empty && lane == 0) atomicOr(status, SDM_DEV_ERR_EMPTY_PATCH);
     const int sw = empty ? 1 : 2 * h;
@@ -283,7 +305,7 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
 
     // ---- per-coordinate values: lane d computes coordinate d once.  The COLUMN copy stays in this lane's
     //      registers; the ROW copy of coordinate yy is fetched from lane yy with v_readlane (no LDS) -----------
-    const int d = lane < S ? lane : S - 1;
+    const int d = col < S ? col : S - 1;
     int bxc; float wx1, wx2;          // HOG cell index / bilinear weights of coordinate d   (hog.c:697-704)
     int row_src, row_beta;            // vertical resize taps of coordinate d (packed)
     int px0, px1, a0, a1;             // horizontal resize taps of column d (image columns, masked weights)
@@ -318,7 +340,7 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
     }
     const float row_w1 = wx1, row_w2 = wx2;   // weights of coordinate d when it is used as a ROW
     const int row_cell = bxc;
-    const bool col_active = (lane >= 1) && (lane < S - 1);
+    const bool col_active = (col >= 1) && (col < S - 1) && (!PAIR || half == 0 || second_valid);
     // padded histogram column of this lane (lanes outside the ROI contribute exact zeros to cell 0)
     const int hcol = col_active ? bxc + 1 : 0;
     if (!col_active) { wx1 = 0.0f; wx2 = 0.0f; }
@@ -327,29 +349,33 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
     if (ACC == ACC_FIXED64) {
         // (16-byte stores: both counts are even and both regions 16-byte aligned)
         const u64x2 z2 = {0ull, 0ull};
-        for (int i = lane; i < 2 * O * PW * R; i += 64) ((u64x2*)w.copies)[i] = z2;
+        for (int i = lane; i < NP * 2 * O * PW * R; i += 64) ((u64x2*)w.copies)[i] = z2;
         const u64x2 b2 = {HF_TWO52_BITS, HF_TWO52_BITS};   // = 0.0 in the biased form the fold stores (see flush_band)
-        for (int i = lane; i < O * CC; i += 64) ((u64x2*)hfin)[i] = b2;
+        for (int hp = 0; hp < NP; ++hp)
+            for (int i = lane; i < O * CC; i += 64) ((u64x2*)((unsigned char*)w.hfin + (size_t)hp * a_bytes))[i] = b2;
     } else {
-        for (int i = lane; i < 2 * O * PWW; i += 64) histf[i] = 0.0f;
+        for (int hp = 0; hp < NP; ++hp)
+            for (int i = lane; i < 2 * O * PWW; i += 64) ((float*)((unsigned char*)w.hfin + (size_t)hp * a_bytes))[i] = 0.0f;
     }
     wave_sync();
     mark(1);   // histogram clear + barrier
     // fixed point: the two cell-row bands (by, by+1) a pixel row feeds are accumulated in private copies (no two
     // lanes of one instruction share an address); a band is folded into hfin when the rows have moved past it
-    const int lane_off = hcol * R + lane % R;
+    const int lane_off = hcol * R + col % R + half * (int)copies_u64;   // (+ this half's accumulator region)
     int cur_by = -2;
     auto flush_band = [&](int band) {
         const int slot = band & 1;
-        for (int t = lane; t < 2 * O * PW; t += 64) {
-            u64* cp = w.copies + (size_t)(slot * 2 * O * PW + t) * R;
-            u64 sum = 0;
-            // all 16-byte reads in flight, then the clears (integer sum: any order)
-            sum = fold_copies<HF_COPIES / 2>((u64x2*)cp) & 0xfffffffffffffull;   // (see fx: bits >= 52 are not data)
-            const int kbin = t / PW, hc = t - kbin * PW;
-            // stored as the bit pattern of the double 2^52 + sum (sum < 2^52), which makes the final u64 -> f32 conversion
-            // one f64 subtraction and one (single) rounding
-            if (band >= 0 && band < C && hc >= 1 && hc <= C) hfin[kbin * CC + band * C + (hc - 1)] = sum | HF_TWO52_BITS;
+        for (int hp = 0; hp < NP; ++hp) {
+            u64* hfin = (u64*)((unsigned char*)w.hfin + (size_t)hp * a_bytes);
+            for (int t = lane; t < 2 * O * PW; t += 64) {
+                u64* cp = w.copies + (size_t)hp * copies_u64 + (size_t)(slot * 2 * O * PW + t) * R;
+                // all 16-byte reads in flight, then the clears (integer sum: any order)
+                const u64 sum = fold_copies<R / 2>((u64x2*)cp) & 0xfffffffffffffull;   // (see fx: bits >= 52 are not data)
+                const int kbin = t / PW, hc = t - kbin * PW;
+                // stored as the bit pattern of the double 2^52 + sum (sum < 2^52), which makes the final u64 -> f32
+                // conversion one f64 subtraction and one (single) rounding
+                if (band >= 0 && band < C && hc >= 1 && hc <= C) hfin[kbin * CC + band * C + (hc - 1)] = sum | HF_TWO52_BITS;
+            }
         }
     };
 
@@ -368,11 +394,19 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
         if (py1 < 0 || py1 >= ih) beta &= 0x0000ffff;
         py0 = py0 < 0 ? 0 : (py0 > ih - 1 ? ih - 1 : py0);
         py1 = py1 < 0 ? 0 : (py1 > ih - 1 ? ih - 1 : py1);
-        const int o0 = py0 * istride, o1 = py1 * istride;
-        q00 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, px0, o0, 0);
-        q01 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, px1, o0, 0);
-        q10 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, px0, o1, 0);
-        q11 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, px1, o1, 0);
+        if (PAIR) {   // y0 differs between the halves: row offsets and masks are per lane (24-bit multiplies: full rate)
+            const int o0 = __mul24(py0, istride), o1 = __mul24(py1, istride);
+            q00 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, px0 + o0, 0, 0);
+            q01 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, px1 + o0, 0, 0);
+            q10 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, px0 + o1, 0, 0);
+            q11 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, px1 + o1, 0, 0);
+        } else {
+            const int o0 = py0 * istride, o1 = py1 * istride;
+            q00 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, px0, o0, 0);
+            q01 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, px1, o0, 0);
+            q10 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, px0, o1, 0);
+            q11 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, px1, o1, 0);
+        }
         bb = beta;
     };
     auto finish_row = [&](int q00, int q01, int q10, int q11, int beta) -> float {
@@ -485,92 +519,100 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
     wave_sync();
     mark(3);   // barrier after the row loop
 
-    // ---- histogram -> f32 [2O][CC] (one conversion per accumulator; region B, dead since the last flush,
-    //      becomes the scratch of the normalisation phase; region A is only read) ----------------------------
-    for (int t = lane; t < 2 * O * CC; t += 64) {
-        const int k = t / CC, c = t - k * CC;
-        const int cyy = c / C, cxx = c - cyy * C;
-        // fixed point: exact sum, ONE rounding (u64 -> f32), then the exact scale 2^-36
-        w.histv[t] = (ACC == ACC_FIXED64)
-                         ? (float)(__builtin_bit_cast(double, hfin[t]) - 4503599627370496.0) * 1.4551915228366852e-11f
-                         : histf[k * PWW + (cyy + 1) * PW + (cxx + 1)];
-    }
-    wave_sync();
-
-    // ---- cell norms (hog.c:875-890) ---------------------------------------------------------------------------
-    for (int c = lane; c < CC; c += 64) {
-        float n = 0.0f;
-        for (int k = 0; k < O; ++k) {
-            const float hs = w.histv[c + k * CC] + w.histv[c + (k + O) * CC];
-            n += hs * hs;
-        }
-        w.nrm[c] = n;
-    }
-    wave_sync();
-    // ---- block factors (hog.c:930-981).  The four factors of a cell are those of the 2x2-cell blocks around its four
-    //      corners, clamped at the border; a block is shared by up to four cells, so the (C+1)^2 distinct ones are
-    //      computed once: block (bx, by) sums cells (xa,ya) (xb,ya) (xa,yb) (xb,yb), left to right, + 1e-4 last, with
-    //      xa = max(bx-1, 0), xb = min(bx, C-1) -- the same operands in the same order as the reference's n1..n9 ----
-    const int CB = C + 1;
-    for (int t = lane; t < CB * CB; t += 64) {
-        const int byb = t / CB, bxb = t - byb * CB;
-        const int xa = bxb - 1 > 0 ? bxb - 1 : 0, xb = bxb < C - 1 ? bxb : C - 1;
-        const int ya = byb - 1 > 0 ? byb - 1 : 0, yb = byb < C - 1 ? byb : C - 1;
-        const double na = w.nrm[xa + ya * C], nb = w.nrm[xb + ya * C];
-        const double nc = w.nrm[xa + yb * C], nd = w.nrm[xb + yb * C];
-        w.fac[t] = 1.0 / sqrt(na + nb + nc + nd + 1e-4);
-    }
-    wave_sync();
-    // ---- normalise, clamp, emit the 3 (UoCTTI) or 4 (Dalal-Triggs) outputs of every (cell, orientation) ------
-    //      desc is written in the Matlab order of the feature row (adaptive_vlhog.hpp:166-175): [dim][x][y]
-    for (int t = lane; t < O * CC; t += 64) {
-        const int k = t / CC, c = t - k * CC;
-        const int y = c / C, x = c - y * C, ct = x * C + y;
-        const double ha = w.histv[c + k * CC], hb = w.histv[c + (k + O) * CC];
-        // j=0: n1+n2+n4+n5  j=1: n2+n3+n5+n6  j=2: n4+n5+n7+n8  j=3: n5+n6+n8+n9
-        const double f1 = w.fac[x + y * CB], f2 = w.fac[x + 1 + y * CB];
-        const double f3 = w.fac[x + (y + 1) * CB], f4 = w.fac[x + 1 + (y + 1) * CB];
-        double ha1 = f1 * ha, ha2 = f2 * ha, ha3 = f3 * ha, ha4 = f4 * ha;
-        double hb1 = f1 * hb, hb2 = f2 * hb, hb3 = f3 * hb, hb4 = f4 * hb;
-        double hc1 = ha1 + hb1, hc2 = ha2 + hb2, hc3 = ha3 + hb3, hc4 = ha4 + hb4;
-#define CL02(v) __builtin_fmin(0.2, (v))          /* VL_MIN(0.2, v): the values are finite and non-negative */
-        ha1 = CL02(ha1); ha2 = CL02(ha2); ha3 = CL02(ha3); ha4 = CL02(ha4);
-        hb1 = CL02(hb1); hb2 = CL02(hb2); hb3 = CL02(hb3); hb4 = CL02(hb4);
-        hc1 = CL02(hc1); hc2 = CL02(hc2); hc3 = CL02(hc3); hc4 = CL02(hc4);
-#undef CL02
-        if (lv.variant == 1) {
-            w.desc[ct + k * CC] = (float)(0.5 * (ha1 + ha2 + ha3 + ha4));
-            w.desc[ct + (k + O) * CC] = (float)(0.5 * (hb1 + hb2 + hb3 + hb4));
-            w.desc[ct + (k + 2 * O) * CC] = (float)(0.5 * (hc1 + hc2 + hc3 + hc4));
-            double* q = w.hcc + (size_t)(k * CC + c) * 4;
-            q[0] = hc1; q[1] = hc2; q[2] = hc3; q[3] = hc4;
-        } else {
-            w.desc[ct + k * CC] = (float)hc1;
-            w.desc[ct + (k + O) * CC] = (float)hc2;
-            w.desc[ct + (k + 2 * O) * CC] = (float)hc3;
-            w.desc[ct + (k + 3 * O) * CC] = (float)hc4;
-        }
-    }
-    wave_sync();
-    // ---- texture features: t_j = sum over k (in order) of the clamped hc_j (hog.c:1020-1023, 1047-1052) ------
-    if (lv.variant == 1) {
-        const float tex = 1.0f / sqrtf(18.0f);
-        for (int t = lane; t < 4 * CC; t += 64) {
-            const int j = t / CC, c = t - j * CC;
-            const int y = c / C, x = c - y * C, ct = x * C + y;
-            double acc = 0.0;
-            for (int k = 0; k < O; ++k) acc += w.hcc[(size_t)(k * CC + c) * 4 + j];
-            w.desc[ct + (3 * O + j) * CC] = (float)(tex * acc);
+    // ---- per patch (one after the other in PAIR mode: they share the normalisation scratch) ------------------------
+    for (int hp = 0; hp < NP; ++hp) {
+        if (hp == 1 && !second_valid) break;
+        const u64* hfin_p = (const u64*)((unsigned char*)w.hfin + (size_t)hp * a_bytes);
+        const float* histf_p = (const float*)((unsigned char*)w.hfin + (size_t)hp * a_bytes);
+        float* out_desc = out_row + (long long)(landmark + hp) * lv.P;
+        // ---- histogram -> f32 [2O][CC] (one conversion per accumulator; region B, dead since the last flush,
+        //      becomes the scratch of the normalisation phase; region A is only read) ----------------------------
+        for (int t = lane; t < 2 * O * CC; t += 64) {
+            const int k = t / CC, c = t - k * CC;
+            const int cyy = c / C, cxx = c - cyy * C;
+            // fixed point: exact sum, ONE rounding (u64 -> f32), then the exact scale 2^-36
+            w.histv[t] = (ACC == ACC_FIXED64)
+                             ? (float)(__builtin_bit_cast(double, hfin_p[t]) - 4503599627370496.0) * 1.4551915228366852e-11f
+                             : histf_p[k * PWW + (cyy + 1) * PW + (cxx + 1)];
         }
         wave_sync();
+
+        // ---- cell norms (hog.c:875-890) ---------------------------------------------------------------------------
+        for (int c = lane; c < CC; c += 64) {
+            float n = 0.0f;
+            for (int k = 0; k < O; ++k) {
+                const float hs = w.histv[c + k * CC] + w.histv[c + (k + O) * CC];
+                n += hs * hs;
+            }
+            w.nrm[c] = n;
+        }
+        wave_sync();
+        // ---- block factors (hog.c:930-981).  The four factors of a cell are those of the 2x2-cell blocks around its four
+        //      corners, clamped at the border; a block is shared by up to four cells, so the (C+1)^2 distinct ones are
+        //      computed once: block (bx, by) sums cells (xa,ya) (xb,ya) (xa,yb) (xb,yb), left to right, + 1e-4 last, with
+        //      xa = max(bx-1, 0), xb = min(bx, C-1) -- the same operands in the same order as the reference's n1..n9 ----
+        const int CB = C + 1;
+        for (int t = lane; t < CB * CB; t += 64) {
+            const int byb = t / CB, bxb = t - byb * CB;
+            const int xa = bxb - 1 > 0 ? bxb - 1 : 0, xb = bxb < C - 1 ? bxb : C - 1;
+            const int ya = byb - 1 > 0 ? byb - 1 : 0, yb = byb < C - 1 ? byb : C - 1;
+            const double na = w.nrm[xa + ya * C], nb = w.nrm[xb + ya * C];
+            const double nc = w.nrm[xa + yb * C], nd = w.nrm[xb + yb * C];
+            w.fac[t] = 1.0 / sqrt(na + nb + nc + nd + 1e-4);
+        }
+        wave_sync();
+        // ---- normalise, clamp, emit the 3 (UoCTTI) or 4 (Dalal-Triggs) outputs of every (cell, orientation) ------
+        //      desc is written in the Matlab order of the feature row (adaptive_vlhog.hpp:166-175): [dim][x][y]
+        for (int t = lane; t < O * CC; t += 64) {
+            const int k = t / CC, c = t - k * CC;
+            const int y = c / C, x = c - y * C, ct = x * C + y;
+            const double ha = w.histv[c + k * CC], hb = w.histv[c + (k + O) * CC];
+            // j=0: n1+n2+n4+n5  j=1: n2+n3+n5+n6  j=2: n4+n5+n7+n8  j=3: n5+n6+n8+n9
+            const double f1 = w.fac[x + y * CB], f2 = w.fac[x + 1 + y * CB];
+            const double f3 = w.fac[x + (y + 1) * CB], f4 = w.fac[x + 1 + (y + 1) * CB];
+            double ha1 = f1 * ha, ha2 = f2 * ha, ha3 = f3 * ha, ha4 = f4 * ha;
+            double hb1 = f1 * hb, hb2 = f2 * hb, hb3 = f3 * hb, hb4 = f4 * hb;
+            double hc1 = ha1 + hb1, hc2 = ha2 + hb2, hc3 = ha3 + hb3, hc4 = ha4 + hb4;
+    #define CL02(v) __builtin_fmin(0.2, (v))          /* VL_MIN(0.2, v): the values are finite and non-negative */
+            ha1 = CL02(ha1); ha2 = CL02(ha2); ha3 = CL02(ha3); ha4 = CL02(ha4);
+            hb1 = CL02(hb1); hb2 = CL02(hb2); hb3 = CL02(hb3); hb4 = CL02(hb4);
+            hc1 = CL02(hc1); hc2 = CL02(hc2); hc3 = CL02(hc3); hc4 = CL02(hc4);
+    #undef CL02
+            if (lv.variant == 1) {
+                w.desc[ct + k * CC] = (float)(0.5 * (ha1 + ha2 + ha3 + ha4));
+                w.desc[ct + (k + O) * CC] = (float)(0.5 * (hb1 + hb2 + hb3 + hb4));
+                w.desc[ct + (k + 2 * O) * CC] = (float)(0.5 * (hc1 + hc2 + hc3 + hc4));
+                double* q = w.hcc + (size_t)(k * CC + c) * 4;
+                q[0] = hc1; q[1] = hc2; q[2] = hc3; q[3] = hc4;
+            } else {
+                w.desc[ct + k * CC] = (float)hc1;
+                w.desc[ct + (k + O) * CC] = (float)hc2;
+                w.desc[ct + (k + 2 * O) * CC] = (float)hc3;
+                w.desc[ct + (k + 3 * O) * CC] = (float)hc4;
+            }
+        }
+        wave_sync();
+        // ---- texture features: t_j = sum over k (in order) of the clamped hc_j (hog.c:1020-1023, 1047-1052) ------
+        if (lv.variant == 1) {
+            const float tex = 1.0f / sqrtf(18.0f);
+            for (int t = lane; t < 4 * CC; t += 64) {
+                const int j = t / CC, c = t - j * CC;
+                const int y = c / C, x = c - y * C, ct = x * C + y;
+                double acc = 0.0;
+                for (int k = 0; k < O; ++k) acc += w.hcc[(size_t)(k * CC + c) * 4 + j];
+                w.desc[ct + (3 * O + j) * CC] = (float)(tex * acc);
+            }
+            wave_sync();
+        }
+        mark(4);   // normalisation / extraction
+        // ---- the feature row segment of this landmark: desc is already in its order -------------------------------
+        for (int o = lane; o < lv.P; o += 64) out_desc[o] = w.desc[o];
+        wave_sync();   // the next patch reuses the scratch
     }
-    mark(4);   // normalisation / extraction
-    // ---- the feature row segment of this landmark: desc is already in its order -------------------------------
-    for (int o = lane; o < lv.P; o += 64) out_desc[o] = w.desc[o];
     mark(5);   // output stores
 }
 
-template <int ACC, int FASTBIN, int TO, int TC, bool PROF = false>
+template <int ACC, int FASTBIN, int TO, int TC, bool PAIR, bool PROF = false>
 __global__ void __launch_bounds__(HF_WAVES * 64)
 hog_fast_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float* __restrict__ x, int N, int L,
                 EyeIdxDev eyes, HogLevelDev lv, float* __restrict__ feat, long long ldf,
@@ -583,19 +625,20 @@ hog_fast_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float* 
     const unsigned nb = gridDim.x, b = blockIdx.x;
     const unsigned q = nb / 8, r = nb % 8, xcd = b % 8;
     const unsigned blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
-    long long p = (long long)blk * HF_WAVES + wave;
-    const long long total = (long long)N * L;
-    if (p >= total) return;          // (no workgroup barriers anywhere: tail waves simply leave)
-    const int s = (int)(p / L), i = (int)(p - (long long)s * L);
+    const long long p = (long long)blk * HF_WAVES + wave;
+    const int Lw = PAIR ? (L + 1) / 2 : L;      // wave slots per sample: one per landmark, or one per landmark pair
+    if (p >= (long long)N * Lw) return;          // (no workgroup barriers anywhere: tail waves simply leave)
+    const int s = (int)(p / Lw), iw = (int)(p - (long long)s * Lw);
+    const int i = PAIR ? 2 * iw : iw;
+    const bool second_valid = PAIR && (i + 1 < L);
     const int im = img_idx ? img_idx[s] : s;
     const float* xr = x + (long long)s * 2 * L;
     float* row = feat + (long long)s * ldf;
-    hog_patch_fast<ACC, FASTBIN, TO, TC, PROF>(imgs, im, xr, L, i, eyes, lv, smem + (size_t)wave * lds_per_wave,
-                                               row + (long long)i * lv.P,
-                                               idx_out ? idx_out + (long long)s * (1 + 2 * L) : nullptr, status, prof);
+    hog_patch_fast<ACC, FASTBIN, TO, TC, PAIR, PROF>(imgs, im, xr, L, i, second_valid, eyes, lv, smem + (size_t)wave * lds_per_wave,
+                                                     row, idx_out ? idx_out + (long long)s * (1 + 2 * L) : nullptr, status, prof);
     if (PROF && (threadIdx.x & 63) == 0) atomicAdd(&prof[7], 1ull);
     // bias, adaptive_vlhog.hpp:182-183 (the non-adaptive example transform has none)
-    if (lv.fixed_h == 0 && i == L - 1 && (threadIdx.x & 63) == 0) row[(long long)L * lv.P] = 1.0f;
+    if (lv.fixed_h == 0 && iw == Lw - 1 && (threadIdx.x & 63) == 0) row[(long long)L * lv.P] = 1.0f;
 }
 
 // count the (gx, gy) pairs for which the un-normalised arg-max disagrees with the reference arithmetic
@@ -627,6 +670,12 @@ bool sdm_hog_fast_supported(const HogLevelDev& lv)
     return lv.S >= 4 && lv.S <= 64 && fast_lds_bytes(lv.cell, lv.C, lv.O, lv.D) * HF_WAVES <= 160 * 1024;
 }
 
+// two patches per wave: the ROI fits a half wave and three workgroups still share a CU
+static bool hog_fast_pair(const HogLevelDev& lv, int fast_bins)
+{
+    return lv.S <= 32 && fast_bins == 2 && fast_lds_bytes(lv.cell, lv.C, lv.O, lv.D, true) * HF_WAVES * 3 <= 160 * 1024;
+}
+
 void sdm_launch_verify_fast_bins(const HogLevelDev& lv, int* mismatches_dev, hipStream_t stream)
 {
     const int n = 511 * 511;
@@ -638,24 +687,27 @@ static void launch_fast_oc(const ImageSetDev& imgs, const int* img_idx, const fl
                            const EyeIdxDev& eyes, const HogLevelDev& lv, float* feat, long long ldf, int* idx_out,
                            int* status, int exact_order, int fast_bins, hipStream_t stream)
 {
-    const long long total = (long long)N * L;
-    const size_t per = fast_lds_bytes(lv.cell, lv.C, lv.O, lv.D);
+    const bool pair = hog_fast_pair(lv, fast_bins);
+    const long long total = (long long)N * (pair ? (L + 1) / 2 : L);
+    const size_t per = fast_lds_bytes(lv.cell, lv.C, lv.O, lv.D, pair);
     const unsigned grid = (unsigned)((total + HF_WAVES - 1) / HF_WAVES);
     const dim3 g(grid), b(HF_WAVES * 64);
     const size_t lds = per * HF_WAVES;
     static bool attr_done = false;
     if (!attr_done) {
-#define HATTR(A, B) (void)hipFuncSetAttribute((const void*)hog_fast_kernel<A, B, TO, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-        HATTR(ACC_EXACT_ORDER, 0); HATTR(ACC_EXACT_ORDER, 1); HATTR(ACC_EXACT_ORDER, 2);
-        HATTR(ACC_FIXED64, 0); HATTR(ACC_FIXED64, 1); HATTR(ACC_FIXED64, 2);
+#define HATTR(A, B, P) (void)hipFuncSetAttribute((const void*)hog_fast_kernel<A, B, TO, TC, P>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+        HATTR(ACC_EXACT_ORDER, 0, false); HATTR(ACC_EXACT_ORDER, 1, false); HATTR(ACC_EXACT_ORDER, 2, false);
+        HATTR(ACC_FIXED64, 0, false); HATTR(ACC_FIXED64, 1, false); HATTR(ACC_FIXED64, 2, false);
+        HATTR(ACC_EXACT_ORDER, 2, true); HATTR(ACC_FIXED64, 2, true);
 #undef HATTR
         attr_done = true;
     }
-#define LAUNCH(ACC, FB)                                                                                              \
-    hipLaunchKernelGGL((hog_fast_kernel<ACC, FB, TO, TC>), g, b, lds, stream, imgs, img_idx, x, N, L, eyes, lv, feat, \
+#define LAUNCH(ACC, FB, P)                                                                                               \
+    hipLaunchKernelGGL((hog_fast_kernel<ACC, FB, TO, TC, P>), g, b, lds, stream, imgs, img_idx, x, N, L, eyes, lv, feat, \
                        ldf, idx_out, status, per)
-    if (exact_order) { if (fast_bins == 2) LAUNCH(ACC_EXACT_ORDER, 2); else if (fast_bins == 1) LAUNCH(ACC_EXACT_ORDER, 1); else LAUNCH(ACC_EXACT_ORDER, 0); }
-    else { if (fast_bins == 2) LAUNCH(ACC_FIXED64, 2); else if (fast_bins == 1) LAUNCH(ACC_FIXED64, 1); else LAUNCH(ACC_FIXED64, 0); }
+    if (pair) { if (exact_order) LAUNCH(ACC_EXACT_ORDER, 2, true); else LAUNCH(ACC_FIXED64, 2, true); }
+    else if (exact_order) { if (fast_bins == 2) LAUNCH(ACC_EXACT_ORDER, 2, false); else if (fast_bins == 1) LAUNCH(ACC_EXACT_ORDER, 1, false); else LAUNCH(ACC_EXACT_ORDER, 0, false); }
+    else { if (fast_bins == 2) LAUNCH(ACC_FIXED64, 2, false); else if (fast_bins == 1) LAUNCH(ACC_FIXED64, 1, false); else LAUNCH(ACC_FIXED64, 0, false); }
 #undef LAUNCH
 }
 
@@ -668,7 +720,7 @@ void sdm_launch_hog_fast_profile(const ImageSetDev& imgs, const int* img_idx, co
     if (total <= 0 || !(lv.O == 4 && lv.C == 5)) return;
     const size_t per = fast_lds_bytes(lv.cell, lv.C, lv.O, lv.D);
     const unsigned grid = (unsigned)((total + HF_WAVES - 1) / HF_WAVES);
-    hipLaunchKernelGGL((hog_fast_kernel<ACC_FIXED64, 2, 4, 5, true>), dim3(grid), dim3(HF_WAVES * 64), per * HF_WAVES,
+    hipLaunchKernelGGL((hog_fast_kernel<ACC_FIXED64, 2, 4, 5, false, true>), dim3(grid), dim3(HF_WAVES * 64), per * HF_WAVES,
                        stream, imgs, img_idx, x, N, L, eyes, lv, feat, ldf, (int*)nullptr, status, per, prof_dev);
 }
 

@@ -539,3 +539,21 @@ def test_non_adaptive_example_transform(gpu_ctx, faces):
     x_orc = osdo.train(xs, x0t, None, ohog)
     assert rel_l2(x_gpu, x_orc) < 1e-4
     assert rel_l2(x_gpu, xs) < rel_l2(x0t, xs)
+
+
+def test_pair_mode_odd_landmark_count(gpu_ctx, faces, hog_mode):
+    """S <= 32 runs two landmarks per wave (lanes 0-31 / 32-63); with an odd landmark count the last wave of a sample
+    carries a single patch.  21 landmarks, cell 6 x 5 cells (S = 30) and cell 10 x 3 cells (S = 30)."""
+    images, _, _, _, x0 = faces
+    ids = IDS[:21]
+    re, le = ibug.eye_indices(ids)
+    x = np.ascontiguousarray(np.concatenate([x0[:, :21], x0[:, 22:43]], axis=1))
+    for p in [(1, 5, 6, 4, 0.3), (1, 3, 10, 4, 0.45), (0, 3, 8, 4, 0.5)]:
+        gpu_ctx.set_model_geometry(len(ids), re, le, [HoGParam(*p)])
+        gpu_ctx.upload_images(images)
+        gpu_ctx.set_sample_image_index(None)
+        gpu_ctx.set_x(x)
+        got = gpu_ctx.hog_features(0, fetch=True)
+        want, widx = orc.hog_features_batch(images, None, x, re, le, orc.HoGParam(*p), n_threads=os.cpu_count() or 1, want_idx=True)
+        assert np.array_equal(gpu_ctx.patch_indices(), widx)
+        check_features(hog_mode, got, want)
