@@ -198,7 +198,7 @@ def main():
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")) as fh:
             tj = json.load(fh)
         ent = tj["kernels"]["hog_fast_kernel"]
-        if int(ent["launch_geometry"]) == args.batch * L * 64:
+        if int(str(ent["launch_geometry"]).split("+")[0]) == args.batch * L * 64:
             traffic, traffic_src = float(ent["bytes_per_launch"]), "profiles/hbm_traffic.json (" + tj["source"] + ")"
             # the bound that actually limits this kernel: VALU issue, one wave instruction per 4 cycles per SIMD
             peak_ginst = 256 * 4 * 2.4 / 4.0
