@@ -424,12 +424,11 @@ void sdm_launch_apply(const float* feat, long long ldf, int N, int F, const floa
         // (feat / Rt rows are zero padded up to ldf >= round_up(F, 128): whole 64-wide slabs are readable)
         const int kslabs = (F + AT_BK - 1) / AT_BK;
         const dim3 grid((N + AT_BM - 1) / AT_BM, splits);
-        static bool attr_done = false;
-        if (!attr_done) {
+        static unsigned long long attr_seen = 0;
+        if (sdm_first_use_on_device(attr_seen)) {
             (void)hipFuncSetAttribute((const void*)apply_tiled_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)apply_tiled_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)apply_tiled_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_done = true;
         }
         const size_t lds = (size_t)2 * (AT_BM + NT * 16) * AT_LD * sizeof(float);
         if (NT == 1) hipLaunchKernelGGL(apply_tiled_kernel<1>, grid, dim3(256), lds, stream, feat, ldf, N, kslabs, Rt, ldr, partial, splits);

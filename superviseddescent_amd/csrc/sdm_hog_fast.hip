@@ -693,14 +693,13 @@ static void launch_fast_oc(const ImageSetDev& imgs, const int* img_idx, const fl
     const unsigned grid = (unsigned)((total + HF_WAVES - 1) / HF_WAVES);
     const dim3 g(grid), b(HF_WAVES * 64);
     const size_t lds = per * HF_WAVES;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_seen = 0;
+    if (sdm_first_use_on_device(attr_seen)) {
 #define HATTR(A, B, P) (void)hipFuncSetAttribute((const void*)hog_fast_kernel<A, B, TO, TC, P>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
         HATTR(ACC_EXACT_ORDER, 0, false); HATTR(ACC_EXACT_ORDER, 1, false); HATTR(ACC_EXACT_ORDER, 2, false);
         HATTR(ACC_FIXED64, 0, false); HATTR(ACC_FIXED64, 1, false); HATTR(ACC_FIXED64, 2, false);
         HATTR(ACC_EXACT_ORDER, 2, true); HATTR(ACC_FIXED64, 2, true);
 #undef HATTR
-        attr_done = true;
     }
 #define LAUNCH(ACC, FB, P)                                                                                               \
     hipLaunchKernelGGL((hog_fast_kernel<ACC, FB, TO, TC, P>), g, b, lds, stream, imgs, img_idx, x, N, L, eyes, lv, feat, \

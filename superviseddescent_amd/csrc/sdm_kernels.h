@@ -121,6 +121,17 @@ void sdm_launch_add_diag(float* G, long long ldg, int F, const double* fro2, int
 // Blocked Cholesky G = U^T U on the upper triangle of the leading F x F block, with the
 // forward substitution fused into the panel updates for the extra columns [rhs0, rhs0+nrhs),
 // then back substitution; R_out [F][ldr].  work: >= 2*NB*NB floats.
+// hipFuncSetAttribute (dynamic LDS above 64 KB) is per device: true the first time a call site runs on the current one
+inline bool sdm_first_use_on_device(unsigned long long& seen)
+{
+    int d = 0;
+    (void)hipGetDevice(&d);
+    const unsigned long long bit = 1ull << (d & 63);
+    if (seen & bit) return false;
+    seen |= bit;
+    return true;
+}
+
 // second queue + two events for the look-ahead of the blocked Cholesky (optional)
 struct SolveAux { hipStream_t stream; hipEvent_t chain_done, tail_done; };
 void sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs, float* R_out,

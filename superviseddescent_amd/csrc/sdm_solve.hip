@@ -536,14 +536,13 @@ void sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrh
     const int T = ncols / TILE;
     const size_t lds_potrf = ((size_t)TILE * TILE + TILE * IB + IB * IB + 4) * sizeof(float);
     const size_t lds_trsm = ((size_t)2 * TILE * TILE) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_seen = 0;
+    if (sdm_first_use_on_device(attr_seen)) {
         (void)hipFuncSetAttribute((const void*)potrf_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)trsm_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #define BSATTR(NJv) (void)hipFuncSetAttribute((const void*)backsolve_step_kernel<NJv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
         BSATTR(1); BSATTR(2); BSATTR(3); BSATTR(4); BSATTR(5);
 #undef BSATTR
-        attr_done = true;
     }
     // Panels are processed in groups of LAZY: inside a group only the NEXT tile row receives the pending rank-128
     // updates (a thin launch); the whole trailing matrix is updated once per group with K = 128*LAZY.  That is 1/LAZY of
