@@ -77,6 +77,13 @@ int main(int argc, char** argv)
         write_mat(dir + "/cpp_x_train.f32", last);
         for (int l = 0; l < n_levels; ++l) write_mat(dir + "/cpp_R" + std::to_string(l) + ".f32", model.get_regressors()[l].x);
         write_mat(dir + "/cpp_x_test.f32", model.test(x0, Mat(), hog));
+        // known-template mode through the same backend (superviseddescent.hpp:287-289): an all-zero template matrix
+        // (one row per sample, feature width of the cascade) must change nothing
+        {
+            Mat zeros = Mat::zeros(N, model.get_regressors()[0].x.rows, CV_32FC1);
+            Mat a = model.test(x0, Mat(), hog), b = model.test(x0, zeros, hog);
+            if (cv::norm(a, b, cv::NORM_L2) != 0.0) throw std::runtime_error("zero templates changed the result");
+        }
 
         // ---- save / load / detect (reference model.hpp:132-157, 192-219) ----
         auto meanv = read_all<float>(dir + "/mean.f32");
