@@ -52,6 +52,15 @@ struct DevBuf {
     }
 };
 
+// function-local scratch: freed on every exit path (the context's own buffers are released in sdm_destroy)
+template <class T>
+struct ScopedBuf : DevBuf<T> {
+    ScopedBuf() = default;
+    ScopedBuf(const ScopedBuf&) = delete;
+    ScopedBuf& operator=(const ScopedBuf&) = delete;
+    ~ScopedBuf() { this->release(); }
+};
+
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 }  // namespace
@@ -384,7 +393,7 @@ int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int*
         {
             // exhaustive on-device check of the orientation shortcut for this level's orientation count
             int mism[2] = {1, 1};
-            DevBuf<int> dm;
+            ScopedBuf<int> dm;
             int rcv = dm.ensure(2, true, c->stream);
             if (rcv) return rcv;
             sdm_launch_verify_fast_bins(lv, dm.p, c->stream);
@@ -541,8 +550,8 @@ int sdm_init_from_boxes(sdm_ctx* c, const float* mean, const int* boxes, const f
     HIP_TRY(hipSetDevice(c->device));
     int rc = ensure_sample_buffers(c, N);
     if (rc) return rc;
-    DevBuf<float> d_mean, d_pert;
-    DevBuf<int> d_box;
+    ScopedBuf<float> d_mean, d_pert;
+    ScopedBuf<int> d_box;
     if ((rc = d_mean.ensure(c->M)) || (rc = d_box.ensure((size_t)4 * N))) return rc;
     if (perturbations && (rc = d_pert.ensure((size_t)3 * N))) return rc;
     HIP_TRY(hipMemcpyAsync(d_mean.p, mean, c->M * sizeof(float), hipMemcpyHostToDevice, c->stream));
@@ -566,8 +575,8 @@ int sdm_normalised_errors(sdm_ctx* c, float* errors_host, double* mean_out)
     if (!c->have_targets) return fail(SDM_ERR_INVALID, "sdm_normalised_errors: no targets set");
     if (c->eyes.nre <= 0 || c->eyes.nle <= 0) return fail(SDM_ERR_INVALID, "sdm_normalised_errors: no eye landmarks");
     HIP_TRY(hipSetDevice(c->device));
-    DevBuf<float> d_err;
-    DevBuf<double> d_work;
+    ScopedBuf<float> d_err;
+    ScopedBuf<double> d_work;
     int rc;
     if ((rc = d_err.ensure((size_t)c->N * c->L)) || (rc = d_work.ensure(SDM_SUM_PARTS + 2))) return rc;
     sdm_launch_landmark_errors(c->x[c->cur].p, c->xstar.p, c->N, c->L, c->eyes, d_err.p, d_work.p, c->stream);
@@ -786,7 +795,7 @@ int sdm_solve_normal_equations(sdm_ctx* c, const float* A, int N, int F, const f
     HIP_TRY(hipSetDevice(c->device));
     const int Mp = Mp_of(M);
     const int Fp = round_up(F, 128), ncols = Fp + 128 * ((Mp + 127) / 128);
-    DevBuf<float> dA, dG, dR, dW; DevBuf<double> dfro;
+    ScopedBuf<float> dA, dG, dR, dW; ScopedBuf<double> dfro;
     int rc;
     if ((rc = dA.ensure((size_t)N * ncols, true, c->stream)) || (rc = dG.ensure((size_t)ncols * ncols)) ||
         (rc = dR.ensure((size_t)Fp * Mp)) || (rc = dW.ensure((size_t)Fp * 128)) || (rc = dfro.ensure((size_t)F + 1)))
@@ -872,7 +881,7 @@ int sdm_debug_patch(sdm_ctx* c, int level, int sample, int landmark, uint8_t* rs
     HIP_TRY(hipSetDevice(c->device));
     const HogLevelDev& lv = c->levels[level];
     const size_t nS = (size_t)lv.S * lv.S, nH = (size_t)2 * lv.O * lv.C * lv.C, nP = lv.P;
-    DevBuf<uint8_t> d_r, d_b; DevBuf<float> d_h, d_d;
+    ScopedBuf<uint8_t> d_r, d_b; ScopedBuf<float> d_h, d_d;
     int rc;
     if ((rc = d_r.ensure(nS)) || (rc = d_b.ensure(nS)) || (rc = d_h.ensure(nH)) || (rc = d_d.ensure(nP))) return rc;
     sdm_launch_hog_debug(image_set(c), c->idx_identity ? nullptr : c->img_idx.p, c->x[c->cur].p, c->N, c->L,
@@ -892,7 +901,7 @@ int sdm_debug_hog_profile(sdm_ctx* c, int level, unsigned long long* out8)
     if (!c || level < 0 || level >= (int)c->levels.size() || !out8) return fail(SDM_ERR_INVALID, "bad arguments");
     if (!c->img_base || c->N <= 0) return fail(SDM_ERR_INVALID, "no images / samples set");
     HIP_TRY(hipSetDevice(c->device));
-    DevBuf<unsigned long long> d;
+    ScopedBuf<unsigned long long> d;
     int rc = d.ensure(8, true, c->stream);
     if (rc) return rc;
     sdm_launch_hog_fast_profile(image_set(c), c->idx_identity ? nullptr : c->img_idx.p, c->x[c->cur].p, c->N, c->L,
@@ -910,7 +919,7 @@ int sdm_debug_gradient_table(sdm_ctx* c, int level, float* g, int* bin)
     if (!c || level < 0 || level >= (int)c->levels.size() || !g || !bin) return fail(SDM_ERR_INVALID, "bad arguments");
     HIP_TRY(hipSetDevice(c->device));
     const size_t n = 511 * 511;
-    DevBuf<float> d_g; DevBuf<int> d_b;
+    ScopedBuf<float> d_g; ScopedBuf<int> d_b;
     int rc;
     if ((rc = d_g.ensure(n)) || (rc = d_b.ensure(n))) return rc;
     sdm_launch_gradient_table(c->levels[level], d_g.p, d_b.p, c->stream);
