@@ -136,6 +136,99 @@ syrk_tn_kernel(const float* __restrict__ A, long long lda, int rows, float* __re
             }
 }
 
+// ---- the same product with LDS-direct staging (rows % 32 == 0) -----------------------------------------------------
+// Slabs of 32 rows go from global memory straight into LDS (global_load_lds, 16 bytes per lane: one wave instruction
+// fills two consecutive 512-byte tile rows), double buffered, one barrier per slab: the loads of slab s+1 are issued
+// when slab s starts and have its 16 k-steps (4096 MFMA cycles per wave) to land.  No staging registers, no LDS store
+// pass; the two-level summation of the Gram instance is unchanged (256-row chunks = 8 slabs).
+#define SYRK_GBK 32
+template <bool CHUNKED>
+__global__ void __launch_bounds__(256)
+syrk_tn_glds_kernel(const float* __restrict__ A, long long lda, int rows, float* __restrict__ C, long long ldc,
+                    float alpha, int accumulate, int tile_i0)
+{
+    const int ti = blockIdx.y + tile_i0, tj = blockIdx.x + tile_i0;
+    if (tj < ti) return;
+    extern __shared__ __attribute__((aligned(16))) float glds[];      // [2 buffers][A | B][SYRK_GBK][TILE]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const bool diag = (ti == tj);
+    const float* Ai = A + (long long)ti * TILE;
+    const float* Aj = A + (long long)tj * TILE;
+
+    f32x16 acc[2][2], tot[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc[m][n][e] = 0.0f; tot[m][n][e] = 0.0f; }
+
+    // thread t fetches float4 number (t % 32) of slab rows t/32 + 8p; a wave's 64 lanes cover rows 2w+8p, 2w+8p+1
+    const int lrow = t >> 5, lcol = (t & 31) * 4;
+    auto issue = [&](int s, int buf) {
+        float* a = glds + (size_t)buf * 2 * SYRK_GBK * TILE;
+        float* b = a + SYRK_GBK * TILE;
+#pragma unroll
+        for (int p = 0; p < SYRK_GBK / 8; ++p) {
+            const long long n = (long long)s * SYRK_GBK + lrow + 8 * p;
+            // LDS destination: wave-uniform base (+ lane * 16 bytes, added by the hardware)
+            float* la = a + (2 * wave + 8 * p) * TILE;
+            __builtin_amdgcn_global_load_lds(Ai + n * lda + lcol, (__attribute__((address_space(3))) void*)la, 16, 0, 0);
+            if (!diag) {
+                float* lb = b + (2 * wave + 8 * p) * TILE;
+                __builtin_amdgcn_global_load_lds(Aj + n * lda + lcol, (__attribute__((address_space(3))) void*)lb, 16, 0, 0);
+            }
+        }
+    };
+    const int nslabs = rows / SYRK_GBK;
+    constexpr int chunk = SYRK_CHUNK * SYRK_BK / SYRK_GBK;      // slabs per 256-row chunk
+    issue(0, 0);
+    for (int s = 0; s < nslabs; ++s) {
+        __syncthreads();                 // slab s has landed (the barrier drains the LDS-direct loads); buffer (s+1)%2 is free
+        if (s + 1 < nslabs) issue(s + 1, (s + 1) & 1);
+        const float (*As)[TILE] = (const float (*)[TILE])(glds + (size_t)(s & 1) * 2 * SYRK_GBK * TILE);
+        const float (*Bp)[TILE] = diag ? As : (const float (*)[TILE])(glds + (size_t)(s & 1) * 2 * SYRK_GBK * TILE + SYRK_GBK * TILE);
+#pragma unroll
+        for (int kk = 0; kk < SYRK_GBK; kk += 2) {
+            const int k = kk + (lane >> 5);
+            float a[2], b[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) a[m] = As[k][wr * 64 + m * 32 + (lane & 31)];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) b[n] = Bp[k][wc * 64 + n * 32 + (lane & 31)];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
+        }
+        if (CHUNKED && ((s + 1) % chunk == 0 || s + 1 == nslabs)) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { tot[m][n][e] += acc[m][n][e]; acc[m][n][e] = 0.0f; }
+        }
+    }
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const long long gi = (long long)ti * TILE + wr * 64 + m * 32 + r;
+                const long long gj = (long long)tj * TILE + wc * 64 + n * 32 + (lane & 31);
+                float* p = C + gi * ldc + gj;
+                float v = alpha * (CHUNKED ? tot[m][n][e] : acc[m][n][e]);
+                if (accumulate) v += *p;
+                *p = v;
+            }
+}
+
 // ---- Frobenius norm of the symmetric matrix stored as its upper triangle ------------------------------
 __global__ void fro2_rows_kernel(const float* __restrict__ G, long long ldg, int F, double* __restrict__ part)
 {
@@ -475,7 +568,19 @@ void sdm_launch_syrk_tn(const float* A, long long lda, int rows, int ncols, floa
     const int T = ncols / TILE - tile_i0;
     if (T <= 0 || rows <= 0) return;
     const int Ty = (tile_rows > 0 && tile_rows < T) ? tile_rows : T;
-    if (rows > SYRK_CHUNK * SYRK_BK * 4)
+    const bool chunked = rows > SYRK_CHUNK * SYRK_BK * 4;
+    if (rows % SYRK_GBK == 0) {      // LDS-direct staging
+        const size_t lds = (size_t)2 * 2 * SYRK_GBK * TILE * sizeof(float);      // 64 KB
+        static unsigned long long attr_seen = 0;
+        if (sdm_first_use_on_device(attr_seen)) {
+            (void)hipFuncSetAttribute((const void*)syrk_tn_glds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)syrk_tn_glds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        }
+        if (chunked)
+            hipLaunchKernelGGL(syrk_tn_glds_kernel<true>, dim3(T, Ty), dim3(256), lds, stream, A, lda, rows, C, ldc, alpha, accumulate, tile_i0);
+        else
+            hipLaunchKernelGGL(syrk_tn_glds_kernel<false>, dim3(T, Ty), dim3(256), lds, stream, A, lda, rows, C, ldc, alpha, accumulate, tile_i0);
+    } else if (chunked)
         hipLaunchKernelGGL(syrk_tn_kernel<true>, dim3(T, Ty), dim3(256), 0, stream, A, lda, rows, C, ldc, alpha,
                            accumulate, tile_i0);
     else
