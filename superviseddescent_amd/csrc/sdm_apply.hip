@@ -138,103 +138,81 @@ apply_partial_kernel(const float* __restrict__ feat, long long ldf, int N, int k
 }
 
 // ---- LDS-staged variant for narrow outputs on large batches (RCR-22 detect) -----------------------------------------
-// 64 rows x (NT*16) columns per workgroup, K in slabs of 64: every wave load instruction fetches 256 contiguous bytes
-// of four feature rows (the direct-to-register kernel above fetches 64-byte pieces of sixteen rows), the slab is
-// staged in LDS (row stride 68 floats: 16-byte fragment reads of 16 consecutive lanes fall into 16 different bank
-// groups) and wave w multiplies rows 16w..16w+15.  Same split-K / partial layout / fixed summation order.
+// 64 rows x (NT*16) columns per workgroup, K in slabs of 64 floats that go from global memory straight into LDS
+// (global_load_lds, 16 bytes per lane: one wave instruction fills four consecutive 256-byte tile rows, i.e. fetches 256
+// contiguous bytes of four feature rows -- the direct-to-register kernel above fetches 64-byte pieces of sixteen rows).
+// LDS-direct loads land lane-linear, so the bank-conflict swizzle is applied on the SOURCE side: position q of tile
+// row r holds the 16-byte chunk q ^ (r & 15); the 16 lanes of a fragment read (same chunk, rows li = 0..15) then hit 16
+// different bank groups.  Double buffered, one barrier per slab; wave w multiplies rows 16w..16w+15.  Same split-K /
+// partial layout / fixed summation order as the kernel above.
 #define AT_BM 64
 #define AT_BK 64
-#define AT_LD (AT_BK + 4)
-#define AT_LPR (AT_BK / 4)            // lanes (float4) per staged row
-#define AT_RPP (256 / AT_LPR)         // rows staged per pass of the 256 threads
-#define AT_APASS (AT_BM / AT_RPP)
+// 16 bytes per lane from global memory straight into LDS at (wave-uniform) lds_dst + lane * 16.  A plain function: inside
+// a template the builtin's arguments become dependent and the host pass of hipcc then drops the whole kernel
+// instantiation without a diagnostic.
+__device__ inline void glds16(const float* g, float* lds_dst)
+{
+    __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
 template <int NT>
 __global__ void __launch_bounds__(256)
 apply_tiled_kernel(const float* __restrict__ feat, long long ldf, int N, int kslabs,
                    const float* __restrict__ Rt, long long ldr, float* __restrict__ partial, int splits)
 {
-    constexpr int BPASS = (NT * 16 + AT_RPP - 1) / AT_RPP;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* As = lds;                                 // [2][AT_BM][AT_LD]
-    float* Bs = lds + 2 * AT_BM * AT_LD;             // [2][NT*16][AT_LD]
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [2 buffers][AT_BM + NT*16 rows][AT_BK]
+    constexpr int ROWS = AT_BM + NT * 16;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 15, lq = lane >> 4;
     const int row0 = blockIdx.x * AT_BM;
     const int split = blockIdx.y;
     const int s0 = (int)(((long long)kslabs * split) / splits), s1 = (int)(((long long)kslabs * (split + 1)) / splits);
-    // staging: thread t moves float4 number (t % AT_LPR) of rows t / AT_LPR + AT_RPP * p
-    const int lrow = t / AT_LPR, lc4 = (t % AT_LPR) * 4;
-    const float* ap[AT_APASS];
+    // staging: thread t fills position (t % 16) of tile rows t/16 + 16p, i.e. loads chunk (t % 16) ^ (row & 15)
+    const int srow = t >> 4, spos = t & 15;
+    const int schunk = spos ^ (srow & 15);                       // (16p does not change row & 15)
+    const float* ap[AT_BM / 16];
 #pragma unroll
-    for (int p = 0; p < AT_APASS; ++p) {
-        int row = row0 + lrow + AT_RPP * p;
-        if (row > N - 1) row = N - 1;                // clamp: duplicates are never stored
-        ap[p] = feat + (long long)row * ldf + lc4;
+    for (int p = 0; p < AT_BM / 16; ++p) {
+        int row = row0 + srow + 16 * p;
+        if (row > N - 1) row = N - 1;                            // clamp: duplicates are never stored
+        ap[p] = feat + (long long)row * ldf + 4 * schunk;
     }
-    const float* bp[BPASS];
-    bool bok[BPASS];
+    const float* bp[NT];
 #pragma unroll
-    for (int c = 0; c < BPASS; ++c) {
-        const int r = lrow + AT_RPP * c;
-        bok[c] = r < NT * 16;
-        bp[c] = Rt + (long long)(bok[c] ? r : 0) * ldr + lc4;
-    }
+    for (int c = 0; c < NT; ++c) bp[c] = Rt + (long long)(srow + 16 * c) * ldr + 4 * schunk;
+    auto issue = [&](int s, int buf) {
+        float* base = lds + (size_t)buf * ROWS * AT_BK;
+        const long long k0 = (long long)s * AT_BK;
+#pragma unroll
+        for (int p = 0; p < AT_BM / 16; ++p)      // wave w: tile rows 4w..4w+3 (+16p), 1 KB contiguous
+            glds16(ap[p] + k0, base + (4 * wave + 16 * p) * AT_BK);
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+            glds16(bp[c] + k0, base + (AT_BM + 4 * wave + 16 * c) * AT_BK);
+    };
 
     f32x4 acc[NT];
 #pragma unroll
     for (int c = 0; c < NT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // global -> registers two slabs ahead, registers -> LDS one slab ahead
-    f32x4 ra0[AT_APASS], rb0[BPASS], ra1[AT_APASS], rb1[BPASS];
-    auto fetch = [&](int s, f32x4 (&ra)[AT_APASS], f32x4 (&rb)[BPASS]) {
-        if (s >= s1) return;
-        const long long k0 = (long long)s * AT_BK;
-#pragma unroll
-        for (int p = 0; p < AT_APASS; ++p) ra[p] = *(const f32x4*)(ap[p] + k0);
-#pragma unroll
-        for (int c = 0; c < BPASS; ++c) rb[c] = *(const f32x4*)(bp[c] + k0);
-    };
-    auto stage = [&](int buf, const f32x4 (&ra)[AT_APASS], const f32x4 (&rb)[BPASS]) {
-        float* a = As + buf * AT_BM * AT_LD;
-        float* b = Bs + buf * NT * 16 * AT_LD;
-#pragma unroll
-        for (int p = 0; p < AT_APASS; ++p) *(f32x4*)(a + (lrow + AT_RPP * p) * AT_LD + lc4) = ra[p];
-#pragma unroll
-        for (int c = 0; c < BPASS; ++c)
-            if (bok[c]) *(f32x4*)(b + (lrow + AT_RPP * c) * AT_LD + lc4) = rb[c];
-    };
-    auto compute = [&](int buf) {
-        const float* a = As + buf * AT_BM * AT_LD + (16 * wave + li) * AT_LD + 4 * lq;
-        const float* b = Bs + buf * NT * 16 * AT_LD + li * AT_LD + 4 * lq;
+    if (s0 < s1) issue(s0, 0);
+    for (int s = s0; s < s1; ++s) {
+        __syncthreads();                 // slab s has landed (the barrier drains the LDS-direct loads); the other buffer is free
+        if (s + 1 < s1) issue(s + 1, (s - s0 + 1) & 1);
+        const float* a = lds + (size_t)((s - s0) & 1) * ROWS * AT_BK + (16 * wave + li) * AT_BK;
+        const float* b = lds + (size_t)((s - s0) & 1) * ROWS * AT_BK + (AT_BM + li) * AT_BK;
 #pragma unroll
         for (int kg = 0; kg < AT_BK / 16; ++kg) {
-            const f32x4 av = *(const f32x4*)(a + 16 * kg);
+            const int pos = 4 * ((lq + 4 * kg) ^ li);            // swizzled position of chunk lq + 4kg in a row with r & 15 == li
+            const f32x4 av = *(const f32x4*)(a + pos);
             f32x4 bv[NT];
 #pragma unroll
-            for (int c = 0; c < NT; ++c) bv[c] = *(const f32x4*)(b + 16 * c * AT_LD + 16 * kg);
+            for (int c = 0; c < NT; ++c) bv[c] = *(const f32x4*)(b + 16 * c * AT_BK + pos);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int c = 0; c < NT; ++c)
                     acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[c][e], acc[c], 0, 0, 0);
         }
-    };
-    if (s0 < s1) {
-        fetch(s0, ra0, rb0);
-        fetch(s0 + 1, ra1, rb1);
-        stage(0, ra0, rb0);
-    }
-    __syncthreads();
-    for (int s = s0; s < s1; s += 2) {
-        // slab s is in LDS buffer 0, slab s+1 in register set 1
-        fetch(s + 2, ra0, rb0);
-        compute(0);
-        if (s + 1 < s1) stage(1, ra1, rb1);
-        __syncthreads();
-        if (s + 1 >= s1) break;
-        fetch(s + 3, ra1, rb1);
-        compute(1);
-        if (s + 2 < s1) stage(0, ra0, rb0);
-        __syncthreads();
     }
     // C/D layout of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + e
     const int Mp = NT * 16;
@@ -430,7 +408,7 @@ void sdm_launch_apply(const float* feat, long long ldf, int N, int F, const floa
             (void)hipFuncSetAttribute((const void*)apply_tiled_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)apply_tiled_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         }
-        const size_t lds = (size_t)2 * (AT_BM + NT * 16) * AT_LD * sizeof(float);
+        const size_t lds = (size_t)2 * (AT_BM + NT * 16) * AT_BK * sizeof(float);
         if (NT == 1) hipLaunchKernelGGL(apply_tiled_kernel<1>, grid, dim3(256), lds, stream, feat, ldf, N, kslabs, Rt, ldr, partial, splits);
         else if (NT == 2) hipLaunchKernelGGL(apply_tiled_kernel<2>, grid, dim3(256), lds, stream, feat, ldf, N, kslabs, Rt, ldr, partial, splits);
         else hipLaunchKernelGGL(apply_tiled_kernel<3>, grid, dim3(256), lds, stream, feat, ldf, N, kslabs, Rt, ldr, partial, splits);
