@@ -483,7 +483,9 @@ __global__ void __launch_bounds__(256)
 backsolve_step_kernel(float* __restrict__ G, long long ldg, int k0, int rhs0, const float* __restrict__ winv_t,
                       float* __restrict__ R_base, long long ldr, int col0)
 {
-    // this launch handles the RHS columns [col0, col0 + 16*NJ) (wide right-hand sides are processed in column chunks)
+    // this launch handles the RHS columns [col0, col0 + 16*NJ) (wide right-hand sides are processed in column chunks).
+    // Both 128 x 128 x nrhs products run on the f32 matrix cores (v_mfma_f32_16x16x4_f32): wave w owns rows 32w..32w+31
+    // (two 16-row tiles) x NJ 16-column tiles; lane (li, lq) feeds A[row li][k lq] and B[k lq][col li].
     constexpr int nrhs = NJ * 16;
     rhs0 += col0;
     float* R = R_base + col0;
@@ -491,7 +493,8 @@ backsolve_step_kernel(float* __restrict__ G, long long ldg, int k0, int rhs0, co
     float* A = sm;                          // [128][128+4]: first W^T (k-major for the product), then U_ik
     float* Yk = sm + TILE * (TILE + 4);     // [128][nrhs]
     float* Rk = Yk + TILE * nrhs;           // [128][nrhs]
-    const int t = threadIdx.x, tr = t >> 4, tc = t & 15;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 15, lq = lane >> 4;
     const int k = k0 / TILE;
     const bool last = (int)blockIdx.x == k;
     const int lr = t >> 5, lc = (t & 31) * 4;
@@ -502,30 +505,36 @@ backsolve_step_kernel(float* __restrict__ G, long long ldg, int k0, int rhs0, co
         Yk[idx] = Yg[(long long)r * ldg + cc];
     }
     __syncthreads();
-    float acc[8][NJ];
+    f32x4 acc[2][NJ];
 #pragma unroll
-    for (int a = 0; a < 8; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < NJ; ++b) acc[a][b] = 0.0f;
+        for (int b = 0; b < NJ; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // R_k[r][c] = sum_m W^T[m][r] * Y_k[m][c]
-    for (int m = 0; m < TILE; ++m) {
-        float wr[8], yc[NJ];
+#pragma unroll 4
+    for (int kk = 0; kk < TILE / 4; ++kk) {
+        const int m = 4 * kk + lq;
+        float av[2], bv[NJ];
 #pragma unroll
-        for (int a = 0; a < 8; ++a) wr[a] = A[m * (TILE + 4) + tr + 16 * a];
+        for (int a = 0; a < 2; ++a) av[a] = A[m * (TILE + 4) + 32 * wave + 16 * a + li];
 #pragma unroll
-        for (int b = 0; b < NJ; ++b) yc[b] = Yk[m * nrhs + tc + 16 * b];
+        for (int b = 0; b < NJ; ++b) bv[b] = Yk[m * nrhs + 16 * b + li];
 #pragma unroll
-        for (int a = 0; a < 8; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < NJ; ++b) acc[a][b] += wr[a] * yc[b];
+            for (int b = 0; b < NJ; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
     }
+    // C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + e
 #pragma unroll
-    for (int a = 0; a < 8; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < NJ; ++b) {
-            Rk[(tr + 16 * a) * nrhs + tc + 16 * b] = acc[a][b];
-            if (last) R[(long long)(k0 + tr + 16 * a) * ldr + tc + 16 * b] = acc[a][b];
-        }
+        for (int b = 0; b < NJ; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = 32 * wave + 16 * a + 4 * lq + e, col = 16 * b + li;
+                Rk[row * nrhs + col] = acc[a][b][e];
+                if (last) R[(long long)(k0 + row) * ldr + col] = acc[a][b][e];
+            }
     if (last) return;
     __syncthreads();
     // Y_i -= U_ik * R_k
@@ -535,28 +544,31 @@ backsolve_step_kernel(float* __restrict__ G, long long ldg, int k0, int rhs0, co
     for (int r = lr; r < TILE; r += 8) *(f32x4s*)(A + r * (TILE + 4) + lc) = *(const f32x4s*)(Uik + (long long)r * ldg + lc);
     __syncthreads();
 #pragma unroll
-    for (int a = 0; a < 8; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < NJ; ++b) acc[a][b] = 0.0f;
-    for (int m = 0; m < TILE; m += 4) {
-        f32x4s ur[8];
+        for (int b = 0; b < NJ; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int kk = 0; kk < TILE / 4; ++kk) {
+        const int m = 4 * kk + lq;
+        float av[2], bv[NJ];
 #pragma unroll
-        for (int a = 0; a < 8; ++a) ur[a] = *(const f32x4s*)(A + (tr + 16 * a) * (TILE + 4) + m);
+        for (int a = 0; a < 2; ++a) av[a] = A[(32 * wave + 16 * a + li) * (TILE + 4) + m];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float xc[NJ];
+        for (int b = 0; b < NJ; ++b) bv[b] = Rk[m * nrhs + 16 * b + li];
 #pragma unroll
-            for (int b = 0; b < NJ; ++b) xc[b] = Rk[(m + e) * nrhs + tc + 16 * b];
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int a = 0; a < 8; ++a)
-#pragma unroll
-                for (int b = 0; b < NJ; ++b) acc[a][b] += ur[a][e] * xc[b];
-        }
+            for (int b = 0; b < NJ; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
     }
 #pragma unroll
-    for (int a = 0; a < 8; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < NJ; ++b) Yi[(long long)(tr + 16 * a) * ldg + tc + 16 * b] -= acc[a][b];
+        for (int b = 0; b < NJ; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = 32 * wave + 16 * a + 4 * lq + e, col = 16 * b + li;
+                Yi[(long long)row * ldg + col] -= acc[a][b][e];
+            }
 }
 
 }  // namespace
