@@ -142,6 +142,11 @@ syrk_tn_kernel(const float* __restrict__ A, long long lda, int rows, float* __re
 // when slab s starts and have its 16 k-steps (4096 MFMA cycles per wave) to land.  No staging registers, no LDS store
 // pass; the two-level summation of the Gram instance is unchanged (256-row chunks = 8 slabs).
 #define SYRK_GBK 32
+// 16 bytes per lane from global memory straight into LDS at (wave-uniform) lds_dst + lane * 16
+__device__ inline void glds16_solve(const float* g, float* lds_dst)
+{
+    __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
 template <bool CHUNKED>
 __global__ void __launch_bounds__(256)
 syrk_tn_glds_kernel(const float* __restrict__ A, long long lda, int rows, float* __restrict__ C, long long ldc,
@@ -227,6 +232,61 @@ syrk_tn_glds_kernel(const float* __restrict__ A, long long lda, int rows, float*
                 if (accumulate) v += *p;
                 *p = v;
             }
+}
+
+// ---- thin updates: ONE tile row, a few hundred rows of K (the eager row update inside a Cholesky panel group) ----------
+// With one workgroup per 128x128 tile such a launch has fewer workgroups than the chip has CUs and every slab costs a full
+// memory round trip.  Here a tile is split into four 64x64 sub-tiles (4x the workgroups), and K arrives in batches of
+// 128 rows -- 2 x 32 KB straight into LDS, all loads of a batch in flight together, one barrier pair per batch.
+#define THIN_BK 128
+#define THIN_N 64
+__global__ void __launch_bounds__(256)
+syrk_tn_thin_kernel(const float* __restrict__ A, long long lda, int rows, float* __restrict__ C, long long ldc,
+                    float alpha, int ti)
+{
+    // blockIdx.x: sub-tile column (64 wide) counted from the start of tile ti; blockIdx.y: sub-tile row inside tile ti
+    const int sj = blockIdx.x, si = blockIdx.y;
+    if (sj < si) return;                                   // lower sub-tile of the diagonal tile
+    extern __shared__ __attribute__((aligned(16))) float tl[];   // [A | B][THIN_BK][THIN_N]
+    float* As = tl;
+    float* Bs = tl + THIN_BK * THIN_N;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const bool diag = (sj == si);
+    const float* Ai = A + (long long)ti * TILE + (long long)si * THIN_N;
+    const float* Aj = A + (long long)ti * TILE + (long long)sj * THIN_N;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    // thread t fetches float4 number (t % 16) of batch rows t/16 + 16p; a wave's 64 lanes cover 4 consecutive rows (1 KB)
+    const int lrow = t >> 4, lcol = (t & 15) * 4;
+    for (int n0 = 0; n0 < rows; n0 += THIN_BK) {
+        if (n0) __syncthreads();                           // the previous batch has been consumed
+#pragma unroll
+        for (int p = 0; p < THIN_BK / 16; ++p) {
+            const long long n = (long long)n0 + lrow + 16 * p;
+            glds16_solve(Ai + n * lda + lcol, As + (4 * wave + 16 * p) * THIN_N);
+            if (!diag) glds16_solve(Aj + n * lda + lcol, Bs + (4 * wave + 16 * p) * THIN_N);
+        }
+        __syncthreads();                                   // (drains the LDS-direct loads)
+        const float* Bp = diag ? As : Bs;
+#pragma unroll 8
+        for (int kk = 0; kk < THIN_BK; kk += 2) {
+            const int k = kk + (lane >> 5);
+            const float a = As[k * THIN_N + wr * 32 + (lane & 31)];
+            const float b = Bp[k * THIN_N + wc * 32 + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+    }
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int r = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        const long long gi = (long long)ti * TILE + si * THIN_N + wr * 32 + r;
+        const long long gj = (long long)ti * TILE + sj * THIN_N + wc * 32 + (lane & 31);
+        float* p = C + gi * ldc + gj;
+        *p += alpha * acc[e];
+    }
 }
 
 // ---- Frobenius norm of the symmetric matrix stored as its upper triangle ------------------------------
@@ -581,6 +641,14 @@ void sdm_launch_syrk_tn(const float* A, long long lda, int rows, int ncols, floa
     if (T <= 0 || rows <= 0) return;
     const int Ty = (tile_rows > 0 && tile_rows < T) ? tile_rows : T;
     const bool chunked = rows > SYRK_CHUNK * SYRK_BK * 4;
+    if (Ty == 1 && accumulate && rows % THIN_BK == 0 && rows <= 1024) {      // thin row update inside a panel group
+        const size_t lds = (size_t)2 * THIN_BK * THIN_N * sizeof(float);      // 64 KB
+        static unsigned long long thin_seen = 0;
+        if (sdm_first_use_on_device(thin_seen))
+            (void)hipFuncSetAttribute((const void*)syrk_tn_thin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(syrk_tn_thin_kernel, dim3(2 * T, 2), dim3(256), lds, stream, A, lda, rows, C, ldc, alpha, tile_i0);
+        return;
+    }
     if (rows % SYRK_GBK == 0) {      // LDS-direct staging
         const size_t lds = (size_t)2 * 2 * SYRK_GBK * TILE * sizeof(float);      // 64 KB
         static unsigned long long attr_seen = 0;
