@@ -234,7 +234,8 @@ syrk_tn_glds_kernel(const float* __restrict__ A, long long lda, int rows, float*
             }
 }
 
-// ---- thin updates: ONE tile row, a few hundred rows of K (the eager row update inside a Cholesky panel group) ----------
+// ---- thin updates: up to four tile rows, a few hundred rows of K (the row update inside a Cholesky panel group and the
+//      head of the group-end update) -----------------------------------------------------------------------------------
 // With one workgroup per 128x128 tile such a launch has fewer workgroups than the chip has CUs and every slab costs a full
 // memory round trip.  Here a tile is split into four 64x64 sub-tiles (4x the workgroups), and K arrives in batches of
 // 128 rows -- 2 x 32 KB straight into LDS, all loads of a batch in flight together, one barrier pair per batch.
@@ -242,11 +243,13 @@ syrk_tn_glds_kernel(const float* __restrict__ A, long long lda, int rows, float*
 #define THIN_N 64
 __global__ void __launch_bounds__(256)
 syrk_tn_thin_kernel(const float* __restrict__ A, long long lda, int rows, float* __restrict__ C, long long ldc,
-                    float alpha, int ti)
+                    float alpha, int tile_i0)
 {
-    // blockIdx.x: sub-tile column (64 wide) counted from the start of tile ti; blockIdx.y: sub-tile row inside tile ti
-    const int sj = blockIdx.x, si = blockIdx.y;
-    if (sj < si) return;                                   // lower sub-tile of the diagonal tile
+    // blockIdx.y: 64-row sub-tile row counted from tile row tile_i0; blockIdx.x: 64-column sub-tile column counted from
+    // tile column tile_i0.  Everything below is relative to the first tile of this sub-tile row.
+    const int ti = tile_i0 + (int)(blockIdx.y >> 1), si = blockIdx.y & 1;
+    const int sj = (int)blockIdx.x - 2 * (ti - tile_i0);    // sub-tile column counted from the start of tile ti
+    if (sj < si) return;                                   // left of / below the diagonal
     extern __shared__ __attribute__((aligned(16))) float tl[];   // [A | B][THIN_BK][THIN_N]
     float* As = tl;
     float* Bs = tl + THIN_BK * THIN_N;
@@ -641,12 +644,13 @@ void sdm_launch_syrk_tn(const float* A, long long lda, int rows, int ncols, floa
     if (T <= 0 || rows <= 0) return;
     const int Ty = (tile_rows > 0 && tile_rows < T) ? tile_rows : T;
     const bool chunked = rows > SYRK_CHUNK * SYRK_BK * 4;
-    if (Ty == 1 && accumulate && rows % THIN_BK == 0 && rows <= 1024) {      // thin row update inside a panel group
+    // thin updates (a panel group's row update / a head with fewer tiles than the chip has CUs)
+    if (Ty <= 4 && T * Ty <= 320 && accumulate && rows % THIN_BK == 0 && rows <= 1024) {
         const size_t lds = (size_t)2 * THIN_BK * THIN_N * sizeof(float);      // 64 KB
         static unsigned long long thin_seen = 0;
         if (sdm_first_use_on_device(thin_seen))
             (void)hipFuncSetAttribute((const void*)syrk_tn_thin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(syrk_tn_thin_kernel, dim3(2 * T, 2), dim3(256), lds, stream, A, lda, rows, C, ldc, alpha, tile_i0);
+        hipLaunchKernelGGL(syrk_tn_thin_kernel, dim3(2 * T, 2 * Ty), dim3(256), lds, stream, A, lda, rows, C, ldc, alpha, tile_i0);
         return;
     }
     if (rows % SYRK_GBK == 0) {      // LDS-direct staging
