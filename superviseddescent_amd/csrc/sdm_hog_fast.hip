@@ -384,23 +384,27 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
     // the image as a raw buffer: per-lane byte offset (column) in the vector offset, the row offset in a scalar
     // register -> no per-row vector address arithmetic at all
     const __amdgpu_buffer_rsrc_t img_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)img, 0, ih * istride, 0x00020000);
+    // PAIR: y0 differs between the halves, so the row offset cannot sit in the scalar operand.  Each lane keeps
+    // px + y0 * stride (possibly negative) and adds the scalar row term; rows above or below the image then fall outside
+    // the buffer's num_records and the hardware range check returns 0 -- the black canvas -- without any clamp or mask.
+    const int vb0 = PAIR ? px0 + y0 * istride : 0, vb1 = PAIR ? px1 + y0 * istride : 0;
     auto issue_row = [&](int y, int& q00, int& q01, int& q10, int& q11, int& bb) {
         const int yy = y < S ? y : S - 1;
         const int src = __builtin_amdgcn_readlane(row_src, yy);
         int beta = __builtin_amdgcn_readlane(row_beta, yy);
-        int py0 = y0 + (src & 0xffff), py1 = y0 + (src >> 16);
-        // rows on the black canvas: vertical weight 0 (scalar), address clamped into the image
-        if (py0 < 0 || py0 >= ih) beta &= 0xffff0000;
-        if (py1 < 0 || py1 >= ih) beta &= 0x0000ffff;
-        py0 = py0 < 0 ? 0 : (py0 > ih - 1 ? ih - 1 : py0);
-        py1 = py1 < 0 ? 0 : (py1 > ih - 1 ? ih - 1 : py1);
-        if (PAIR) {   // y0 differs between the halves: row offsets and masks are per lane (24-bit multiplies: full rate)
-            const int o0 = __mul24(py0, istride), o1 = __mul24(py1, istride);
-            q00 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, px0 + o0, 0, 0);
-            q01 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, px1 + o0, 0, 0);
-            q10 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, px0 + o1, 0, 0);
-            q11 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, px1 + o1, 0, 0);
+        if (PAIR) {
+            const int r0 = (src & 0xffff) * istride, r1 = (src >> 16) * istride;     // scalar
+            q00 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, vb0 + r0, 0, 0);
+            q01 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, vb1 + r0, 0, 0);
+            q10 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, vb0 + r1, 0, 0);
+            q11 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, vb1 + r1, 0, 0);
         } else {
+            int py0 = y0 + (src & 0xffff), py1 = y0 + (src >> 16);
+            // rows on the black canvas: vertical weight 0 (scalar), address clamped into the image
+            if (py0 < 0 || py0 >= ih) beta &= 0xffff0000;
+            if (py1 < 0 || py1 >= ih) beta &= 0x0000ffff;
+            py0 = py0 < 0 ? 0 : (py0 > ih - 1 ? ih - 1 : py0);
+            py1 = py1 < 0 ? 0 : (py1 > ih - 1 ? ih - 1 : py1);
             const int o0 = py0 * istride, o1 = py1 * istride;
             q00 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, px0, o0, 0);
             q01 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, px1, o0, 0);

@@ -557,3 +557,23 @@ def test_pair_mode_odd_landmark_count(gpu_ctx, faces, hog_mode):
         want, widx = orc.hog_features_batch(images, None, x, re, le, orc.HoGParam(*p), n_threads=os.cpu_count() or 1, want_idx=True)
         assert np.array_equal(gpu_ctx.patch_indices(), widx)
         check_features(hog_mode, got, want)
+
+
+@pytest.mark.parametrize("shift", [(-140.0, 30.0), (35.0, -150.0), (120.0, 170.0), (-300.0, -300.0)])
+def test_patches_on_the_black_canvas(gpu_ctx, faces, hog_mode, shift):
+    """adaptive_vlhog.hpp:136-151: ROI pixels outside the image are the zero canvas of copyMakeBorder.  Landmark rows
+    shifted so that patches straddle or leave every image border (the paired level relies on the buffer range check
+    for rows above / below the image, the others on clamped addresses with zero weights)."""
+    images, _, _, _, x0 = faces
+    x = x0[:64].copy()
+    x[:, :len(IDS)] += np.float32(shift[0])
+    x[:, len(IDS):] += np.float32(shift[1])
+    gpu_ctx.set_model_geometry(len(IDS), RE, LE, SHIPPED)
+    gpu_ctx.upload_images(images)
+    gpu_ctx.set_sample_image_index(None)
+    gpu_ctx.set_x(x)
+    for level in (0, 3):
+        got = gpu_ctx.hog_features(level, fetch=True)
+        want, widx = orc.hog_features_batch(images, None, x, RE, LE, O_SHIPPED[level], n_threads=os.cpu_count() or 1, want_idx=True)
+        assert np.array_equal(gpu_ctx.patch_indices(), widx)
+        check_features(hog_mode, got, want)
