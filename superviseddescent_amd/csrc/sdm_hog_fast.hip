@@ -248,6 +248,100 @@ __device__ inline void wave_sync()
 __device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ inline float lane_f(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 
+// ---- one finished histogram -> descriptor -> feature row segment (vl_hog_extract, hog.c:857-1062, and the Matlab-order
+//      flatten of adaptive_vlhog.hpp:166-175).  `w` is the calling wave's scratch; hfin_p / histf_p the patch's finished
+//      histogram (fixed point / exact order).  Runs on one wave. ----------------------------------------------------------
+template <int ACC, int TO, int TC>
+__device__ void hog_finish_patch(const FastLds& w, const u64* hfin_p, const float* histf_p, float* __restrict__ out_desc,
+                                 const HogLevelDev& lv, int lane)
+{
+    const int O = TO ? TO : lv.O;
+    const int C = TC ? TC : lv.C;
+    const int CC = C * C, PW = C + 2, PWW = PW * PW;
+    // ---- histogram -> f32 [2O][CC] (one conversion per accumulator; region B, dead since the last flush,
+    //      becomes the scratch of the normalisation phase; region A is only read) ----------------------------
+    for (int t = lane; t < 2 * O * CC; t += 64) {
+        const int k = t / CC, c = t - k * CC;
+        const int cyy = c / C, cxx = c - cyy * C;
+        // fixed point: exact sum, ONE rounding (u64 -> f32), then the exact scale 2^-36
+        w.histv[t] = (ACC == ACC_FIXED64)
+                         ? (float)(__builtin_bit_cast(double, hfin_p[t]) - 4503599627370496.0) * 1.4551915228366852e-11f
+                         : histf_p[k * PWW + (cyy + 1) * PW + (cxx + 1)];
+    }
+    wave_sync();
+
+    // ---- cell norms (hog.c:875-890) ---------------------------------------------------------------------------
+    for (int c = lane; c < CC; c += 64) {
+        float n = 0.0f;
+        for (int k = 0; k < O; ++k) {
+            const float hs = w.histv[c + k * CC] + w.histv[c + (k + O) * CC];
+            n += hs * hs;
+        }
+        w.nrm[c] = n;
+    }
+    wave_sync();
+    // ---- block factors (hog.c:930-981).  The four factors of a cell are those of the 2x2-cell blocks around its four
+    //      corners, clamped at the border; a block is shared by up to four cells, so the (C+1)^2 distinct ones are
+    //      computed once: block (bx, by) sums cells (xa,ya) (xb,ya) (xa,yb) (xb,yb), left to right, + 1e-4 last, with
+    //      xa = max(bx-1, 0), xb = min(bx, C-1) -- the same operands in the same order as the reference's n1..n9 ----
+    const int CB = C + 1;
+    for (int t = lane; t < CB * CB; t += 64) {
+        const int byb = t / CB, bxb = t - byb * CB;
+        const int xa = bxb - 1 > 0 ? bxb - 1 : 0, xb = bxb < C - 1 ? bxb : C - 1;
+        const int ya = byb - 1 > 0 ? byb - 1 : 0, yb = byb < C - 1 ? byb : C - 1;
+        const double na = w.nrm[xa + ya * C], nb = w.nrm[xb + ya * C];
+        const double nc = w.nrm[xa + yb * C], nd = w.nrm[xb + yb * C];
+        w.fac[t] = 1.0 / sqrt(na + nb + nc + nd + 1e-4);
+    }
+    wave_sync();
+    // ---- normalise, clamp, emit the 3 (UoCTTI) or 4 (Dalal-Triggs) outputs of every (cell, orientation) ------
+    //      desc is written in the Matlab order of the feature row (adaptive_vlhog.hpp:166-175): [dim][x][y]
+    for (int t = lane; t < O * CC; t += 64) {
+        const int k = t / CC, c = t - k * CC;
+        const int y = c / C, x = c - y * C, ct = x * C + y;
+        const double ha = w.histv[c + k * CC], hb = w.histv[c + (k + O) * CC];
+        // j=0: n1+n2+n4+n5  j=1: n2+n3+n5+n6  j=2: n4+n5+n7+n8  j=3: n5+n6+n8+n9
+        const double f1 = w.fac[x + y * CB], f2 = w.fac[x + 1 + y * CB];
+        const double f3 = w.fac[x + (y + 1) * CB], f4 = w.fac[x + 1 + (y + 1) * CB];
+        double ha1 = f1 * ha, ha2 = f2 * ha, ha3 = f3 * ha, ha4 = f4 * ha;
+        double hb1 = f1 * hb, hb2 = f2 * hb, hb3 = f3 * hb, hb4 = f4 * hb;
+        double hc1 = ha1 + hb1, hc2 = ha2 + hb2, hc3 = ha3 + hb3, hc4 = ha4 + hb4;
+#define CL02(v) __builtin_fmin(0.2, (v))          /* VL_MIN(0.2, v): the values are finite and non-negative */
+        ha1 = CL02(ha1); ha2 = CL02(ha2); ha3 = CL02(ha3); ha4 = CL02(ha4);
+        hb1 = CL02(hb1); hb2 = CL02(hb2); hb3 = CL02(hb3); hb4 = CL02(hb4);
+        hc1 = CL02(hc1); hc2 = CL02(hc2); hc3 = CL02(hc3); hc4 = CL02(hc4);
+#undef CL02
+        if (lv.variant == 1) {
+            w.desc[ct + k * CC] = (float)(0.5 * (ha1 + ha2 + ha3 + ha4));
+            w.desc[ct + (k + O) * CC] = (float)(0.5 * (hb1 + hb2 + hb3 + hb4));
+            w.desc[ct + (k + 2 * O) * CC] = (float)(0.5 * (hc1 + hc2 + hc3 + hc4));
+            double* q = w.hcc + (size_t)(k * CC + c) * 4;
+            q[0] = hc1; q[1] = hc2; q[2] = hc3; q[3] = hc4;
+        } else {
+            w.desc[ct + k * CC] = (float)hc1;
+            w.desc[ct + (k + O) * CC] = (float)hc2;
+            w.desc[ct + (k + 2 * O) * CC] = (float)hc3;
+            w.desc[ct + (k + 3 * O) * CC] = (float)hc4;
+        }
+    }
+    wave_sync();
+    // ---- texture features: t_j = sum over k (in order) of the clamped hc_j (hog.c:1020-1023, 1047-1052) ------
+    if (lv.variant == 1) {
+        const float tex = 1.0f / sqrtf(18.0f);
+        for (int t = lane; t < 4 * CC; t += 64) {
+            const int j = t / CC, c = t - j * CC;
+            const int y = c / C, x = c - y * C, ct = x * C + y;
+            double acc = 0.0;
+            for (int k = 0; k < O; ++k) acc += w.hcc[(size_t)(k * CC + c) * 4 + j];
+            w.desc[ct + (3 * O + j) * CC] = (float)(tex * acc);
+        }
+        wave_sync();
+    }
+    // ---- the feature row segment of this landmark: desc is already in its order -------------------------------
+    for (int o = lane; o < lv.P; o += 64) out_desc[o] = w.desc[o];
+    wave_sync();   // the caller may reuse the scratch for the next patch
+}
+
 // TO / TC: compile-time orientation count / cell count (0 = take the run-time value from lv)
 // PAIR: landmarks `landmark` and `landmark + 1` of the same sample side by side in lanes 0-31 / 32-63 (S <= 32).  They
 // share the image, the IED, hence h, the scale and every per-coordinate table; only the patch centre differs, which
@@ -529,89 +623,8 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
         const u64* hfin_p = (const u64*)((unsigned char*)w.hfin + (size_t)hp * a_bytes);
         const float* histf_p = (const float*)((unsigned char*)w.hfin + (size_t)hp * a_bytes);
         float* out_desc = out_row + (long long)(landmark + hp) * lv.P;
-        // ---- histogram -> f32 [2O][CC] (one conversion per accumulator; region B, dead since the last flush,
-        //      becomes the scratch of the normalisation phase; region A is only read) ----------------------------
-        for (int t = lane; t < 2 * O * CC; t += 64) {
-            const int k = t / CC, c = t - k * CC;
-            const int cyy = c / C, cxx = c - cyy * C;
-            // fixed point: exact sum, ONE rounding (u64 -> f32), then the exact scale 2^-36
-            w.histv[t] = (ACC == ACC_FIXED64)
-                             ? (float)(__builtin_bit_cast(double, hfin_p[t]) - 4503599627370496.0) * 1.4551915228366852e-11f
-                             : histf_p[k * PWW + (cyy + 1) * PW + (cxx + 1)];
-        }
-        wave_sync();
-
-        // ---- cell norms (hog.c:875-890) ---------------------------------------------------------------------------
-        for (int c = lane; c < CC; c += 64) {
-            float n = 0.0f;
-            for (int k = 0; k < O; ++k) {
-                const float hs = w.histv[c + k * CC] + w.histv[c + (k + O) * CC];
-                n += hs * hs;
-            }
-            w.nrm[c] = n;
-        }
-        wave_sync();
-        // ---- block factors (hog.c:930-981).  The four factors of a cell are those of the 2x2-cell blocks around its four
-        //      corners, clamped at the border; a block is shared by up to four cells, so the (C+1)^2 distinct ones are
-        //      computed once: block (bx, by) sums cells (xa,ya) (xb,ya) (xa,yb) (xb,yb), left to right, + 1e-4 last, with
-        //      xa = max(bx-1, 0), xb = min(bx, C-1) -- the same operands in the same order as the reference's n1..n9 ----
-        const int CB = C + 1;
-        for (int t = lane; t < CB * CB; t += 64) {
-            const int byb = t / CB, bxb = t - byb * CB;
-            const int xa = bxb - 1 > 0 ? bxb - 1 : 0, xb = bxb < C - 1 ? bxb : C - 1;
-            const int ya = byb - 1 > 0 ? byb - 1 : 0, yb = byb < C - 1 ? byb : C - 1;
-            const double na = w.nrm[xa + ya * C], nb = w.nrm[xb + ya * C];
-            const double nc = w.nrm[xa + yb * C], nd = w.nrm[xb + yb * C];
-            w.fac[t] = 1.0 / sqrt(na + nb + nc + nd + 1e-4);
-        }
-        wave_sync();
-        // ---- normalise, clamp, emit the 3 (UoCTTI) or 4 (Dalal-Triggs) outputs of every (cell, orientation) ------
-        //      desc is written in the Matlab order of the feature row (adaptive_vlhog.hpp:166-175): [dim][x][y]
-        for (int t = lane; t < O * CC; t += 64) {
-            const int k = t / CC, c = t - k * CC;
-            const int y = c / C, x = c - y * C, ct = x * C + y;
-            const double ha = w.histv[c + k * CC], hb = w.histv[c + (k + O) * CC];
-            // j=0: n1+n2+n4+n5  j=1: n2+n3+n5+n6  j=2: n4+n5+n7+n8  j=3: n5+n6+n8+n9
-            const double f1 = w.fac[x + y * CB], f2 = w.fac[x + 1 + y * CB];
-            const double f3 = w.fac[x + (y + 1) * CB], f4 = w.fac[x + 1 + (y + 1) * CB];
-            double ha1 = f1 * ha, ha2 = f2 * ha, ha3 = f3 * ha, ha4 = f4 * ha;
-            double hb1 = f1 * hb, hb2 = f2 * hb, hb3 = f3 * hb, hb4 = f4 * hb;
-            double hc1 = ha1 + hb1, hc2 = ha2 + hb2, hc3 = ha3 + hb3, hc4 = ha4 + hb4;
-    #define CL02(v) __builtin_fmin(0.2, (v))          /* VL_MIN(0.2, v): the values are finite and non-negative */
-            ha1 = CL02(ha1); ha2 = CL02(ha2); ha3 = CL02(ha3); ha4 = CL02(ha4);
-            hb1 = CL02(hb1); hb2 = CL02(hb2); hb3 = CL02(hb3); hb4 = CL02(hb4);
-            hc1 = CL02(hc1); hc2 = CL02(hc2); hc3 = CL02(hc3); hc4 = CL02(hc4);
-    #undef CL02
-            if (lv.variant == 1) {
-                w.desc[ct + k * CC] = (float)(0.5 * (ha1 + ha2 + ha3 + ha4));
-                w.desc[ct + (k + O) * CC] = (float)(0.5 * (hb1 + hb2 + hb3 + hb4));
-                w.desc[ct + (k + 2 * O) * CC] = (float)(0.5 * (hc1 + hc2 + hc3 + hc4));
-                double* q = w.hcc + (size_t)(k * CC + c) * 4;
-                q[0] = hc1; q[1] = hc2; q[2] = hc3; q[3] = hc4;
-            } else {
-                w.desc[ct + k * CC] = (float)hc1;
-                w.desc[ct + (k + O) * CC] = (float)hc2;
-                w.desc[ct + (k + 2 * O) * CC] = (float)hc3;
-                w.desc[ct + (k + 3 * O) * CC] = (float)hc4;
-            }
-        }
-        wave_sync();
-        // ---- texture features: t_j = sum over k (in order) of the clamped hc_j (hog.c:1020-1023, 1047-1052) ------
-        if (lv.variant == 1) {
-            const float tex = 1.0f / sqrtf(18.0f);
-            for (int t = lane; t < 4 * CC; t += 64) {
-                const int j = t / CC, c = t - j * CC;
-                const int y = c / C, x = c - y * C, ct = x * C + y;
-                double acc = 0.0;
-                for (int k = 0; k < O; ++k) acc += w.hcc[(size_t)(k * CC + c) * 4 + j];
-                w.desc[ct + (3 * O + j) * CC] = (float)(tex * acc);
-            }
-            wave_sync();
-        }
-        mark(4);   // normalisation / extraction
-        // ---- the feature row segment of this landmark: desc is already in its order -------------------------------
-        for (int o = lane; o < lv.P; o += 64) out_desc[o] = w.desc[o];
-        wave_sync();   // the next patch reuses the scratch
+        hog_finish_patch<ACC, TO, TC>(w, hfin_p, histf_p, out_desc, lv, lane);
+        mark(4);   // normalisation / extraction / store
     }
     mark(5);   // output stores
 }
