@@ -5,12 +5,14 @@ import numpy as np
 from superviseddescent_amd import Context, HoGParam, ibug, synth
 ids = ibug.RCR22_IDS; re, le = ibug.eye_indices(ids)
 params = [HoGParam(*p) for p in ibug.SHIPPED_HOG_PARAMS]
+if len(sys.argv) > 1 and sys.argv[1] == "bins31":   # BASELINE config 3: 31-bin VlHog (9 orientations), 5 levels
+    params = [HoGParam(1, 5, c, 9, r) for c, r in ((11, 1.0), (10, 0.7), (8, 0.4), (6, 0.25), (6, 0.25))]
 images, boxes, gt = synth.make_faces(4096, seed=11)
 xs, x0, idx = synth.make_samples(boxes, gt, ids, 0, seed=12)
 ctx = Context(0); ctx.set_model_geometry(len(ids), re, le, params); ctx.upload_images(images); ctx.set_sample_image_index(None); ctx.set_x(x0)
 ctx.enable_timing(True)
 out = []
-for l in range(4):
+for l in range(len(params)):
     for _ in range(3): ctx.hog_features(l)
     ctx.synchronize(); ctx.get_timing(reset=True)
     for _ in range(10): ctx.hog_features(l)

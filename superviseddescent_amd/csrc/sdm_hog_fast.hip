@@ -687,10 +687,16 @@ bool sdm_hog_fast_supported(const HogLevelDev& lv)
     return lv.S >= 4 && lv.S <= 64 && fast_lds_bytes(lv.cell, lv.C, lv.O, lv.D) * HF_WAVES <= 160 * 1024;
 }
 
-// two patches per wave: the ROI fits a half wave and three workgroups still share a CU
+// two patches per wave: the ROI fits a half wave and the CU still holds at least as many patches in flight as with one
+// patch per wave (LDS-limited workgroups per CU x patches per wave)
 static bool hog_fast_pair(const HogLevelDev& lv, int fast_bins)
 {
-    return lv.S <= 32 && fast_bins == 2 && fast_lds_bytes(lv.cell, lv.C, lv.O, lv.D, true) * HF_WAVES * 3 <= 160 * 1024;
+    if (lv.S > 32 || fast_bins != 2) return false;
+    const size_t one = fast_lds_bytes(lv.cell, lv.C, lv.O, lv.D, false) * HF_WAVES;
+    const size_t two = fast_lds_bytes(lv.cell, lv.C, lv.O, lv.D, true) * HF_WAVES;
+    if (two > 160 * 1024) return false;
+    const size_t wg_one = (160 * 1024) / one, wg_two = (160 * 1024) / two;
+    return 2 * wg_two >= wg_one;
 }
 
 void sdm_launch_verify_fast_bins(const HogLevelDev& lv, int* mismatches_dev, hipStream_t stream)
