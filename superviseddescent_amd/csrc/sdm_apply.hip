@@ -258,6 +258,20 @@ __global__ void targets_kernel(const float* __restrict__ x, const float* __restr
     feat[(long long)row * ldf + bcol0 + col] = (xr[col] - xstar[t]) * n;
 }
 
+// ---- the solved regressor R (Fp x Mp, row-major) -> the apply GEMM's operand Rt (Mp x ldf, zero padded beyond F / M) and,
+//      optionally, the compact F x M matrix the caller receives (LinearRegressor::x) --------------------------------
+__global__ void pack_regressor_kernel(const float* __restrict__ Rsol, int F, int M, int Mp, float* __restrict__ Rt,
+                                      long long ldf, float* __restrict__ Rc)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)Mp * ldf) return;
+    const int j = (int)(t / ldf);
+    const long long k = t - (long long)j * ldf;
+    const float v = (k < F && j < M) ? Rsol[k * Mp + j] : 0.0f;
+    Rt[t] = v;
+    if (Rc && k < F && j < M) Rc[k * M + j] = v;
+}
+
 // ---- known-template mode: observed = features - templates (superviseddescent.hpp:195-197, 287-289) ---------------------
 __global__ void subtract_templates_kernel(float* __restrict__ feat, long long ldf, const float* __restrict__ tmpl, int N, int F)
 {
@@ -333,6 +347,12 @@ __global__ void sum_final_kernel(const double* __restrict__ part, int nparts, lo
 }
 
 }  // namespace
+
+void sdm_launch_pack_regressor(const float* Rsol, int F, int M, int Mp, float* Rt, long long ldf, float* Rc, hipStream_t stream)
+{
+    const long long total = (long long)Mp * ldf;
+    hipLaunchKernelGGL(pack_regressor_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, Rsol, F, M, Mp, Rt, ldf, Rc);
+}
 
 void sdm_launch_subtract_templates(float* feat, long long ldf, const float* tmpl, int N, int F, hipStream_t stream)
 {

@@ -764,25 +764,16 @@ int sdm_solve(sdm_ctx* c, int level, int reg_type, float reg_param, int regulari
         sdm_launch_cholesky_solve(c->G.p, ncols, F, Fp, Mp, c->Rsol.p, Mp, c->winv.p, c->status.p, c->stream, &c->solve_aux);
     }
     HIP_TRY(hipGetLastError());
-    // R (Fp x Mp) -> Rt (Mp x ldf), zero padded
-    HIP_TRY(hipMemsetAsync(c->Rt[level].p, 0, (size_t)Mp * c->ldf * sizeof(float), c->stream));
-    std::vector<float> r((size_t)Fp * Mp);
-    HIP_TRY(hipMemcpyAsync(r.data(), c->Rsol.p, r.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if ((rc = check_status(c))) return rc;
-    std::vector<float> t((size_t)Mp * c->ldf, 0.0f);
-    for (int k = 0; k < F; ++k)
-        for (int j = 0; j < M; ++j) t[(size_t)j * c->ldf + k] = r[(size_t)k * Mp + j];
-    HIP_TRY(hipMemcpyAsync(c->Rt[level].p, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    // R (Fp x Mp) -> Rt (Mp x ldf, zero padded: the apply GEMM's operand) on the device; the host copy only on request
+    ScopedBuf<float> rc_dev;
+    if (R_host && (rc = rc_dev.ensure((size_t)F * M))) return rc;
+    sdm_launch_pack_regressor(c->Rsol.p, F, M, Mp, c->Rt[level].p, c->ldf, R_host ? rc_dev.p : nullptr, c->stream);
+    HIP_TRY(hipGetLastError());
+    if (R_host) HIP_TRY(hipMemcpyAsync(R_host, rc_dev.p, (size_t)F * M * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (lambda_out) HIP_TRY(hipMemcpyAsync(lambda_out, c->lambda_dev.p, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if ((rc = check_status(c))) return rc;          // (synchronises the stream)
     c->have_R[level] = true;
     c->g_level = -1;   // G now holds the factor
-    if (R_host)
-        for (int k = 0; k < F; ++k)
-            for (int j = 0; j < M; ++j) R_host[(size_t)k * M + j] = r[(size_t)k * Mp + j];
-    if (lambda_out) {
-        HIP_TRY(hipMemcpy(lambda_out, c->lambda_dev.p, sizeof(float), hipMemcpyDeviceToHost));
-    }
     return SDM_OK;
 }
 

@@ -87,6 +87,8 @@ void sdm_launch_apply(const float* feat, long long ldf, int N, int F, const floa
                       int M, const float* x_in, float* x_out, int L, const EyeIdxDev& eyes,
                       float* partial, int splits, hipStream_t stream);
 
+// Rsol [Fp][Mp] -> Rt [Mp][ldf] (zero padded) and, if Rc != null, the compact [F][M] copy
+void sdm_launch_pack_regressor(const float* Rsol, int F, int M, int Mp, float* Rt, long long ldf, float* Rc, hipStream_t stream);
 // feat[n][0:F] -= tmpl[n][0:F]  (known-template mode, superviseddescent.hpp:195-197)
 void sdm_launch_subtract_templates(float* feat, long long ldf, const float* tmpl, int N, int F, hipStream_t stream);
 
