@@ -96,6 +96,7 @@ int sdm_feature_dim(const sdm_ctx* ctx, int level);          /* F of that level,
  *                        deterministic, within a few ulp of the reference's sequentially rounded sum */
 #define SDM_HOG_EXACT_ORDER 0
 #define SDM_HOG_FAST 1
+#define SDM_HOG_COLUMNS 2
 int sdm_set_hog_mode(sdm_ctx* ctx, int mode);
 /* Which kernel a level runs: *fast_kernel = 1 when the fused S<=64 kernel is used; *fast_bins = the orientation
  * binning method that passed the exhaustive on-device check (511x511 gradients) for that level: 2 = sector count,

@@ -16,7 +16,7 @@ SDM_ERR_INVALID, SDM_ERR_NO_DEVICE, SDM_ERR_HIP, SDM_ERR_EMPTY_PATCH, SDM_ERR_NO
     -1, -2, -3, -4, -5, -6
 SDM_T_HOG, SDM_T_APPLY, SDM_T_GRAM, SDM_T_REG, SDM_T_FACTOR, SDM_T_BACKSOLVE, SDM_T_ALLREDUCE = range(7)
 SDM_T_COUNT = 8
-SDM_HOG_EXACT_ORDER, SDM_HOG_FAST = 0, 1
+SDM_HOG_EXACT_ORDER, SDM_HOG_FAST, SDM_HOG_COLUMNS = 0, 1, 2
 TIMING_NAMES = ["hog", "apply", "gram", "reg", "factor_solve", "backsolve", "allreduce", "_"]
 
 # every symbol include/sdm.h declares (checked by tests/test_capi_symbols.py without a GPU)

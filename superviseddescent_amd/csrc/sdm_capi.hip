@@ -89,6 +89,7 @@ struct sdm_ctx {
     DevBuf<long long> img_off;
     DevBuf<int> img_w, img_h, img_stride;
     int n_images = 0;
+    bool narrow_images = false;   // an image less than 2 pixels wide: the fused kernel's paired-byte loads need w >= 2
     DevBuf<int> img_idx;
     bool idx_identity = true;
 
@@ -225,10 +226,10 @@ int do_hog(sdm_ctx* c, int level)
     }
     {
         Timer t(c, SDM_T_HOG);
-        if (c->fast_kernel[level])
+        if (c->fast_kernel[level] && !c->narrow_images)
             sdm_launch_hog_fast(image_set(c), c->idx_identity ? nullptr : c->img_idx.p, c->x[c->cur].p, c->N, c->L,
                                 c->eyes, c->levels[level], c->feat.p, c->ldf, c->patch_idx.p, c->status.p,
-                                c->hog_mode == SDM_HOG_EXACT_ORDER, c->fast_bins[level], c->stream);
+                                c->hog_mode /* = the kernel's ACC_* value */, c->fast_bins[level], c->stream);
         else   // generic S > 64 geometry: the reference-order kernel
             sdm_launch_hog(image_set(c), c->idx_identity ? nullptr : c->img_idx.p, c->x[c->cur].p, c->N, c->L,
                            c->eyes, c->levels[level], c->feat.p, c->ldf, c->patch_idx.p, c->status.p, c->stream);
@@ -419,7 +420,7 @@ int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int*
 
 int sdm_set_hog_mode(sdm_ctx* c, int mode)
 {
-    if (!c || (mode != SDM_HOG_EXACT_ORDER && mode != SDM_HOG_FAST)) return fail(SDM_ERR_INVALID, "bad HOG mode");
+    if (!c || (mode != SDM_HOG_EXACT_ORDER && mode != SDM_HOG_FAST && mode != SDM_HOG_COLUMNS)) return fail(SDM_ERR_INVALID, "bad HOG mode");
     c->hog_mode = mode;
     return SDM_OK;
 }
@@ -473,6 +474,8 @@ int sdm_upload_images_u8(sdm_ctx* c, const uint8_t* const* images, const int* w,
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->img_base = c->img_owned.p;
     c->n_images = n;
+    c->narrow_images = false;
+    for (int i = 0; i < n; ++i) c->narrow_images = c->narrow_images || w[i] < 2;
     return SDM_OK;
 }
 
@@ -493,6 +496,7 @@ int sdm_set_images_device(sdm_ctx* c, const uint8_t* dev_base, int n, int w, int
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->img_base = dev_base;
     c->n_images = n;
+    c->narrow_images = w < 2;
     return SDM_OK;
 }
 

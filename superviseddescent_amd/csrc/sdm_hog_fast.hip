@@ -24,6 +24,13 @@
 //                       float atomic); the sum is exact and order independent, converted back to f32 with
 //                       ONE rounding.  Differs from the reference's sequentially rounded f32 sum by a few
 //                       ulp at most; integer decisions (ROI geometry, resized bytes, bins) are identical.
+//      ACC_COLUMNS      the spatial interpolation is separated: during the row loop lane x adds g*wy to ITS OWN
+//                       pixel column [bin][x][cell row] -- a plain LDS read / f32 add / write of two neighbouring cell
+//                       rows (ds_read2 / ds_write2; no atomics: nothing is shared between lanes, so the order is fixed
+//                       and the result deterministic), software-pipelined one pixel row behind the gradient; after
+//                       the loop the columns are folded into cells, hist[band][bin][cx] = sum_x col[band][bin][x] *
+//                       W[x][cx], as a (2*O*C x 64) x (64 x 16) product on the matrix cores.  Same integer decisions;
+//                       the f32 roundings happen in a different order ((sum_y g*wy)*wx instead of sum (g*wx)*wy).
 //  * the orientation arg-max uses the un-normalised gradient (gx*ox + gy*oy) when, for the level's
 //    orientation count, that shortcut has been verified on the device to give the reference's bin for
 //    EVERY possible pair of u8 central differences (511 x 511 inputs); otherwise the reference's
@@ -35,14 +42,20 @@
 #pragma clang fp contract(off)
 
 #define HF_WAVES 4
+#define HF_PREFETCH 2
 #define ACC_EXACT_ORDER 0
 #define ACC_FIXED64 1
+#define ACC_COLUMNS 2
+// ACC_COLUMNS layout: f32 [2O bins][ST pixel columns][C cell rows], ST = S rounded up to a multiple of 4 (64 for a landmark
+// pair).  The two cell rows a pixel row feeds are neighbouring dwords (one ds_read2 / ds_write2 with fixed offsets); within
+// one bin the 64 lanes hit banks 5x + const, all distinct.
 
 namespace {
 
 typedef unsigned long long u64;
 typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ inline double ied_of(const float* __restrict__ xr, int L, const EyeIdxDev& e)
 {
@@ -155,7 +168,8 @@ __device__ inline void bin_sector(float gx, float gy, const HogLevelDev& lv, int
     }
     int d = (fx >= 0.0f) ? m : O - m;
     d += flip ? O : 0;
-    bin = d >= 2 * O ? d - 2 * O : d;
+    if (TO > 0 && ((2 * TO) & (2 * TO - 1)) == 0) bin = d & (2 * TO - 1);      // d <= 2O: the wrap is a mask for 2O = 2^k
+    else bin = d >= 2 * O ? d - 2 * O : d;
 }
 
 // per-wave LDS layout.  Region A lives for the whole patch, region B is first the rolling private
@@ -194,13 +208,22 @@ __host__ __device__ inline size_t fast_copies_bytes(int C, int O, bool pair)
 
 // region A (per patch: the finished histogram) x patches, then region B = max(accumulator copies x patches,
 // normalisation scratch of ONE patch: the patches of a pair are normalised one after the other)
-__host__ __device__ inline size_t fast_lds_bytes(int cell, int C, int O, int D, bool pair = false)
+__host__ __device__ inline int fast_columns_stride(int cell, int C, bool pair) { return pair ? 64 : ((C * cell + 3) & ~3); }
+__host__ __device__ inline size_t fast_columns_bytes(int cell, int C, int O, bool pair)
 {
-    (void)cell;
+    return al16((size_t)2 * O * fast_columns_stride(cell, C, pair) * C * 4);
+}
+// ACC_COLUMNS: the column rows overlay regions A and B (they are dead before either is written)
+__host__ __device__ inline size_t fast_lds_bytes(int cell, int C, int O, int D, bool pair = false, bool columns = false)
+{
     const int CC = C * C, np = pair ? 2 : 1;
     const size_t b_rows = np * fast_copies_bytes(C, O, pair);
     const size_t b_norm = al16((size_t)2 * O * CC * 4) + al16((size_t)CC * 4) + al16((size_t)4 * CC * 8) +
                           al16((size_t)O * CC * 4 * 8) + al16((size_t)D * CC * 4);
+    if (columns) {
+        const size_t rest = np * fast_region_a(C, O) + b_norm, cols = fast_columns_bytes(cell, C, O, pair);
+        return cols > rest ? cols : rest;
+    }
     return np * fast_region_a(C, O) + (b_rows > b_norm ? b_rows : b_norm);
 }
 
@@ -243,6 +266,26 @@ __device__ inline void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+// the two source bytes of a 16-bit load -> the two 16-bit halves of a register {b0, 0, b1, 0} (v_perm_b32 reads the loaded
+// register as it is: no zero-extension instruction), ready for v_dot2_u32_u16 with the packed tap weights
+#define HF_SPREAD_SEL 0x0c010c00u
+__device__ inline unsigned spread_bytes(unsigned short v, unsigned sel)
+{
+    unsigned r;
+    u16x2 t;            // (the upper half stays undefined on purpose: a 16 -> 32 bit conversion would cost a v_and)
+    t.x = v;
+    asm("v_perm_b32 %0, 0, %1, %2" : "=v"(r) : "v"(__builtin_bit_cast(unsigned, t)), "v"(sel));
+    return r;
+}
+// (a * b) >> 32 for a, b < 2^24 on the full-rate 24-bit multiplier; a is wave-uniform (scalar operand)
+__device__ inline unsigned mul_hi_u24(unsigned a, unsigned b)
+{
+    unsigned r;
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "s"(a), "v"(b));
+    return r;
 }
 
 __device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -403,6 +446,7 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
     int bxc; float wx1, wx2;          // HOG cell index / bilinear weights of coordinate d   (hog.c:697-704)
     int row_src, row_beta;            // vertical resize taps of coordinate d (packed)
     int px0, px1, a0, a1;             // horizontal resize taps of column d (image columns, masked weights)
+    int pl; unsigned wpk;             // ... as ONE 16-bit load at column pl with the weights of its two bytes packed
     {
         const float hx = (float)((d + 0.5) / (double)cell - 0.5);
         bxc = vl_floor(hx);
@@ -431,16 +475,36 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
         if (px1 < 0 || px1 >= iw || empty) a1 = 0;
         px0 = px0 < 0 ? 0 : (px0 > iw - 1 ? iw - 1 : px0);
         px1 = px1 < 0 ? 0 : (px1 > iw - 1 ? iw - 1 : px1);
+        // Two live taps are neighbours (px1 = px0 + 1): one 16-bit load at px0.  A single live tap p is paired with a
+        // zero-weight neighbour INSIDE the row (the load never crosses the end of the row, hence never the end of the image).
+        if (a0 != 0 && a1 != 0) {
+            pl = px0; wpk = (unsigned)a0 | ((unsigned)a1 << 16);
+        } else {
+            const int p = a0 != 0 ? px0 : px1;
+            const unsigned wt = (unsigned)(a0 != 0 ? a0 : a1);
+            if (p + 1 <= iw - 1 || p == 0) { pl = p; wpk = wt; }       // (p == 0 in a 1-pixel-wide image: see sdm_capi, not used)
+            else { pl = p - 1; wpk = wt << 16; }
+        }
     }
     const float row_w1 = wx1, row_w2 = wx2;   // weights of coordinate d when it is used as a ROW
     const int row_cell = bxc;
+    // ACC_COLUMNS: row d feeds the cell rows (band, band + 1) with the weights (wa, wb); the cell rows -1 and C do not exist
+    // (hog.c:713-724 bounds checks): their share is dropped by pairing the remaining one with a zero weight
+    const int row_band = bxc < 0 ? 0 : (bxc > C - 2 ? C - 2 : bxc);
+    const float row_wa = bxc < 0 ? wx2 : (bxc > C - 2 ? 0.0f : wx1);
+    const float row_wb = bxc < 0 ? 0.0f : (bxc > C - 2 ? wx1 : wx2);
     const bool col_active = (col >= 1) && (col < S - 1) && (!PAIR || half == 0 || second_valid);
     // padded histogram column of this lane (lanes outside the ROI contribute exact zeros to cell 0)
     const int hcol = col_active ? bxc + 1 : 0;
     if (!col_active) { wx1 = 0.0f; wx2 = 0.0f; }
 
     mark(0);   // geometry + per-coordinate tables
-    if (ACC == ACC_FIXED64) {
+    float* colrows = (float*)lds_base;      // ACC_COLUMNS: [2O][ST][C]
+    const int ST = fast_columns_stride(cell, C, PAIR);
+    if (ACC == ACC_COLUMNS) {
+        const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int i = lane; i < (int)(fast_columns_bytes(cell, C, O, PAIR) / 16); i += 64) ((f32x4*)colrows)[i] = z4;
+    } else if (ACC == ACC_FIXED64) {
         // (16-byte stores: both counts are even and both regions 16-byte aligned)
         const u64x2 z2 = {0ull, 0ull};
         for (int i = lane; i < NP * 2 * O * PW * R; i += 64) ((u64x2*)w.copies)[i] = z2;
@@ -481,17 +545,15 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
     // PAIR: y0 differs between the halves, so the row offset cannot sit in the scalar operand.  Each lane keeps
     // px + y0 * stride (possibly negative) and adds the scalar row term; rows above or below the image then fall outside
     // the buffer's num_records and the hardware range check returns 0 -- the black canvas -- without any clamp or mask.
-    const int vb0 = PAIR ? px0 + y0 * istride : 0, vb1 = PAIR ? px1 + y0 * istride : 0;
-    auto issue_row = [&](int y, int& q00, int& q01, int& q10, int& q11, int& bb) {
+    const int vb = PAIR ? pl + y0 * istride : 0;
+    auto issue_row = [&](int y, unsigned short& q0, unsigned short& q1, int& bb) {
         const int yy = y < S ? y : S - 1;
         const int src = __builtin_amdgcn_readlane(row_src, yy);
         int beta = __builtin_amdgcn_readlane(row_beta, yy);
         if (PAIR) {
             const int r0 = (src & 0xffff) * istride, r1 = (src >> 16) * istride;     // scalar
-            q00 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, vb0 + r0, 0, 0);
-            q01 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, vb1 + r0, 0, 0);
-            q10 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, vb0 + r1, 0, 0);
-            q11 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, vb1 + r1, 0, 0);
+            q0 = __builtin_amdgcn_raw_buffer_load_b16(img_rsrc, vb + r0, 0, 0);
+            q1 = __builtin_amdgcn_raw_buffer_load_b16(img_rsrc, vb + r1, 0, 0);
         } else {
             int py0 = y0 + (src & 0xffff), py1 = y0 + (src >> 16);
             // rows on the black canvas: vertical weight 0 (scalar), address clamped into the image
@@ -499,25 +561,30 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
             if (py1 < 0 || py1 >= ih) beta &= 0x0000ffff;
             py0 = py0 < 0 ? 0 : (py0 > ih - 1 ? ih - 1 : py0);
             py1 = py1 < 0 ? 0 : (py1 > ih - 1 ? ih - 1 : py1);
-            const int o0 = py0 * istride, o1 = py1 * istride;
-            q00 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, px0, o0, 0);
-            q01 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, px1, o0, 0);
-            q10 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, px0, o1, 0);
-            q11 = __builtin_amdgcn_raw_buffer_load_b8(img_rsrc, px1, o1, 0);
+            q0 = __builtin_amdgcn_raw_buffer_load_b16(img_rsrc, pl, py0 * istride, 0);
+            q1 = __builtin_amdgcn_raw_buffer_load_b16(img_rsrc, pl, py1 * istride, 0);
         }
         bb = beta;
     };
-    auto finish_row = [&](int q00, int q01, int q10, int q11, int beta) -> float {
-        const int H0 = __mul24(q00, a0) + __mul24(q01, a1);
-        const int H1 = __mul24(q10, a0) + __mul24(q11, a1);
+    // horizontal pass of one output row: byte0 * w0 + byte1 * w1 per source row (the loaded registers are dead afterwards
+    // and take a later row)
+    unsigned spread_sel = HF_SPREAD_SEL;
+    asm volatile("" : "+v"(spread_sel));      // (kept in a register: v_perm_b32 takes no literal selector)
+    const u16x2 wpk2 = __builtin_bit_cast(u16x2, wpk);
+    auto horizontal = [&](unsigned short q0, unsigned short q1, int& H0, int& H1) {
+        H0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, spread_bytes(q0, spread_sel)), wpk2, 0u, false);
+        H1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, spread_bytes(q1, spread_sel)), wpk2, 0u, false);
+    };
+    auto vertical = [&](int H0, int H1, int beta) -> float {
         int out;
         if (area2) {
             const int e0 = (beta & 0xffff) ? 1 : 0, e1 = (beta >> 16) ? 1 : 0;   // row validity survives in beta
             out = (H0 * e0 + H1 * e1 + 2) >> 2;
         } else {
-            const int b0 = beta & 0xffff, b1 = beta >> 16;
-            // operands < 2^24 (b <= 2048, H >> 4 <= 32640): the 24-bit multiplier is exact and full rate
-            out = (int)(((__umul24((unsigned)b0, (unsigned)(H0 >> 4)) >> 16) + (__umul24((unsigned)b1, (unsigned)(H1 >> 4)) >> 16) + 2u) >> 2);
+            // (b * (H >> 4)) >> 16 as the high half of the 48-bit product (b << 12) * (H & ~15): b <= 2048 and H < 2^19, so
+            // both operands fit the full-rate 24-bit multiplier and the separate shifts disappear
+            const unsigned b0 = (unsigned)(beta & 0xffff) << 12, b1 = (unsigned)(beta >> 16) << 12;      // scalar
+            out = (int)((mul_hi_u24(b0, (unsigned)H0 & ~15u) + mul_hi_u24(b1, (unsigned)H1 & ~15u) + 2u) >> 2);
         }
         return (float)out;      // convertTo(CV_32F), adaptive_vlhog.hpp:157
     };
@@ -525,12 +592,33 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
     double two52 = 4503599627370496.0;   // 2^52, kept in a register pair for the fixed-point conversion
     asm volatile("" : "+v"(two52));       // (opaque to the optimiser so that it is not re-materialised per use)
     float rm2 = 0.0f, rm1 = 0.0f;       // resized rows y-2, y-1 of this lane's column
-    int n00, n01, n10, n11, nbeta;
-    issue_row(0, n00, n01, n10, n11, nbeta);
-    for (int y = 0; y < S; ++y) {
-        const int c00 = n00, c01 = n01, c10 = n10, c11 = n11, cbeta = nbeta;
-        issue_row(y + 1, n00, n01, n10, n11, nbeta);               // prefetch (clamped past the last row)
-        const float r0 = finish_row(c00, c01, c10, c11, cbeta);
+    // ACC_COLUMNS: the contribution of the previous pixel row, added while this row's gradient is computed
+    // (lanes beyond the ROI share column 0, which is never active: its sums are finite garbage with fold weight 0)
+    const unsigned col_off = (unsigned)(PAIR ? lane : (col < S ? col : 0)) * (unsigned)(C * 4);
+    const unsigned bin_stride = (unsigned)(ST * C * 4);
+    float* pend_p = (float*)((unsigned char*)colrows + col_off);
+    float pend_a = 0.0f, pend_b = 0.0f;
+    // The source bytes of a row are requested HF_PREFETCH rows ahead (depths 1, 2 and 4 measure alike: the loop is bound by
+    // instruction issue, not by the load latency); the row group is unrolled so that each row's bytes and the two previous
+    // resized rows stay in fixed registers (no rotation copies).
+    constexpr int PD = HF_PREFETCH;
+    unsigned short q0[PD], q1[PD];
+    int qbeta[PD];
+#pragma unroll
+    for (int j = 0; j < PD; ++j) issue_row(j, q0[j], q1[j], qbeta[j]);
+    for (int yb = 0; yb < S; yb += PD) {
+#pragma unroll
+      for (int j = 0; j < PD; ++j) {
+        const int y = yb + j;
+        if (y >= S) break;                                           // (wave-uniform)
+        int H0, H1;
+        horizontal(q0[j], q1[j], H0, H1);
+        const int cbeta = qbeta[j];
+        if (y + PD < S) issue_row(y + PD, q0[j], q1[j], qbeta[j]);
+        float qa = 0.0f, qb = 0.0f;
+        if (ACC == ACC_COLUMNS) { qa = pend_p[0]; qb = pend_p[1]; }     // (in flight during the arithmetic below)
+        const float r0 = vertical(H0, H1, cbeta);
+        if (ACC == ACC_COLUMNS && y < 2) { pend_p[0] = qa + pend_a; pend_p[1] = qb + pend_b; }
         if (y >= 2) {
             // gradient of row yy = y-1 (hog.c:616-672)
             const int yy = y - 1;
@@ -570,6 +658,19 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
             if (FASTBIN != 2 && (!col_active || bin < 0)) { g = 0.0f; bin = 0; }
             const int by = __builtin_amdgcn_readlane(row_cell, yy);
             const float wy1 = lane_f(row_w1, yy), wy2 = lane_f(row_w2, yy);
+            if (ACC == ACC_COLUMNS) {
+                pend_p[0] = qa + pend_a; pend_p[1] = qb + pend_b;
+                // this row: g * (wa, wb) into the cell rows (band, band + 1) of this lane's own column, next iteration
+                // (24-bit multiply-add on the bin + the lane's byte offset; the cell-row term is scalar)
+                const int band = __builtin_amdgcn_readlane(row_band, yy);
+                const float wa = lane_f(row_wa, yy), wb = lane_f(row_wb, yy);
+                const unsigned a = __umul24((unsigned)bin, bin_stride) + col_off;
+                pend_p = (float*)((unsigned char*)colrows + (a + (unsigned)band * 4u));
+                const f32x2 pv = (f32x2){wa, wb} * g;
+                pend_a = pv.x; pend_b = pv.y;
+                rm2 = rm1; rm1 = r0;
+                continue;
+            }
             // (grad * wx) * wy, hog.c:714-723: six f32 products as three packed multiplies
             const f32x2 t = (f32x2){wx2, wx1} * g;
             const f32x2 ab = t * wy1, cd = t * wy2;
@@ -611,10 +712,61 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
             }
         }
         rm2 = rm1; rm1 = r0;
+      }
     }
     if (ACC == ACC_FIXED64 && cur_by != -2) { flush_band(cur_by); flush_band(cur_by + 1); }
+    if (ACC == ACC_COLUMNS) { pend_p[0] += pend_a; pend_p[1] += pend_b; }
     mark(2);   // row loop
     wave_sync();
+    if (ACC == ACC_COLUMNS) {
+        // ---- fold the pixel columns into cells on the matrix cores: D[r][n] = sum_x col[r][x] * W[x][n], r = bin*C + band,
+        //      n = patch * C + cell column.  v_mfma_f32_16x16x4_f32: lane (li, lq) feeds A[row li][k lq], B[k lq][col li] and
+        //      receives D[row 4*lq + e][col li].  W[x][n] = wx1(x) if cell(x) == n, wx2(x) if cell(x) + 1 == n (hog.c:697-704),
+        //      fetched from lane x (the lane that owns coordinate x) with ds_bpermute.
+        constexpr int NT = (TC * 2 * TO + 15) / 16;
+        const int nrows = C * 2 * O;
+        const int li = lane & 15, lq = lane >> 4;
+        const int hp_n = li / C, cx_n = li - hp_n * C;
+        f32x4 accf[NT > 0 ? NT : 1];
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) accf[mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        const float* arow[NT > 0 ? NT : 1];
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) {
+            int r = 16 * mt + li;
+            r = r < nrows ? r : nrows - 1;
+            const int kb = r / C, band = r - kb * C;
+            arow[mt] = colrows + (kb * ST + lq) * C + band;
+        }
+        const int nks = ST / 4;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            if (ks < nks) {                       // (wave-uniform)
+                const int xs = 4 * ks + lq;
+                const int cellx = __builtin_amdgcn_ds_bpermute(xs * 4, bxc);
+                const float w1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(xs * 4, __builtin_bit_cast(int, wx1)));
+                const float w2 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(xs * 4, __builtin_bit_cast(int, wx2)));
+                float b = cellx == cx_n ? w1 : (cellx + 1 == cx_n ? w2 : 0.0f);
+                if (hp_n >= NP || (PAIR && (xs >> 5) != hp_n)) b = 0.0f;
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt)
+                    accf[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[mt][4 * ks * C], b, accf[mt], 0, 0, 0);
+            }
+        }
+        wave_sync();    // every column is read before the finished histograms overwrite the region
+        if (hp_n < NP) {
+            float* hf = (float*)((unsigned char*)w.hfin + (size_t)hp_n * a_bytes);
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 16 * mt + 4 * lq + e;
+                    const int kb = r / C, band = r - kb * C;
+                    if (r < nrows) hf[kb * PWW + (band + 1) * PW + cx_n + 1] = accf[mt][e];
+                }
+        }
+        wave_sync();
+    }
     mark(3);   // barrier after the row loop
 
     // ---- per patch (one after the other in PAIR mode: they share the normalisation scratch) ------------------------
@@ -689,11 +841,11 @@ bool sdm_hog_fast_supported(const HogLevelDev& lv)
 
 // two patches per wave: the ROI fits a half wave and the CU still holds at least as many patches in flight as with one
 // patch per wave (LDS-limited workgroups per CU x patches per wave)
-static bool hog_fast_pair(const HogLevelDev& lv, int fast_bins)
+static bool hog_fast_pair(const HogLevelDev& lv, int fast_bins, bool columns = false)
 {
     if (lv.S > 32 || fast_bins != 2) return false;
-    const size_t one = fast_lds_bytes(lv.cell, lv.C, lv.O, lv.D, false) * HF_WAVES;
-    const size_t two = fast_lds_bytes(lv.cell, lv.C, lv.O, lv.D, true) * HF_WAVES;
+    const size_t one = fast_lds_bytes(lv.cell, lv.C, lv.O, lv.D, false, columns) * HF_WAVES;
+    const size_t two = fast_lds_bytes(lv.cell, lv.C, lv.O, lv.D, true, columns) * HF_WAVES;
     if (two > 160 * 1024) return false;
     const size_t wg_one = (160 * 1024) / one, wg_two = (160 * 1024) / two;
     return 2 * wg_two >= wg_one;
@@ -708,11 +860,14 @@ void sdm_launch_verify_fast_bins(const HogLevelDev& lv, int* mismatches_dev, hip
 template <int TO, int TC>
 static void launch_fast_oc(const ImageSetDev& imgs, const int* img_idx, const float* x, int N, int L,
                            const EyeIdxDev& eyes, const HogLevelDev& lv, float* feat, long long ldf, int* idx_out,
-                           int* status, int exact_order, int fast_bins, hipStream_t stream)
+                           int* status, int acc_mode, int fast_bins, hipStream_t stream)
 {
-    const bool pair = hog_fast_pair(lv, fast_bins);
+    // column sums need the compile-time geometry (MFMA tile count) and both patches' cell columns in 16 MFMA columns
+    const bool columns = acc_mode == ACC_COLUMNS && TO > 0 && TC > 0 && 2 * TC <= 16;
+    const bool exact_order = acc_mode == ACC_EXACT_ORDER;
+    const bool pair = hog_fast_pair(lv, fast_bins, columns);
     const long long total = (long long)N * (pair ? (L + 1) / 2 : L);
-    const size_t per = fast_lds_bytes(lv.cell, lv.C, lv.O, lv.D, pair);
+    const size_t per = fast_lds_bytes(lv.cell, lv.C, lv.O, lv.D, pair, columns);
     const unsigned grid = (unsigned)((total + HF_WAVES - 1) / HF_WAVES);
     const dim3 g(grid), b(HF_WAVES * 64);
     const size_t lds = per * HF_WAVES;
@@ -722,14 +877,23 @@ static void launch_fast_oc(const ImageSetDev& imgs, const int* img_idx, const fl
         HATTR(ACC_EXACT_ORDER, 0, false); HATTR(ACC_EXACT_ORDER, 1, false); HATTR(ACC_EXACT_ORDER, 2, false);
         HATTR(ACC_FIXED64, 0, false); HATTR(ACC_FIXED64, 1, false); HATTR(ACC_FIXED64, 2, false);
         HATTR(ACC_EXACT_ORDER, 2, true); HATTR(ACC_FIXED64, 2, true);
+        if constexpr (TO > 0) { HATTR(ACC_COLUMNS, 0, false); HATTR(ACC_COLUMNS, 1, false); HATTR(ACC_COLUMNS, 2, false); HATTR(ACC_COLUMNS, 2, true); }
 #undef HATTR
     }
 #define LAUNCH(ACC, FB, P)                                                                                               \
     hipLaunchKernelGGL((hog_fast_kernel<ACC, FB, TO, TC, P>), g, b, lds, stream, imgs, img_idx, x, N, L, eyes, lv, feat, \
                        ldf, idx_out, status, per)
-    if (pair) { if (exact_order) LAUNCH(ACC_EXACT_ORDER, 2, true); else LAUNCH(ACC_FIXED64, 2, true); }
-    else if (exact_order) { if (fast_bins == 2) LAUNCH(ACC_EXACT_ORDER, 2, false); else if (fast_bins == 1) LAUNCH(ACC_EXACT_ORDER, 1, false); else LAUNCH(ACC_EXACT_ORDER, 0, false); }
-    else { if (fast_bins == 2) LAUNCH(ACC_FIXED64, 2, false); else if (fast_bins == 1) LAUNCH(ACC_FIXED64, 1, false); else LAUNCH(ACC_FIXED64, 0, false); }
+#define LAUNCH_ACC(ACC)                                                                    \
+    do {                                                                                   \
+        if (pair) LAUNCH(ACC, 2, true);                                                    \
+        else if (fast_bins == 2) LAUNCH(ACC, 2, false);                                    \
+        else if (fast_bins == 1) LAUNCH(ACC, 1, false);                                    \
+        else LAUNCH(ACC, 0, false);                                                        \
+    } while (0)
+    if (exact_order) LAUNCH_ACC(ACC_EXACT_ORDER);
+    else if (columns) { if constexpr (TO > 0) LAUNCH_ACC(ACC_COLUMNS); }
+    else LAUNCH_ACC(ACC_FIXED64);
+#undef LAUNCH_ACC
 #undef LAUNCH
 }
 
@@ -748,15 +912,15 @@ void sdm_launch_hog_fast_profile(const ImageSetDev& imgs, const int* img_idx, co
 
 void sdm_launch_hog_fast(const ImageSetDev& imgs, const int* img_idx, const float* x, int N, int L,
                          const EyeIdxDev& eyes, const HogLevelDev& lv, float* feat, long long ldf, int* idx_out,
-                         int* status, int exact_order, int fast_bins, hipStream_t stream)
+                         int* status, int acc_mode, int fast_bins, hipStream_t stream)
 {
     if ((long long)N * L <= 0) return;
     // specialised instances for the shipped (4 orientations) and the "31-bin" (9 orientations) 5x5-cell geometry
     const bool small_cell = lv.cell <= 13;   // the specialised instances rely on cell^2 * 361 < 2^16 (see fx)
     if (lv.O == 4 && lv.C == 5 && small_cell)
-        launch_fast_oc<4, 5>(imgs, img_idx, x, N, L, eyes, lv, feat, ldf, idx_out, status, exact_order, fast_bins, stream);
+        launch_fast_oc<4, 5>(imgs, img_idx, x, N, L, eyes, lv, feat, ldf, idx_out, status, acc_mode, fast_bins, stream);
     else if (lv.O == 9 && lv.C == 5 && small_cell)
-        launch_fast_oc<9, 5>(imgs, img_idx, x, N, L, eyes, lv, feat, ldf, idx_out, status, exact_order, fast_bins, stream);
+        launch_fast_oc<9, 5>(imgs, img_idx, x, N, L, eyes, lv, feat, ldf, idx_out, status, acc_mode, fast_bins, stream);
     else
-        launch_fast_oc<0, 0>(imgs, img_idx, x, N, L, eyes, lv, feat, ldf, idx_out, status, exact_order, fast_bins, stream);
+        launch_fast_oc<0, 0>(imgs, img_idx, x, N, L, eyes, lv, feat, ldf, idx_out, status, acc_mode, fast_bins, stream);
 }

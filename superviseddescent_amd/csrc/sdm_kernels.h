@@ -56,8 +56,9 @@ void sdm_launch_hog(const ImageSetDev& imgs, const int* img_idx, const float* x,
                     const EyeIdxDev& eyes, const HogLevelDev& lv, float* feat, long long ldf,
                     int* idx_out, int* status, hipStream_t stream);
 
-// Production kernel (sdm_hog_fast.hip), S <= 64.  exact_order: accumulate with ds_add_f32 in the reference's
-// raster order (bit-identical histogram) instead of the exact 2^-36 fixed-point sum; fast_bins: use the
+// Production kernel (sdm_hog_fast.hip), S <= 64.  acc_mode (= SDM_HOG_*): 0 accumulate with ds_add_f32 in the reference's
+// raster order (bit-identical histogram), 1 the exact 2^-36 fixed-point sum, 2 per-pixel-column f32 sums folded into
+// cells on the matrix cores (specialised geometries only; others fall back to 1); fast_bins: use the
 // cheaper orientation binning (1 = un-normalised arg-max, 2 = first-quadrant sector count; each only when
 // sdm_launch_verify_fast_bins counted 0 mismatches for it; 0 = the reference arithmetic).
 bool sdm_hog_fast_supported(const HogLevelDev& lv);
@@ -65,7 +66,7 @@ bool sdm_hog_fast_supported(const HogLevelDev& lv);
 void sdm_launch_verify_fast_bins(const HogLevelDev& lv, int* mismatches_dev, hipStream_t stream);
 void sdm_launch_hog_fast(const ImageSetDev& imgs, const int* img_idx, const float* x, int N, int L,
                          const EyeIdxDev& eyes, const HogLevelDev& lv, float* feat, long long ldf, int* idx_out,
-                         int* status, int exact_order, int fast_bins, hipStream_t stream);
+                         int* status, int acc_mode, int fast_bins, hipStream_t stream);
 
 void sdm_launch_hog_fast_profile(const ImageSetDev& imgs, const int* img_idx, const float* x, int N, int L,
                                  const EyeIdxDev& eyes, const HogLevelDev& lv, float* feat, long long ldf,

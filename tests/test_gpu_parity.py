@@ -10,7 +10,7 @@ import pytest
 from oracle import sdm_oracle as orc
 from superviseddescent_amd import (Context, HoGParam, HogTransform, LinearRegressor, Regulariser, SdmError,
                                    SupervisedDescentOptimiser, detection_model, ibug, synth)
-from superviseddescent_amd._lib import SDM_HOG_EXACT_ORDER, SDM_HOG_FAST
+from superviseddescent_amd._lib import SDM_HOG_COLUMNS, SDM_HOG_EXACT_ORDER, SDM_HOG_FAST
 
 pytestmark = pytest.mark.gpu
 
@@ -35,7 +35,7 @@ def check_features(ctx_mode, got, want):
         assert rel_l2(got, want) <= 5e-7
 
 
-@pytest.fixture(params=[SDM_HOG_EXACT_ORDER, SDM_HOG_FAST], ids=["exact_order", "fast"])
+@pytest.fixture(params=[SDM_HOG_EXACT_ORDER, SDM_HOG_FAST, SDM_HOG_COLUMNS], ids=["exact_order", "fast", "columns"])
 def hog_mode(request, gpu_ctx):
     gpu_ctx.set_hog_mode(request.param)
     yield request.param
