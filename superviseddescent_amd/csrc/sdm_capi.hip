@@ -78,7 +78,7 @@ struct sdm_ctx {
     std::vector<sdm_hog_param> params;
     std::vector<int> fast_kernel;   // per level: fused S<=64 kernel usable
     std::vector<int> fast_bins;     // per level: un-normalised arg-max verified on all 511x511 gradients
-    int hog_mode = SDM_HOG_FAST;
+    int hog_mode = SDM_HOG_COLUMNS;
     int Fmax = 0;
     long long ldf = 0;      // feature row stride: round_up(Fmax,128) + 128*rhs_tiles (tail tiles = training targets)
     int rhs_tiles = 1;      // 128-column tiles that hold the 2L target columns (2 when 2L > 128)

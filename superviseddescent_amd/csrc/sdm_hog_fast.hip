@@ -42,7 +42,7 @@
 #pragma clang fp contract(off)
 
 #define HF_WAVES 4
-#define HF_PREFETCH 2
+#define HF_PREFETCH 2   /* rows in flight = rows per unrolled group (the slot of row y is y & 1) */
 #define ACC_EXACT_ORDER 0
 #define ACC_FIXED64 1
 #define ACC_COLUMNS 2
@@ -461,13 +461,15 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
         int sy1 = s + 1 < 0 ? 0 : (s + 1 > sw - 1 ? sw - 1 : s + 1);
         if (area2) { sy0 = 2 * d; sy1 = 2 * d + 1; }
         row_src = sy0 | (sy1 << 16);
-        row_beta = (c0 & 0xffff) | (c1 << 16);
+        row_beta = area2 ? (1024 | (1024 << 16)) : ((c0 & 0xffff) | (c1 << 16));
         // horizontal taps: clamped in the table
         int sx = s;
         a0 = c0; a1 = c1;
         if (sx < 0) { sx = 0; a0 = 2048; a1 = 0; }
         if (sx >= sw - 1) { sx = sw - 1; a0 = 2048; a1 = 0; }
-        if (area2) { sx = 2 * d; a0 = 1; a1 = 1; }
+        // exact 2x reduction (INTER_AREA 2x2 box): with all four weights 1024 the bilinear fixed-point formula below gives
+        // exactly (p00 + p01 + p10 + p11 + 2) >> 2 -- (1024 * (1024 * s >> 4)) >> 16 = s -- so the row loop needs no second form
+        if (area2) { sx = 2 * d; a0 = 1024; a1 = 1024; }
         const int sx1 = (sx + 1 < sw) ? sx + 1 : sx;
         px0 = x0 + sx; px1 = x0 + sx1;
         // columns on the black canvas (or an empty patch) get weight 0 instead of a per-row mask
@@ -576,16 +578,10 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
         H1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, spread_bytes(q1, spread_sel)), wpk2, 0u, false);
     };
     auto vertical = [&](int H0, int H1, int beta) -> float {
-        int out;
-        if (area2) {
-            const int e0 = (beta & 0xffff) ? 1 : 0, e1 = (beta >> 16) ? 1 : 0;   // row validity survives in beta
-            out = (H0 * e0 + H1 * e1 + 2) >> 2;
-        } else {
-            // (b * (H >> 4)) >> 16 as the high half of the 48-bit product (b << 12) * (H & ~15): b <= 2048 and H < 2^19, so
-            // both operands fit the full-rate 24-bit multiplier and the separate shifts disappear
-            const unsigned b0 = (unsigned)(beta & 0xffff) << 12, b1 = (unsigned)(beta >> 16) << 12;      // scalar
-            out = (int)((mul_hi_u24(b0, (unsigned)H0 & ~15u) + mul_hi_u24(b1, (unsigned)H1 & ~15u) + 2u) >> 2);
-        }
+        // (b * (H >> 4)) >> 16 as the high half of the 48-bit product (b << 12) * (H & ~15): b <= 2048 and H < 2^19, so
+        // both operands fit the full-rate 24-bit multiplier and the separate shifts disappear
+        const unsigned b0 = (unsigned)(beta & 0xffff) << 12, b1 = (unsigned)(beta >> 16) << 12;      // scalar
+        const int out = (int)((mul_hi_u24(b0, (unsigned)H0 & ~15u) + mul_hi_u24(b1, (unsigned)H1 & ~15u) + 2u) >> 2);
         return (float)out;      // convertTo(CV_32F), adaptive_vlhog.hpp:157
     };
 
@@ -598,28 +594,24 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
     const unsigned bin_stride = (unsigned)(ST * C * 4);
     float* pend_p = (float*)((unsigned char*)colrows + col_off);
     float pend_a = 0.0f, pend_b = 0.0f;
-    // The source bytes of a row are requested HF_PREFETCH rows ahead (depths 1, 2 and 4 measure alike: the loop is bound by
-    // instruction issue, not by the load latency); the row group is unrolled so that each row's bytes and the two previous
-    // resized rows stay in fixed registers (no rotation copies).
+    // Rows are processed in pairs: each row's two source loads and the two previous resized rows stay in fixed registers (no
+    // rotation copies), the pair is one straight-line block the scheduler can interleave (row y+1's resize does not depend on
+    // row y's gradient), and the loads of row y+2 are issued as soon as row y's bytes are consumed.  (Deeper prefetch
+    // measures the same: the loop is bound by instruction issue, not by the load latency.)
     constexpr int PD = HF_PREFETCH;
     unsigned short q0[PD], q1[PD];
     int qbeta[PD];
 #pragma unroll
     for (int j = 0; j < PD; ++j) issue_row(j, q0[j], q1[j], qbeta[j]);
-    for (int yb = 0; yb < S; yb += PD) {
-#pragma unroll
-      for (int j = 0; j < PD; ++j) {
-        const int y = yb + j;
-        if (y >= S) break;                                           // (wave-uniform)
+    auto row_step = [&](const int j, const int y, const bool grad) __attribute__((always_inline)) {
         int H0, H1;
         horizontal(q0[j], q1[j], H0, H1);
         const int cbeta = qbeta[j];
-        if (y + PD < S) issue_row(y + PD, q0[j], q1[j], qbeta[j]);
+        issue_row(y + PD, q0[j], q1[j], qbeta[j]);      // (past the last row: a harmless reload of row S-1)
         float qa = 0.0f, qb = 0.0f;
-        if (ACC == ACC_COLUMNS) { qa = pend_p[0]; qb = pend_p[1]; }     // (in flight during the arithmetic below)
+        if (ACC == ACC_COLUMNS && grad) { qa = pend_p[0]; qb = pend_p[1]; }     // (in flight during the arithmetic below)
         const float r0 = vertical(H0, H1, cbeta);
-        if (ACC == ACC_COLUMNS && y < 2) { pend_p[0] = qa + pend_a; pend_p[1] = qb + pend_b; }
-        if (y >= 2) {
+        if (grad) {
             // gradient of row yy = y-1 (hog.c:616-672)
             const int yy = y - 1;
             const float gx = from_right(rm1) - from_left(rm1);
@@ -668,9 +660,7 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
                 pend_p = (float*)((unsigned char*)colrows + (a + (unsigned)band * 4u));
                 const f32x2 pv = (f32x2){wa, wb} * g;
                 pend_a = pv.x; pend_b = pv.y;
-                rm2 = rm1; rm1 = r0;
-                continue;
-            }
+            } else {
             // (grad * wx) * wy, hog.c:714-723: six f32 products as three packed multiplies
             const f32x2 t = (f32x2){wx2, wx1} * g;
             const f32x2 ab = t * wy1, cd = t * wy2;
@@ -710,10 +700,18 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
                 if (vc != 0.0f) atomicAdd(&histf[base + PW + 1], vc);
                 if (vd != 0.0f) atomicAdd(&histf[base + PW], vd);
             }
+            }
         }
         rm2 = rm1; rm1 = r0;
-      }
+    };
+    row_step(0, 0, false);
+    row_step(1, 1, false);
+    int yrow = 2;
+    for (; yrow + 1 < S; yrow += 2) {
+        row_step(0, yrow, true);
+        row_step(1, yrow + 1, true);
     }
+    if (yrow < S) row_step(0, yrow, true);
     if (ACC == ACC_FIXED64 && cur_by != -2) { flush_band(cur_by); flush_band(cur_by + 1); }
     if (ACC == ACC_COLUMNS) { pend_p[0] += pend_a; pend_p[1] += pend_b; }
     mark(2);   // row loop
@@ -904,9 +902,12 @@ void sdm_launch_hog_fast_profile(const ImageSetDev& imgs, const int* img_idx, co
 {
     const long long total = (long long)N * L;
     if (total <= 0 || !(lv.O == 4 && lv.C == 5)) return;
-    const size_t per = fast_lds_bytes(lv.cell, lv.C, lv.O, lv.D);
+    const size_t per = fast_lds_bytes(lv.cell, lv.C, lv.O, lv.D, false, true);
     const unsigned grid = (unsigned)((total + HF_WAVES - 1) / HF_WAVES);
-    hipLaunchKernelGGL((hog_fast_kernel<ACC_FIXED64, 2, 4, 5, false, true>), dim3(grid), dim3(HF_WAVES * 64), per * HF_WAVES,
+    static unsigned long long attr_seen = 0;
+    if (sdm_first_use_on_device(attr_seen))
+        (void)hipFuncSetAttribute((const void*)hog_fast_kernel<ACC_COLUMNS, 2, 4, 5, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((hog_fast_kernel<ACC_COLUMNS, 2, 4, 5, false, true>), dim3(grid), dim3(HF_WAVES * 64), per * HF_WAVES,
                        stream, imgs, img_idx, x, N, L, eyes, lv, feat, ldf, (int*)nullptr, status, per, prof_dev);
 }
 

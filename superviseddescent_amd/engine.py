@@ -94,8 +94,9 @@ class Context:
         self.L, self.n_levels = num_landmarks, len(hog_params)
 
     def set_hog_mode(self, mode: int):
-        """``_lib.SDM_HOG_FAST`` (default: exact fixed-point sum, rounded once) or ``_lib.SDM_HOG_EXACT_ORDER``
-        (reference accumulation order, features bit-identical to the reference's CPU path)."""
+        """``_lib.SDM_HOG_COLUMNS`` (default: per-pixel-column f32 sums folded into cells on the matrix cores),
+        ``_lib.SDM_HOG_FAST`` (exact fixed-point sum, rounded once) or ``_lib.SDM_HOG_EXACT_ORDER`` (reference
+        accumulation order, features bit-identical to the reference's CPU path)."""
         check(self._lib.sdm_set_hog_mode(self._h, int(mode)))
 
     def hog_info(self, level: int):

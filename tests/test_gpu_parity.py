@@ -39,7 +39,7 @@ def check_features(ctx_mode, got, want):
 def hog_mode(request, gpu_ctx):
     gpu_ctx.set_hog_mode(request.param)
     yield request.param
-    gpu_ctx.set_hog_mode(SDM_HOG_FAST)
+    gpu_ctx.set_hog_mode(SDM_HOG_COLUMNS)
 
 
 def rel_l2(a, b):
@@ -507,7 +507,7 @@ def test_non_adaptive_example_transform(gpu_ctx, faces):
     images, boxes, gt, x_star, x0 = faces
     params = [(1, 3, 12, 4, 0.0), (1, 5, 6, 9, 0.0)]
     oparams = [orc.HoGParam(*p) for p in params]
-    for mode in (SDM_HOG_EXACT_ORDER, SDM_HOG_FAST):
+    for mode in (SDM_HOG_EXACT_ORDER, SDM_HOG_FAST, SDM_HOG_COLUMNS):
         gpu_ctx.set_model_geometry(len(IDS), [], [], [HoGParam(*p) for p in params])
         gpu_ctx.set_hog_mode(mode)
         gpu_ctx.upload_images(images)
@@ -522,7 +522,7 @@ def test_non_adaptive_example_transform(gpu_ctx, faces):
             gidx = gpu_ctx.patch_indices()
             assert np.array_equal(gidx, widx) and (gidx[:, 0] == op.num_cells * (op.cell_size // 2)).all()
             check_features(mode, got, want)
-    gpu_ctx.set_hog_mode(SDM_HOG_FAST)
+    gpu_ctx.set_hog_mode(SDM_HOG_COLUMNS)
     with pytest.raises(SdmError):                                    # odd cell size: the unresized ROI has another cell grid
         gpu_ctx.set_model_geometry(len(IDS), [], [], [HoGParam(1, 3, 11, 4, 0.0)])
     with pytest.raises(SdmError):                                    # the adaptive transform needs the eyes
