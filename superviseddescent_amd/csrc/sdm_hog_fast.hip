@@ -25,12 +25,15 @@
 //                       ONE rounding.  Differs from the reference's sequentially rounded f32 sum by a few
 //                       ulp at most; integer decisions (ROI geometry, resized bytes, bins) are identical.
 //      ACC_COLUMNS      the spatial interpolation is separated: during the row loop lane x adds g*wy to ITS OWN
-//                       pixel column [bin][x][cell row] -- a plain LDS read / f32 add / write of two neighbouring cell
-//                       rows (ds_read2 / ds_write2; no atomics: nothing is shared between lanes, so the order is fixed
-//                       and the result deterministic), software-pipelined one pixel row behind the gradient; after
-//                       the loop the columns are folded into cells, hist[band][bin][cx] = sum_x col[band][bin][x] *
-//                       W[x][cx], as a (2*O*C x 64) x (64 x 16) product on the matrix cores.  Same integer decisions;
-//                       the f32 roundings happen in a different order ((sum_y g*wy)*wx instead of sum (g*wx)*wy).
+//                       pixel column [bin][x][band slot] -- a plain 8-byte LDS read / two f32 adds / write of the two
+//                       cell rows (bands) the pixel row feeds, no atomics: nothing is shared between lanes, so the order
+//                       is fixed and the result deterministic; the read-modify-write runs one pixel row behind the
+//                       gradient.  Only two bands are live at a time (slot = band & 1): when the rows leave a band its
+//                       columns are folded into cells, hist[bin][band][cx] = sum_x col[bin][x] * W[x][cx], as a
+//                       (2O x 64) x (64 x 16) product on the matrix cores, and the slot is cleared for band + 2.  Same
+//                       integer decisions; the f32 roundings happen in a different order ((sum_y g*wy)*wx instead of
+//                       sum (g*wx)*wy).  Per wave this needs 2O*S*8 bytes of LDS instead of a histogram per lane group,
+//                       which is what lets 6-7 waves per SIMD stay resident.
 //  * the orientation arg-max uses the un-normalised gradient (gx*ox + gy*oy) when, for the level's
 //    orientation count, that shortcut has been verified on the device to give the reference's bin for
 //    EVERY possible pair of u8 central differences (511 x 511 inputs); otherwise the reference's
@@ -46,9 +49,9 @@
 #define ACC_EXACT_ORDER 0
 #define ACC_FIXED64 1
 #define ACC_COLUMNS 2
-// ACC_COLUMNS layout: f32 [2O bins][ST pixel columns][C cell rows], ST = S rounded up to a multiple of 4 (64 for a landmark
-// pair).  The two cell rows a pixel row feeds are neighbouring dwords (one ds_read2 / ds_write2 with fixed offsets); within
-// one bin the 64 lanes hit banks 5x + const, all distinct.
+// ACC_COLUMNS: the fold weights W[x][n] (n = patch * C + cell column, 16 columns) are the same for every patch of a
+// launch; one copy per workgroup behind the waves' private regions
+#define HF_WT_BYTES (64 * 16 * 4)
 
 namespace {
 
@@ -206,25 +209,39 @@ __host__ __device__ inline size_t fast_copies_bytes(int C, int O, bool pair)
     return al16((size_t)2 * 2 * O * (C + 2) * copies_R(pair) * 8);
 }
 
+// ---- ACC_COLUMNS per-wave layout: [ column rows f32 [2O][ST][2 band slots] | later: nrm, fac, desc of the finish phase ]
+//      [ finished histograms f32 [patches][2O][C*C] ] ----
+__host__ __device__ inline int fast_columns_stride(int cell, int C, bool pair) { return pair ? 64 : ((C * cell + 7) & ~7); }
+__host__ __device__ inline size_t fast_columns_rows_bytes(int cell, int C, int O, bool pair)
+{
+    return al16((size_t)2 * O * fast_columns_stride(cell, C, pair) * 8);
+}
+__host__ __device__ inline size_t fast_columns_scratch_bytes(int C, int D)
+{
+    return al16((size_t)C * C * 4) + al16((size_t)(C + 1) * (C + 1) * 8) + al16((size_t)D * C * C * 4);
+}
+__host__ __device__ inline size_t fast_columns_hist_off(int cell, int C, int O, int D, bool pair)
+{
+    const size_t a = fast_columns_rows_bytes(cell, C, O, pair), b = fast_columns_scratch_bytes(C, D);
+    return a > b ? a : b;
+}
+__host__ __device__ inline size_t fast_columns_hist_bytes(int C, int O) { return al16((size_t)2 * O * C * C * 4); }
+
 // region A (per patch: the finished histogram) x patches, then region B = max(accumulator copies x patches,
 // normalisation scratch of ONE patch: the patches of a pair are normalised one after the other)
-__host__ __device__ inline int fast_columns_stride(int cell, int C, bool pair) { return pair ? 64 : ((C * cell + 3) & ~3); }
-__host__ __device__ inline size_t fast_columns_bytes(int cell, int C, int O, bool pair)
-{
-    return al16((size_t)2 * O * fast_columns_stride(cell, C, pair) * C * 4);
-}
-// ACC_COLUMNS: the column rows overlay regions A and B (they are dead before either is written)
 __host__ __device__ inline size_t fast_lds_bytes(int cell, int C, int O, int D, bool pair = false, bool columns = false)
 {
     const int CC = C * C, np = pair ? 2 : 1;
+    if (columns) return fast_columns_hist_off(cell, C, O, D, pair) + np * fast_columns_hist_bytes(C, O);
     const size_t b_rows = np * fast_copies_bytes(C, O, pair);
     const size_t b_norm = al16((size_t)2 * O * CC * 4) + al16((size_t)CC * 4) + al16((size_t)4 * CC * 8) +
                           al16((size_t)O * CC * 4 * 8) + al16((size_t)D * CC * 4);
-    if (columns) {
-        const size_t rest = np * fast_region_a(C, O) + b_norm, cols = fast_columns_bytes(cell, C, O, pair);
-        return cols > rest ? cols : rest;
-    }
     return np * fast_region_a(C, O) + (b_rows > b_norm ? b_rows : b_norm);
+}
+// dynamic LDS of one workgroup
+__host__ __device__ inline size_t fast_wg_lds_bytes(int cell, int C, int O, int D, bool pair, bool columns)
+{
+    return fast_lds_bytes(cell, C, O, D, pair, columns) * HF_WAVES + (columns ? HF_WT_BYTES : 0);
 }
 
 __device__ inline FastLds fast_carve(unsigned char* base, int C, int O, int D, bool pair = false)
@@ -385,6 +402,88 @@ __device__ void hog_finish_patch(const FastLds& w, const u64* hfin_p, const floa
     wave_sync();   // the caller may reuse the scratch for the next patch
 }
 
+// ---- ACC_COLUMNS finish: the same arithmetic as hog_finish_patch on a third of its scratch.  hist = f32 [2O][C*C] (cell
+//      index cy*C + cx) as the folds left it; nrm / fac / desc overlay the dead column rows; the texture sums recompute
+//      their clamped terms instead of staging them (O products per output). -----------------------------------------
+template <int TO, int TC>
+__device__ void hog_finish_lean(const float* hist, unsigned char* scratch, float* __restrict__ out_desc,
+                                const HogLevelDev& lv, int lane)
+{
+    const int O = TO ? TO : lv.O;
+    const int C = TC ? TC : lv.C;
+    const int CC = C * C, CB = C + 1;
+    float* nrm = (float*)scratch;
+    double* fac = (double*)(scratch + al16((size_t)CC * 4));
+    float* desc = (float*)(scratch + al16((size_t)CC * 4) + al16((size_t)CB * CB * 8));
+    // ---- cell norms (hog.c:875-890) ---------------------------------------------------------------------------
+    for (int c = lane; c < CC; c += 64) {
+        float n = 0.0f;
+        for (int k = 0; k < O; ++k) {
+            const float hs = hist[c + k * CC] + hist[c + (k + O) * CC];
+            n += hs * hs;
+        }
+        nrm[c] = n;
+    }
+    wave_sync();
+    // ---- block factors (hog.c:930-981): see hog_finish_patch ------------------------------------------------------
+    for (int t = lane; t < CB * CB; t += 64) {
+        const int byb = t / CB, bxb = t - byb * CB;
+        const int xa = bxb - 1 > 0 ? bxb - 1 : 0, xb = bxb < C - 1 ? bxb : C - 1;
+        const int ya = byb - 1 > 0 ? byb - 1 : 0, yb = byb < C - 1 ? byb : C - 1;
+        const double na = nrm[xa + ya * C], nb = nrm[xb + ya * C];
+        const double nc = nrm[xa + yb * C], nd = nrm[xb + yb * C];
+        fac[t] = 1.0 / sqrt(na + nb + nc + nd + 1e-4);
+    }
+    wave_sync();
+#define CL02(v) __builtin_fmin(0.2, (v))          /* VL_MIN(0.2, v): the values are finite and non-negative */
+    // ---- normalise, clamp, emit the 3 (UoCTTI) or 4 (Dalal-Triggs) outputs of every (cell, orientation), in the Matlab
+    //      order of the feature row (adaptive_vlhog.hpp:166-175): [dim][x][y] ---------------------------------------
+    for (int t = lane; t < O * CC; t += 64) {
+        const int k = t / CC, c = t - k * CC;
+        const int y = c / C, x = c - y * C, ct = x * C + y;
+        const double ha = hist[c + k * CC], hb = hist[c + (k + O) * CC];
+        const double f1 = fac[x + y * CB], f2 = fac[x + 1 + y * CB];
+        const double f3 = fac[x + (y + 1) * CB], f4 = fac[x + 1 + (y + 1) * CB];
+        double ha1 = f1 * ha, ha2 = f2 * ha, ha3 = f3 * ha, ha4 = f4 * ha;
+        double hb1 = f1 * hb, hb2 = f2 * hb, hb3 = f3 * hb, hb4 = f4 * hb;
+        double hc1 = ha1 + hb1, hc2 = ha2 + hb2, hc3 = ha3 + hb3, hc4 = ha4 + hb4;
+        ha1 = CL02(ha1); ha2 = CL02(ha2); ha3 = CL02(ha3); ha4 = CL02(ha4);
+        hb1 = CL02(hb1); hb2 = CL02(hb2); hb3 = CL02(hb3); hb4 = CL02(hb4);
+        hc1 = CL02(hc1); hc2 = CL02(hc2); hc3 = CL02(hc3); hc4 = CL02(hc4);
+        if (lv.variant == 1) {
+            desc[ct + k * CC] = (float)(0.5 * (ha1 + ha2 + ha3 + ha4));
+            desc[ct + (k + O) * CC] = (float)(0.5 * (hb1 + hb2 + hb3 + hb4));
+            desc[ct + (k + 2 * O) * CC] = (float)(0.5 * (hc1 + hc2 + hc3 + hc4));
+        } else {
+            desc[ct + k * CC] = (float)hc1;
+            desc[ct + (k + O) * CC] = (float)hc2;
+            desc[ct + (k + 2 * O) * CC] = (float)hc3;
+            desc[ct + (k + 3 * O) * CC] = (float)hc4;
+        }
+    }
+    // ---- texture features: t_j = sum over k (in order) of the clamped hc_j (hog.c:1020-1023, 1047-1052) ------
+    if (lv.variant == 1) {
+        const float tex = 1.0f / sqrtf(18.0f);
+        for (int t = lane; t < 4 * CC; t += 64) {
+            const int j = t / CC, c = t - j * CC;
+            const int y = c / C, x = c - y * C, ct = x * C + y;
+            const double fj = fac[x + (j & 1) + (y + (j >> 1)) * CB];
+            double acc = 0.0;
+            for (int k = 0; k < O; ++k) {
+                const double ha = hist[c + k * CC], hb = hist[c + (k + O) * CC];
+                const double haj = fj * ha, hbj = fj * hb;
+                acc += CL02(haj + hbj);
+            }
+            desc[ct + (3 * O + j) * CC] = (float)(tex * acc);
+        }
+    }
+#undef CL02
+    wave_sync();
+    // ---- the feature row segment of this landmark: desc is already in its order -------------------------------
+    for (int o = lane; o < lv.P; o += 64) out_desc[o] = desc[o];
+    wave_sync();   // the next patch of a pair reuses the scratch
+}
+
 // TO / TC: compile-time orientation count / cell count (0 = take the run-time value from lv)
 // PAIR: landmarks `landmark` and `landmark + 1` of the same sample side by side in lanes 0-31 / 32-63 (S <= 32).  They
 // share the image, the IED, hence h, the scale and every per-coordinate table; only the patch centre differs, which
@@ -394,7 +493,7 @@ template <int ACC, int FASTBIN, int TO, int TC, bool PAIR, bool PROF = false>
 __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* __restrict__ xr, int L, int landmark,
                                bool second_valid, const EyeIdxDev& eyes, const HogLevelDev& lv, unsigned char* lds_base,
                                float* __restrict__ out_row, int* idx_row, int* status,
-                               unsigned long long* prof = nullptr)
+                               unsigned long long* prof = nullptr, float* wt = nullptr, bool valid = true)
 {
     long long tprev = PROF ? clock64() : 0;
     auto mark = [&](int slot) {
@@ -490,22 +589,37 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
     }
     const float row_w1 = wx1, row_w2 = wx2;   // weights of coordinate d when it is used as a ROW
     const int row_cell = bxc;
-    // ACC_COLUMNS: row d feeds the cell rows (band, band + 1) with the weights (wa, wb); the cell rows -1 and C do not exist
-    // (hog.c:713-724 bounds checks): their share is dropped by pairing the remaining one with a zero weight
-    const int row_band = bxc < 0 ? 0 : (bxc > C - 2 ? C - 2 : bxc);
-    const float row_wa = bxc < 0 ? wx2 : (bxc > C - 2 ? 0.0f : wx1);
-    const float row_wb = bxc < 0 ? 0.0f : (bxc > C - 2 ? wx1 : wx2);
+    // ACC_COLUMNS: row d feeds the cell rows (bands) bxc and bxc + 1; band b lives in slot b & 1.  The bands -1 and C do
+    // not exist (hog.c:713-724 bounds checks): their weight is 0.
+    const float row_wlo = bxc >= 0 ? wx1 : 0.0f, row_whi = bxc + 1 <= C - 1 ? wx2 : 0.0f;
+    const float row_ws0 = (bxc & 1) ? row_whi : row_wlo, row_ws1 = (bxc & 1) ? row_wlo : row_whi;
     const bool col_active = (col >= 1) && (col < S - 1) && (!PAIR || half == 0 || second_valid);
     // padded histogram column of this lane (lanes outside the ROI contribute exact zeros to cell 0)
     const int hcol = col_active ? bxc + 1 : 0;
     if (!col_active) { wx1 = 0.0f; wx2 = 0.0f; }
 
     mark(0);   // geometry + per-coordinate tables
-    float* colrows = (float*)lds_base;      // ACC_COLUMNS: [2O][ST][C]
+    float* colrows = (float*)lds_base;      // ACC_COLUMNS: [2O][ST][2 band slots]
     const int ST = fast_columns_stride(cell, C, PAIR);
+    float* chist = (float*)(lds_base + fast_columns_hist_off(cell, C, O, D, PAIR));    // [patch][2O][CC]
+    const int chist_stride = (int)(fast_columns_hist_bytes(C, O) / 4);
     if (ACC == ACC_COLUMNS) {
         const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (int i = lane; i < (int)(fast_columns_bytes(cell, C, O, PAIR) / 16); i += 64) ((f32x4*)colrows)[i] = z4;
+        for (int i = lane; i < (int)(fast_columns_rows_bytes(cell, C, O, PAIR) / 16); i += 64) ((f32x4*)colrows)[i] = z4;
+        for (int i = lane; i < NP * chist_stride / 4; i += 64) ((f32x4*)chist)[i] = z4;
+        // the fold weights of coordinate x = this lane: W[x][patch * C + cell] = wx1 for cell(x), wx2 for cell(x) + 1
+        // (hog.c:697-704), 0 elsewhere and for the columns outside the ROI interior.  Pure level geometry: the four waves
+        // of the workgroup write identical tables, and the barrier orders every write before the first fold.
+        float* wrow = wt + lane * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ((f32x4*)wrow)[i] = z4;
+        if (col >= 1 && col < S - 1) {
+            const int nb = half * C;
+            if (bxc >= 0) wrow[nb + bxc] = row_w1;              // (the unmasked weights: wx1 / wx2 are zeroed per patch)
+            if (bxc + 1 <= C - 1) wrow[nb + bxc + 1] = row_w2;
+        }
+        __syncthreads();
+        if (!valid) return;
     } else if (ACC == ACC_FIXED64) {
         // (16-byte stores: both counts are even and both regions 16-byte aligned)
         const u64x2 z2 = {0ull, 0ull};
@@ -590,10 +704,58 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
     float rm2 = 0.0f, rm1 = 0.0f;       // resized rows y-2, y-1 of this lane's column
     // ACC_COLUMNS: the contribution of the previous pixel row, added while this row's gradient is computed
     // (lanes beyond the ROI share column 0, which is never active: its sums are finite garbage with fold weight 0)
-    const unsigned col_off = (unsigned)(PAIR ? lane : (col < S ? col : 0)) * (unsigned)(C * 4);
-    const unsigned bin_stride = (unsigned)(ST * C * 4);
-    float* pend_p = (float*)((unsigned char*)colrows + col_off);
-    float pend_a = 0.0f, pend_b = 0.0f;
+    const unsigned col_off = (unsigned)(PAIR ? lane : (col < S ? col : 0)) * 8u;
+    const unsigned bin_stride = (unsigned)(ST * 8);
+    f32x2* pend_p = (f32x2*)((unsigned char*)colrows + col_off);
+    f32x2 pend_v = {0.0f, 0.0f};
+    int prev_by = -1;
+    // fold band b (slot b & 1) into the cells of cell row b, then clear the slot for band b + 2.  v_mfma_f32_16x16x4_f32:
+    // lane (li, lq) feeds A[row li][k lq] = col[bin li][x = 4 ks + lq], B[k lq][col li] = W[x][li] and receives
+    // D[row 4 lq + e][col li]; two accumulators per tile halve the dependent chain.
+    auto fold_band = [&](const int b) __attribute__((always_inline)) {
+#ifdef HF_DBG_NOFOLD
+        return;
+#endif
+        constexpr int NTB = (2 * TO + 15) / 16 > 0 ? (2 * TO + 15) / 16 : 1;
+        const int sl = b & 1;
+        const int li = lane & 15, lq = lane >> 4;
+        wave_sync();
+        f32x4 fa[NTB][2];
+        const float* ap[NTB];
+#pragma unroll
+        for (int t = 0; t < NTB; ++t) {
+            fa[t][0] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; fa[t][1] = fa[t][0];
+            const int br = 16 * t + li;
+            ap[t] = colrows + ((br < 2 * O ? br : 2 * O - 1) * ST + lq) * 2 + sl;
+        }
+        const float* bp = wt + lq * 16 + li;
+        // (ST is a multiple of 8: an even number of k steps, two per trip, one accumulator each; a plain counted loop keeps
+        // the accumulators in place -- guarding unrolled steps individually makes the compiler shuttle them through VGPRs)
+        for (int kp = 0; kp < ST / 8; ++kp) {
+            const float bw0 = bp[0], bw1 = bp[64];
+#pragma unroll
+            for (int t = 0; t < NTB; ++t) {
+                fa[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[t][0], bw0, fa[t][0], 0, 0, 0);
+                fa[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[t][8], bw1, fa[t][1], 0, 0, 0);
+                ap[t] += 16;
+            }
+            bp += 128;
+        }
+        // (the LDS unit executes a wave's instructions in order: the clears below follow the reads above)
+        for (int i = lane; i < 2 * O * ST; i += 64) colrows[2 * i + sl] = 0.0f;
+        const int hp_n = li / C, cx_n = li - hp_n * C;
+        if (hp_n < NP) {
+            float* hf = chist + hp_n * chist_stride + b * C + cx_n;
+#pragma unroll
+            for (int t = 0; t < NTB; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int br = 16 * t + 4 * lq + e;
+                    if (br < 2 * O) hf[br * CC] = fa[t][0][e] + fa[t][1][e];
+                }
+        }
+        wave_sync();
+    };
     // Rows are processed in pairs: each row's two source loads and the two previous resized rows stay in fixed registers (no
     // rotation copies), the pair is one straight-line block the scheduler can interleave (row y+1's resize does not depend on
     // row y's gradient), and the loads of row y+2 are issued as soon as row y's bytes are consumed.  (Deeper prefetch
@@ -608,8 +770,8 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
         horizontal(q0[j], q1[j], H0, H1);
         const int cbeta = qbeta[j];
         issue_row(y + PD, q0[j], q1[j], qbeta[j]);      // (past the last row: a harmless reload of row S-1)
-        float qa = 0.0f, qb = 0.0f;
-        if (ACC == ACC_COLUMNS && grad) { qa = pend_p[0]; qb = pend_p[1]; }     // (in flight during the arithmetic below)
+        f32x2 qv = {0.0f, 0.0f};
+        if (ACC == ACC_COLUMNS && grad) qv = *pend_p;     // (in flight during the arithmetic below)
         const float r0 = vertical(H0, H1, cbeta);
         if (grad) {
             // gradient of row yy = y-1 (hog.c:616-672)
@@ -651,15 +813,17 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
             const int by = __builtin_amdgcn_readlane(row_cell, yy);
             const float wy1 = lane_f(row_w1, yy), wy2 = lane_f(row_w2, yy);
             if (ACC == ACC_COLUMNS) {
-                pend_p[0] = qa + pend_a; pend_p[1] = qb + pend_b;
-                // this row: g * (wa, wb) into the cell rows (band, band + 1) of this lane's own column, next iteration
-                // (24-bit multiply-add on the bin + the lane's byte offset; the cell-row term is scalar)
-                const int band = __builtin_amdgcn_readlane(row_band, yy);
-                const float wa = lane_f(row_wa, yy), wb = lane_f(row_wb, yy);
-                const unsigned a = __umul24((unsigned)bin, bin_stride) + col_off;
-                pend_p = (float*)((unsigned char*)colrows + (a + (unsigned)band * 4u));
-                const f32x2 pv = (f32x2){wa, wb} * g;
-                pend_a = pv.x; pend_b = pv.y;
+                *pend_p = qv + pend_v;
+                // the rows entered the next band (wave-uniform): the one they left is complete
+                if (by != prev_by) {
+                    if (prev_by >= 0) fold_band(prev_by);
+                    prev_by = by;
+                }
+                // this row: g * (slot weights) into the two band slots of this lane's own column, next iteration
+                // (24-bit multiply-add on the bin + the lane's byte offset)
+                const float ws0 = lane_f(row_ws0, yy), ws1 = lane_f(row_ws1, yy);
+                pend_p = (f32x2*)((unsigned char*)colrows + (__umul24((unsigned)bin, bin_stride) + col_off));
+                pend_v = (f32x2){ws0, ws1} * g;
             } else {
             // (grad * wx) * wy, hog.c:714-723: six f32 products as three packed multiplies
             const f32x2 t = (f32x2){wx2, wx1} * g;
@@ -713,58 +877,13 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
     }
     if (yrow < S) row_step(0, yrow, true);
     if (ACC == ACC_FIXED64 && cur_by != -2) { flush_band(cur_by); flush_band(cur_by + 1); }
-    if (ACC == ACC_COLUMNS) { pend_p[0] += pend_a; pend_p[1] += pend_b; }
+    if (ACC == ACC_COLUMNS) {
+        *pend_p += pend_v;
+        if (prev_by >= 0) fold_band(prev_by);
+        if (prev_by + 1 <= C - 1) fold_band(prev_by + 1);      // (cell sizes < 3: the last rows never reach the last band)
+    }
     mark(2);   // row loop
     wave_sync();
-    if (ACC == ACC_COLUMNS) {
-        // ---- fold the pixel columns into cells on the matrix cores: D[r][n] = sum_x col[r][x] * W[x][n], r = bin*C + band,
-        //      n = patch * C + cell column.  v_mfma_f32_16x16x4_f32: lane (li, lq) feeds A[row li][k lq], B[k lq][col li] and
-        //      receives D[row 4*lq + e][col li].  W[x][n] = wx1(x) if cell(x) == n, wx2(x) if cell(x) + 1 == n (hog.c:697-704),
-        //      fetched from lane x (the lane that owns coordinate x) with ds_bpermute.
-        constexpr int NT = (TC * 2 * TO + 15) / 16;
-        const int nrows = C * 2 * O;
-        const int li = lane & 15, lq = lane >> 4;
-        const int hp_n = li / C, cx_n = li - hp_n * C;
-        f32x4 accf[NT > 0 ? NT : 1];
-#pragma unroll
-        for (int mt = 0; mt < NT; ++mt) accf[mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-        const float* arow[NT > 0 ? NT : 1];
-#pragma unroll
-        for (int mt = 0; mt < NT; ++mt) {
-            int r = 16 * mt + li;
-            r = r < nrows ? r : nrows - 1;
-            const int kb = r / C, band = r - kb * C;
-            arow[mt] = colrows + (kb * ST + lq) * C + band;
-        }
-        const int nks = ST / 4;
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            if (ks < nks) {                       // (wave-uniform)
-                const int xs = 4 * ks + lq;
-                const int cellx = __builtin_amdgcn_ds_bpermute(xs * 4, bxc);
-                const float w1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(xs * 4, __builtin_bit_cast(int, wx1)));
-                const float w2 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(xs * 4, __builtin_bit_cast(int, wx2)));
-                float b = cellx == cx_n ? w1 : (cellx + 1 == cx_n ? w2 : 0.0f);
-                if (hp_n >= NP || (PAIR && (xs >> 5) != hp_n)) b = 0.0f;
-#pragma unroll
-                for (int mt = 0; mt < NT; ++mt)
-                    accf[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[mt][4 * ks * C], b, accf[mt], 0, 0, 0);
-            }
-        }
-        wave_sync();    // every column is read before the finished histograms overwrite the region
-        if (hp_n < NP) {
-            float* hf = (float*)((unsigned char*)w.hfin + (size_t)hp_n * a_bytes);
-#pragma unroll
-            for (int mt = 0; mt < NT; ++mt)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 16 * mt + 4 * lq + e;
-                    const int kb = r / C, band = r - kb * C;
-                    if (r < nrows) hf[kb * PWW + (band + 1) * PW + cx_n + 1] = accf[mt][e];
-                }
-        }
-        wave_sync();
-    }
     mark(3);   // barrier after the row loop
 
     // ---- per patch (one after the other in PAIR mode: they share the normalisation scratch) ------------------------
@@ -773,7 +892,8 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
         const u64* hfin_p = (const u64*)((unsigned char*)w.hfin + (size_t)hp * a_bytes);
         const float* histf_p = (const float*)((unsigned char*)w.hfin + (size_t)hp * a_bytes);
         float* out_desc = out_row + (long long)(landmark + hp) * lv.P;
-        hog_finish_patch<ACC, TO, TC>(w, hfin_p, histf_p, out_desc, lv, lane);
+        if (ACC == ACC_COLUMNS) hog_finish_lean<TO, TC>(chist + hp * chist_stride, lds_base, out_desc, lv, lane);
+        else hog_finish_patch<ACC, TO, TC>(w, hfin_p, histf_p, out_desc, lv, lane);
         mark(4);   // normalisation / extraction / store
     }
     mark(5);   // output stores
@@ -794,15 +914,20 @@ hog_fast_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float* 
     const unsigned blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
     const long long p = (long long)blk * HF_WAVES + wave;
     const int Lw = PAIR ? (L + 1) / 2 : L;      // wave slots per sample: one per landmark, or one per landmark pair
-    if (p >= (long long)N * Lw) return;          // (no workgroup barriers anywhere: tail waves simply leave)
-    const int s = (int)(p / Lw), iw = (int)(p - (long long)s * Lw);
+    const bool valid = p < (long long)N * Lw;
+    // (ACC_COLUMNS has one workgroup barrier, behind the shared fold weights: tail waves stay until then, on patch 0)
+    if (!valid && ACC != ACC_COLUMNS) return;
+    const long long pe = valid ? p : 0;
+    const int s = (int)(pe / Lw), iw = (int)(pe - (long long)s * Lw);
     const int i = PAIR ? 2 * iw : iw;
     const bool second_valid = PAIR && (i + 1 < L);
     const int im = img_idx ? img_idx[s] : s;
     const float* xr = x + (long long)s * 2 * L;
     float* row = feat + (long long)s * ldf;
     hog_patch_fast<ACC, FASTBIN, TO, TC, PAIR, PROF>(imgs, im, xr, L, i, second_valid, eyes, lv, smem + (size_t)wave * lds_per_wave,
-                                                     row, idx_out ? idx_out + (long long)s * (1 + 2 * L) : nullptr, status, prof);
+                                                     row, idx_out ? idx_out + (long long)s * (1 + 2 * L) : nullptr, status, prof,
+                                                     (float*)(smem + (size_t)HF_WAVES * lds_per_wave), valid);
+    if (!valid) return;
     if (PROF && (threadIdx.x & 63) == 0) atomicAdd(&prof[7], 1ull);
     // bias, adaptive_vlhog.hpp:182-183 (the non-adaptive example transform has none)
     if (lv.fixed_h == 0 && iw == Lw - 1 && (threadIdx.x & 63) == 0) row[(long long)L * lv.P] = 1.0f;
@@ -842,8 +967,8 @@ bool sdm_hog_fast_supported(const HogLevelDev& lv)
 static bool hog_fast_pair(const HogLevelDev& lv, int fast_bins, bool columns = false)
 {
     if (lv.S > 32 || fast_bins != 2) return false;
-    const size_t one = fast_lds_bytes(lv.cell, lv.C, lv.O, lv.D, false, columns) * HF_WAVES;
-    const size_t two = fast_lds_bytes(lv.cell, lv.C, lv.O, lv.D, true, columns) * HF_WAVES;
+    const size_t one = fast_wg_lds_bytes(lv.cell, lv.C, lv.O, lv.D, false, columns);
+    const size_t two = fast_wg_lds_bytes(lv.cell, lv.C, lv.O, lv.D, true, columns);
     if (two > 160 * 1024) return false;
     const size_t wg_one = (160 * 1024) / one, wg_two = (160 * 1024) / two;
     return 2 * wg_two >= wg_one;
@@ -868,7 +993,7 @@ static void launch_fast_oc(const ImageSetDev& imgs, const int* img_idx, const fl
     const size_t per = fast_lds_bytes(lv.cell, lv.C, lv.O, lv.D, pair, columns);
     const unsigned grid = (unsigned)((total + HF_WAVES - 1) / HF_WAVES);
     const dim3 g(grid), b(HF_WAVES * 64);
-    const size_t lds = per * HF_WAVES;
+    const size_t lds = fast_wg_lds_bytes(lv.cell, lv.C, lv.O, lv.D, pair, columns);
     static unsigned long long attr_seen = 0;
     if (sdm_first_use_on_device(attr_seen)) {
 #define HATTR(A, B, P) (void)hipFuncSetAttribute((const void*)hog_fast_kernel<A, B, TO, TC, P>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
@@ -907,7 +1032,7 @@ void sdm_launch_hog_fast_profile(const ImageSetDev& imgs, const int* img_idx, co
     static unsigned long long attr_seen = 0;
     if (sdm_first_use_on_device(attr_seen))
         (void)hipFuncSetAttribute((const void*)hog_fast_kernel<ACC_COLUMNS, 2, 4, 5, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((hog_fast_kernel<ACC_COLUMNS, 2, 4, 5, false, true>), dim3(grid), dim3(HF_WAVES * 64), per * HF_WAVES,
+    hipLaunchKernelGGL((hog_fast_kernel<ACC_COLUMNS, 2, 4, 5, false, true>), dim3(grid), dim3(HF_WAVES * 64), per * HF_WAVES + HF_WT_BYTES,
                        stream, imgs, img_idx, x, N, L, eyes, lv, feat, ldf, (int*)nullptr, status, per, prof_dev);
 }
 
