@@ -389,6 +389,16 @@ int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int*
         }
         lv.n_sector = lv.O / 2;
         for (int j = 0; j < lv.n_sector; ++j) lv.sector_t[j] = (float)tan((2 * j + 1) * 3.141592653589793 / (2.0 * lv.O));
+        for (int d = 0; d < 64 && d < lv.S; ++d) {      // the kernel's per-coordinate arithmetic (hog.c:697-704), IEEE on the host
+            const float hx = (float)((d + 0.5) / (double)lv.cell - 0.5);
+            int b = (int)hx;
+            if (!(hx >= 0.0f || (float)b == hx)) b -= 1;                        // vl_floor_f
+            const float w2 = hx - (float)b, w1 = (float)(1.0 - w2);
+            const float wlo = b >= 0 ? w1 : 0.0f, whi = b + 1 <= lv.C - 1 ? w2 : 0.0f;   // the cell rows -1 and C do not exist
+            lv.row_tab[d][0] = (b & 1) ? whi : wlo;                              // band b lives in slot b & 1
+            lv.row_tab[d][1] = (b & 1) ? wlo : whi;
+            memcpy(&lv.row_tab[d][2], &b, sizeof(int));
+        }
         if (sdm_hog_lds_bytes(lv, 4) > 160 * 1024) return fail(SDM_ERR_INVALID, "HOG geometry exceeds the LDS budget");
         c->levels.push_back(lv); c->params.push_back(p);
         {

@@ -814,14 +814,17 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
             const float wy1 = lane_f(row_w1, yy), wy2 = lane_f(row_w2, yy);
             if (ACC == ACC_COLUMNS) {
                 *pend_p = qv + pend_v;
+                // the row's level constants come from the kernel arguments with one scalar load (no cross-lane reads)
+                const float* rt = lv.row_tab[yy];
+                const float ws0 = rt[0], ws1 = rt[1];
+                const int cby = __builtin_bit_cast(int, rt[2]);
                 // the rows entered the next band (wave-uniform): the one they left is complete
-                if (by != prev_by) {
+                if (cby != prev_by) {
                     if (prev_by >= 0) fold_band(prev_by);
-                    prev_by = by;
+                    prev_by = cby;
                 }
                 // this row: g * (slot weights) into the two band slots of this lane's own column, next iteration
                 // (24-bit multiply-add on the bin + the lane's byte offset)
-                const float ws0 = lane_f(row_ws0, yy), ws1 = lane_f(row_ws1, yy);
                 pend_p = (f32x2*)((unsigned char*)colrows + (__umul24((unsigned)bin, bin_stride) + col_off));
                 pend_v = (f32x2){ws0, ws1} * g;
             } else {

@@ -24,6 +24,9 @@ struct HogLevelDev {
     float oy[SDM_MAX_ORIENT];  // (float)sin(k*pi/O)
     int n_sector;              // floor(O/2): sector boundaries inside the first quadrant
     float sector_t[SDM_MAX_ORIENT / 2];   // (float)tan((2j+1)*pi/(2O))
+    // per resized-ROI row d < S (level constants, hog.c:697-704, read with scalar loads straight from the kernel arguments):
+    // {weight of band slot 0, weight of band slot 1, cell row index floor(hy) as int bits, 0} -- see ACC_COLUMNS
+    alignas(16) float row_tab[64][4];
 };
 
 struct EyeIdxDev {
