@@ -89,7 +89,8 @@ struct sdm_ctx {
     DevBuf<long long> img_off;
     DevBuf<int> img_w, img_h, img_stride;
     int n_images = 0;
-    bool narrow_images = false;   // an image less than 2 pixels wide: the fused kernel's paired-byte loads need w >= 2
+    bool narrow_images = false;   // an image less than 2 pixels wide or 65536+ rows high: the fused kernel's paired-byte
+                                  // loads need w >= 2, its packed row tables h < 2^16 -> the generic kernel runs instead
     DevBuf<int> img_idx;
     bool idx_identity = true;
 
@@ -485,7 +486,7 @@ int sdm_upload_images_u8(sdm_ctx* c, const uint8_t* const* images, const int* w,
     c->img_base = c->img_owned.p;
     c->n_images = n;
     c->narrow_images = false;
-    for (int i = 0; i < n; ++i) c->narrow_images = c->narrow_images || w[i] < 2;
+    for (int i = 0; i < n; ++i) c->narrow_images = c->narrow_images || w[i] < 2 || h[i] > 65535;
     return SDM_OK;
 }
 
@@ -506,7 +507,7 @@ int sdm_set_images_device(sdm_ctx* c, const uint8_t* dev_base, int n, int w, int
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->img_base = dev_base;
     c->n_images = n;
-    c->narrow_images = w < 2;
+    c->narrow_images = w < 2 || h > 65535;
     return SDM_OK;
 }
 

@@ -561,6 +561,16 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
         if (area2) { sy0 = 2 * d; sy1 = 2 * d + 1; }
         row_src = sy0 | (sy1 << 16);
         row_beta = area2 ? (1024 | (1024 << 16)) : ((c0 & 0xffff) | (c1 << 16));
+        if (!PAIR) {
+            // one patch per wave: the patch origin is wave-uniform, so the image rows of the two taps are final here -- clamped
+            // into the image (< 2^16 rows, checked by the host), a row on the black canvas keeps its address but loses its weight
+            int py0 = (cy - h) + sy0, py1 = (cy - h) + sy1;
+            if (py0 < 0 || py0 >= ih) row_beta &= 0xffff0000;
+            if (py1 < 0 || py1 >= ih) row_beta &= 0x0000ffff;
+            py0 = py0 < 0 ? 0 : (py0 > ih - 1 ? ih - 1 : py0);
+            py1 = py1 < 0 ? 0 : (py1 > ih - 1 ? ih - 1 : py1);
+            row_src = py0 | (py1 << 16);
+        }
         // horizontal taps: clamped in the table
         int sx = s;
         a0 = c0; a1 = c1;
@@ -671,14 +681,9 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
             q0 = __builtin_amdgcn_raw_buffer_load_b16(img_rsrc, vb + r0, 0, 0);
             q1 = __builtin_amdgcn_raw_buffer_load_b16(img_rsrc, vb + r1, 0, 0);
         } else {
-            int py0 = y0 + (src & 0xffff), py1 = y0 + (src >> 16);
-            // rows on the black canvas: vertical weight 0 (scalar), address clamped into the image
-            if (py0 < 0 || py0 >= ih) beta &= 0xffff0000;
-            if (py1 < 0 || py1 >= ih) beta &= 0x0000ffff;
-            py0 = py0 < 0 ? 0 : (py0 > ih - 1 ? ih - 1 : py0);
-            py1 = py1 < 0 ? 0 : (py1 > ih - 1 ? ih - 1 : py1);
-            q0 = __builtin_amdgcn_raw_buffer_load_b16(img_rsrc, pl, py0 * istride, 0);
-            q1 = __builtin_amdgcn_raw_buffer_load_b16(img_rsrc, pl, py1 * istride, 0);
+            // (image rows, clamped into the image and with the weight of a row on the black canvas already 0: see row_src)
+            q0 = __builtin_amdgcn_raw_buffer_load_b16(img_rsrc, pl, (src & 0xffff) * istride, 0);
+            q1 = __builtin_amdgcn_raw_buffer_load_b16(img_rsrc, pl, (int)((unsigned)src >> 16) * istride, 0);
         }
         bb = beta;
     };
