@@ -673,7 +673,9 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
     // the buffer's num_records and the hardware range check returns 0 -- the black canvas -- without any clamp or mask.
     const int vb = PAIR ? pl + y0 * istride : 0;
     auto issue_row = [&](int y, unsigned short& q0, unsigned short& q1, int& bb) {
-        const int yy = y < S ? y : S - 1;
+        // (rows past the last one -- the pipeline's harmless extra loads -- need no clamp: v_readlane takes the lane index
+        // modulo 64 and every lane holds the taps of a valid row)
+        const int yy = y;
         const int src = __builtin_amdgcn_readlane(row_src, yy);
         int beta = __builtin_amdgcn_readlane(row_beta, yy);
         if (PAIR) {
