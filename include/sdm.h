@@ -108,7 +108,8 @@ int sdm_set_hog_mode(sdm_ctx* ctx, int mode);
 int sdm_get_hog_info(sdm_ctx* ctx, int level, int* fast_kernel, int* fast_bins);
 
 /* Images: the `const std::vector<cv::Mat>& images` of HogTransform (adaptive_vlhog.hpp:92,188),
- * single channel u8.  Host images are copied to HBM once. */
+ * single channel u8.  Host images are copied to HBM once.  (Images less than 2 pixels wide or 65 536+ rows high run the
+ * generic HOG kernel instead of the fused one: same results, slower.) */
 int sdm_upload_images_u8(sdm_ctx* ctx, const uint8_t* const* images, const int* width, const int* height,
                          const int* stride_bytes, int n_images);
 /* Device-resident stack of equally sized images (image i at base + i*height*stride_bytes); not copied. */
