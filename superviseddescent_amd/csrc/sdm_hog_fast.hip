@@ -738,18 +738,27 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
         const float* bp = wt + lq * 16 + li;
         // (ST is a multiple of 8: an even number of k steps, two per trip, one accumulator each; a plain counted loop keeps
         // the accumulators in place -- guarding unrolled steps individually makes the compiler shuttle them through VGPRs)
+        // (ST is a multiple of 8: an even number of k steps, two per trip, one accumulator each; a plain counted loop keeps
+        // the accumulators in place -- guarding unrolled steps individually makes the compiler shuttle them through VGPRs)
         for (int kp = 0; kp < ST / 8; ++kp) {
             const float bw0 = bp[0], bw1 = bp[64];
 #pragma unroll
             for (int t = 0; t < NTB; ++t) {
-                fa[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[t][0], bw0, fa[t][0], 0, 0, 0);
-                fa[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[t][8], bw1, fa[t][1], 0, 0, 0);
+                float* a = const_cast<float*>(ap[t]);
+                const float a0v = a[0], a1v = a[8];
+                // one patch per wave: clear what was just read (the LDS unit executes a wave's instructions in order).  The
+                // 16 rows x 4 + 4 columns of a step pair are exactly the slot's entries of these 8 pixel columns; rows beyond 2O
+                // repeat the last bin.  (With the compile-time 64 columns of a landmark pair the loop is unrolled and the
+                // stores would serialise the operand reads: there the slot is cleared afterwards.)
+                if (!PAIR) { a[0] = 0.0f; a[8] = 0.0f; }
+                fa[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v, bw0, fa[t][0], 0, 0, 0);
+                fa[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v, bw1, fa[t][1], 0, 0, 0);
                 ap[t] += 16;
             }
             bp += 128;
         }
-        // (the LDS unit executes a wave's instructions in order: the clears below follow the reads above)
-        for (int i = lane; i < 2 * O * ST; i += 64) colrows[2 * i + sl] = 0.0f;
+        if (PAIR)
+            for (int i = lane; i < 2 * O * ST; i += 64) colrows[2 * i + sl] = 0.0f;
         const int hp_n = li / C, cx_n = li - hp_n * C;
         if (hp_n < NP) {
             float* hf = chist + hp_n * chist_stride + b * C + cx_n;
