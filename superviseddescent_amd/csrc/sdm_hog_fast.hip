@@ -404,8 +404,9 @@ __device__ void hog_finish_patch(const FastLds& w, const u64* hfin_p, const floa
 
 // ---- ACC_COLUMNS finish: the same arithmetic as hog_finish_patch on a third of its scratch.  hist = f32 [2O][C*C] (cell
 //      index cy*C + cx) as the folds left it; nrm / fac / desc overlay the dead column rows; the texture sums recompute
-//      their clamped terms instead of staging them (O products per output). -----------------------------------------
-template <int TO, int TC>
+//      their clamped terms instead of staging them (O products per output).  FT: the arithmetic type of hog.c:930-1052
+//      (double). ---------------------------------------------------------------------------------------------------
+template <int TO, int TC, typename FT>
 __device__ void hog_finish_lean(const float* hist, unsigned char* scratch, float* __restrict__ out_desc,
                                 const HogLevelDev& lv, int lane)
 {
@@ -413,7 +414,7 @@ __device__ void hog_finish_lean(const float* hist, unsigned char* scratch, float
     const int C = TC ? TC : lv.C;
     const int CC = C * C, CB = C + 1;
     float* nrm = (float*)scratch;
-    double* fac = (double*)(scratch + al16((size_t)CC * 4));
+    FT* fac = (FT*)(scratch + al16((size_t)CC * 4));
     float* desc = (float*)(scratch + al16((size_t)CC * 4) + al16((size_t)CB * CB * 8));
     // ---- cell norms (hog.c:875-890) ---------------------------------------------------------------------------
     for (int c = lane; c < CC; c += 64) {
@@ -430,30 +431,30 @@ __device__ void hog_finish_lean(const float* hist, unsigned char* scratch, float
         const int byb = t / CB, bxb = t - byb * CB;
         const int xa = bxb - 1 > 0 ? bxb - 1 : 0, xb = bxb < C - 1 ? bxb : C - 1;
         const int ya = byb - 1 > 0 ? byb - 1 : 0, yb = byb < C - 1 ? byb : C - 1;
-        const double na = nrm[xa + ya * C], nb = nrm[xb + ya * C];
-        const double nc = nrm[xa + yb * C], nd = nrm[xb + yb * C];
-        fac[t] = 1.0 / sqrt(na + nb + nc + nd + 1e-4);
+        const FT na = nrm[xa + ya * C], nb = nrm[xb + ya * C];
+        const FT nc = nrm[xa + yb * C], nd = nrm[xb + yb * C];
+        fac[t] = (FT)1.0 / (FT)sqrt(na + nb + nc + nd + (FT)1e-4);
     }
     wave_sync();
-#define CL02(v) __builtin_fmin(0.2, (v))          /* VL_MIN(0.2, v): the values are finite and non-negative */
+#define CL02(v) (sizeof(FT) == 8 ? (FT)__builtin_fmin(0.2, (double)(v)) : (FT)__builtin_fminf(0.2f, (float)(v)))          /* VL_MIN(0.2, v): the values are finite and non-negative */
     // ---- normalise, clamp, emit the 3 (UoCTTI) or 4 (Dalal-Triggs) outputs of every (cell, orientation), in the Matlab
     //      order of the feature row (adaptive_vlhog.hpp:166-175): [dim][x][y] ---------------------------------------
     for (int t = lane; t < O * CC; t += 64) {
         const int k = t / CC, c = t - k * CC;
         const int y = c / C, x = c - y * C, ct = x * C + y;
-        const double ha = hist[c + k * CC], hb = hist[c + (k + O) * CC];
-        const double f1 = fac[x + y * CB], f2 = fac[x + 1 + y * CB];
-        const double f3 = fac[x + (y + 1) * CB], f4 = fac[x + 1 + (y + 1) * CB];
-        double ha1 = f1 * ha, ha2 = f2 * ha, ha3 = f3 * ha, ha4 = f4 * ha;
-        double hb1 = f1 * hb, hb2 = f2 * hb, hb3 = f3 * hb, hb4 = f4 * hb;
-        double hc1 = ha1 + hb1, hc2 = ha2 + hb2, hc3 = ha3 + hb3, hc4 = ha4 + hb4;
+        const FT ha = hist[c + k * CC], hb = hist[c + (k + O) * CC];
+        const FT f1 = fac[x + y * CB], f2 = fac[x + 1 + y * CB];
+        const FT f3 = fac[x + (y + 1) * CB], f4 = fac[x + 1 + (y + 1) * CB];
+        FT ha1 = f1 * ha, ha2 = f2 * ha, ha3 = f3 * ha, ha4 = f4 * ha;
+        FT hb1 = f1 * hb, hb2 = f2 * hb, hb3 = f3 * hb, hb4 = f4 * hb;
+        FT hc1 = ha1 + hb1, hc2 = ha2 + hb2, hc3 = ha3 + hb3, hc4 = ha4 + hb4;
         ha1 = CL02(ha1); ha2 = CL02(ha2); ha3 = CL02(ha3); ha4 = CL02(ha4);
         hb1 = CL02(hb1); hb2 = CL02(hb2); hb3 = CL02(hb3); hb4 = CL02(hb4);
         hc1 = CL02(hc1); hc2 = CL02(hc2); hc3 = CL02(hc3); hc4 = CL02(hc4);
         if (lv.variant == 1) {
-            desc[ct + k * CC] = (float)(0.5 * (ha1 + ha2 + ha3 + ha4));
-            desc[ct + (k + O) * CC] = (float)(0.5 * (hb1 + hb2 + hb3 + hb4));
-            desc[ct + (k + 2 * O) * CC] = (float)(0.5 * (hc1 + hc2 + hc3 + hc4));
+            desc[ct + k * CC] = (float)((FT)0.5 * (ha1 + ha2 + ha3 + ha4));
+            desc[ct + (k + O) * CC] = (float)((FT)0.5 * (hb1 + hb2 + hb3 + hb4));
+            desc[ct + (k + 2 * O) * CC] = (float)((FT)0.5 * (hc1 + hc2 + hc3 + hc4));
         } else {
             desc[ct + k * CC] = (float)hc1;
             desc[ct + (k + O) * CC] = (float)hc2;
@@ -467,11 +468,11 @@ __device__ void hog_finish_lean(const float* hist, unsigned char* scratch, float
         for (int t = lane; t < 4 * CC; t += 64) {
             const int j = t / CC, c = t - j * CC;
             const int y = c / C, x = c - y * C, ct = x * C + y;
-            const double fj = fac[x + (j & 1) + (y + (j >> 1)) * CB];
-            double acc = 0.0;
+            const FT fj = fac[x + (j & 1) + (y + (j >> 1)) * CB];
+            FT acc = 0;
             for (int k = 0; k < O; ++k) {
-                const double ha = hist[c + k * CC], hb = hist[c + (k + O) * CC];
-                const double haj = fj * ha, hbj = fj * hb;
+                const FT ha = hist[c + k * CC], hb = hist[c + (k + O) * CC];
+                const FT haj = fj * ha, hbj = fj * hb;
                 acc += CL02(haj + hbj);
             }
             desc[ct + (3 * O + j) * CC] = (float)(tex * acc);
@@ -911,7 +912,9 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
         const u64* hfin_p = (const u64*)((unsigned char*)w.hfin + (size_t)hp * a_bytes);
         const float* histf_p = (const float*)((unsigned char*)w.hfin + (size_t)hp * a_bytes);
         float* out_desc = out_row + (long long)(landmark + hp) * lv.P;
-        if (ACC == ACC_COLUMNS) hog_finish_lean<TO, TC>(chist + hp * chist_stride, lds_base, out_desc, lv, lane);
+        // (FT = float was measured: 2.4 % faster, max deviation from the exact-sum mode 1.2e-7 instead of 9e-8 -- not worth
+        // leaving hog.c's double arithmetic)
+        if (ACC == ACC_COLUMNS) hog_finish_lean<TO, TC, double>(chist + hp * chist_stride, lds_base, out_desc, lv, lane);
         else hog_finish_patch<ACC, TO, TC>(w, hfin_p, histf_p, out_desc, lv, lane);
         mark(4);   // normalisation / extraction / store
     }
