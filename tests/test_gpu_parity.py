@@ -155,6 +155,39 @@ def test_ragged_images(gpu_ctx, hog_mode):
         check_features(hog_mode, feat[i:i + 1], of)
 
 
+@pytest.mark.parametrize("pair", [False, True], ids=["one_patch_per_wave", "landmark_pairs"])
+def test_tiny_images(gpu_ctx, hog_mode, pair):
+    """Images only a few pixels wide or high: every horizontal tap pair of the fused kernel sits at an image edge (its
+    paired-byte loads must never leave a row), most of each ROI is zero canvas; a 1-pixel-wide image is served by the
+    generic kernel.  Both the one-patch-per-wave and the landmark-pair geometry."""
+    rng = np.random.default_rng(21)
+    imgs = [rng.integers(0, 256, (h, w)).astype(np.uint8) for (h, w) in [(40, 2), (3, 37), (2, 2), (33, 3), (5, 5), (64, 1)]]
+    n = len(imgs)
+    L = 4
+    x = np.zeros((n, 2 * L), np.float32)
+    for i, im in enumerate(imgs):
+        h, w = im.shape
+        x[i, :L] = rng.uniform(-6, w + 6, L)            # landmark x, some outside
+        x[i, L:] = rng.uniform(-6, h + 6, L)
+        x[i, 0], x[i, 2] = w / 2 - 9.0, w / 2 + 9.0     # eyes 0 and 2: inter-eye distance >= 18 px
+    pt = (1, 5, 6, 4, 1.0) if pair else (1, 5, 8, 4, 1.3)       # S = 30 (pairs) / S = 40
+    op = orc.HoGParam(*pt)
+    gpu_ctx.set_model_geometry(L, [0], [2], [HoGParam(*pt)])
+    for lo, hi in ((0, n - 1), (n - 1, n)):              # the 1-pixel-wide image in its own upload (it selects the generic kernel)
+        gpu_ctx.upload_images(imgs[lo:hi])
+        gpu_ctx.set_sample_image_index(None)
+        gpu_ctx.set_x(x[lo:hi])
+        feat = gpu_ctx.hog_features(0, fetch=True)
+        idx = gpu_ctx.patch_indices()
+        for i in range(lo, hi):
+            of, oidx = orc.hog_features_batch(imgs[i][None], None, x[i:i + 1], [0], [2], op, want_idx=True)
+            assert np.array_equal(idx[i - lo:i - lo + 1], oidx)
+            if hi - lo == 1:        # generic kernel: reference order whatever the mode
+                assert np.array_equal(bits(feat[i - lo:i - lo + 1]), bits(of))
+            else:
+                check_features(hog_mode, feat[i - lo:i - lo + 1], of)
+
+
 def test_large_roi_uses_generic_kernel(gpu_ctx, faces):
     """S = 5*16 = 80 > 64 lanes: served by the generic reference-order kernel (sdm_hog.hip), bit-exact."""
     images, _, _, _, x0 = faces
