@@ -399,7 +399,10 @@ int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int*
             lv.row_tab[d][0] = (b & 1) ? whi : wlo;                              // band b lives in slot b & 1
             lv.row_tab[d][1] = (b & 1) ? wlo : whi;
             memcpy(&lv.row_tab[d][2], &b, sizeof(int));
+            lv.row_tab[d][3] = w2;
         }
+        for (int hh = 1; hh < SDM_SCALE_TAB; ++hh) lv.scale_tab[hh] = 1.0 / ((double)lv.S / (double)(2 * hh));
+        lv.scale_tab[0] = 1.0 / ((double)lv.S / 1.0);      // an empty patch (h <= 0) is given a 1-pixel source
         if (sdm_hog_lds_bytes(lv, 4) > 160 * 1024) return fail(SDM_ERR_INVALID, "HOG geometry exceeds the LDS budget");
         c->levels.push_back(lv); c->params.push_back(p);
         {

@@ -534,7 +534,8 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
     const int sw = empty ? 1 : 2 * h;
     const int x0 = cx - h, y0 = cy - h;
     const bool area2 = (sw == 2 * S);   // both scales exactly 2: INTER_LINEAR is redirected to the 2x2 box average
-    const double scale = 1.0 / ((double)S / (double)sw);
+    // (the f64 divisions of cv::resize's scale come from a per-level table in the kernel arguments: one scalar load)
+    const double scale = (h < SDM_SCALE_TAB) ? lv.scale_tab[h > 0 ? h : 0] : 1.0 / ((double)S / (double)sw);
 
     const int im = uni(im_in);
     const uint8_t* img = imgs.base + imgs.offset[im];
@@ -548,9 +549,10 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
     int px0, px1, a0, a1;             // horizontal resize taps of column d (image columns, masked weights)
     int pl; unsigned wpk;             // ... as ONE 16-bit load at column pl with the weights of its two bytes packed
     {
-        const float hx = (float)((d + 0.5) / (double)cell - 0.5);
-        bxc = vl_floor(hx);
-        wx2 = hx - (float)bxc;
+        // hog.c:697-704 per coordinate: hx = (d + 0.5) / cell - 0.5, cell floor(hx), weights hx - floor(hx) and its
+        // complement -- level constants, computed by the host with the same arithmetic (sdm_set_model_geometry)
+        bxc = __builtin_bit_cast(int, lv.row_tab[d][2]);
+        wx2 = lv.row_tab[d][3];
         wx1 = (float)(1.0 - wx2);
         float f = (float)((d + 0.5) * scale - 0.5);
         const int s = (int)floorf(f);

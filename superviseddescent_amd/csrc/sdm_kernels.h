@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#define SDM_SCALE_TAB 128
 #define SDM_MAX_ORIENT 16  // max undirected orientations (num_bins) a level may ask for
 #define SDM_MAX_EYE 4      // max landmarks averaged per eye centre
 
@@ -25,8 +26,12 @@ struct HogLevelDev {
     int n_sector;              // floor(O/2): sector boundaries inside the first quadrant
     float sector_t[SDM_MAX_ORIENT / 2];   // (float)tan((2j+1)*pi/(2O))
     // per resized-ROI row d < S (level constants, hog.c:697-704, read with scalar loads straight from the kernel arguments):
-    // {weight of band slot 0, weight of band slot 1, cell row index floor(hy) as int bits, 0} -- see ACC_COLUMNS
+    // {weight of band slot 0, weight of band slot 1, cell index floor(h) as int bits, upper weight h - floor(h)} -- the first
+    // three are ACC_COLUMNS' per-row constants, the last two are what every mode's set-up needs per coordinate
     alignas(16) float row_tab[64][4];
+    // 1.0 / ((double)S / (double)(2 h)), cv::resize's source/destination scale (resize.cpp), for patch half-widths
+    // h < SDM_SCALE_TAB; larger patches compute it on the device
+    double scale_tab[SDM_SCALE_TAB];
 };
 
 struct EyeIdxDev {
