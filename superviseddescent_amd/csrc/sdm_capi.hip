@@ -358,6 +358,8 @@ int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int*
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->L = L; c->M = 2 * L;
     c->eyes.nre = nre; c->eyes.nle = nle;
+    c->eyes.inv_nre = (nre > 0 && (nre & (nre - 1)) == 0) ? 1.0f / (float)nre : 0.0f;
+    c->eyes.inv_nle = (nle > 0 && (nle & (nle - 1)) == 0) ? 1.0f / (float)nle : 0.0f;
     for (int i = 0; i < nre; ++i) c->eyes.re[i] = re[i];
     for (int i = 0; i < nle; ++i) c->eyes.le[i] = le[i];
     c->levels.clear(); c->params.clear(); c->fast_kernel.clear(); c->fast_bins.clear();

@@ -64,9 +64,10 @@ __device__ inline double ied_of(const float* __restrict__ xr, int L, const EyeId
 {
     float rx = 0.0f, ry = 0.0f, lx = 0.0f, ly = 0.0f;
     for (int i = 0; i < e.nre; ++i) { rx += xr[e.re[i]]; ry += xr[e.re[i] + L]; }
-    rx /= (float)e.nre; ry /= (float)e.nre;
+    // (helpers.hpp:143-157 divides the f32 sums by the count; for a power of two that is exactly this multiplication)
+    if (e.inv_nre != 0.0f) { rx *= e.inv_nre; ry *= e.inv_nre; } else { rx /= (float)e.nre; ry /= (float)e.nre; }
     for (int i = 0; i < e.nle; ++i) { lx += xr[e.le[i]]; ly += xr[e.le[i] + L]; }
-    lx /= (float)e.nle; ly /= (float)e.nle;
+    if (e.inv_nle != 0.0f) { lx *= e.inv_nle; ly *= e.inv_nle; } else { lx /= (float)e.nle; ly /= (float)e.nle; }
     float dxf = rx - lx, dyf = ry - ly;
     double dx = dxf, dy = dyf;
     return sqrt(dx * dx + dy * dy);

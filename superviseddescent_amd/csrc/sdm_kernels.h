@@ -38,6 +38,8 @@ struct EyeIdxDev {
     int nre, nle;
     int re[SDM_MAX_EYE];
     int le[SDM_MAX_EYE];
+    // 1 / count when the count is a power of two (the f32 division by it is then exactly a multiplication), else 0
+    float inv_nre, inv_nle;
 };
 
 // Image set: a stack of single-channel u8 images addressed through per-image descriptors.
