@@ -188,6 +188,30 @@ def test_tiny_images(gpu_ctx, hog_mode, pair):
                 check_features(hog_mode, feat[i - lo:i - lo + 1], of)
 
 
+def test_large_patch_half_width(gpu_ctx, hog_mode):
+    """Inter-eye distance 300 px: patch half-widths of 150 and 105 px (beyond the kernel's host table of resize scales, so the
+    device computes the scale itself), a 5.5x and a 7x downscale, ROIs hanging over every border of the 640 x 640 image."""
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (640, 640)).astype(np.uint8)
+    L = 6
+    x = np.zeros((2, 2 * L), np.float32)
+    x[:, 0], x[:, 1] = 170.0, 470.0                       # eyes 0 and 1, same row
+    x[:, L + 0] = x[:, L + 1] = 300.0
+    x[0, 2:L] = [20.0, 320.0, 630.0, 100.0]; x[0, L + 2:] = [15.0, 600.0, 320.0, 500.0]
+    x[1, 2:L] = [-40.0, 700.0, 319.5, 320.5]; x[1, L + 2:] = [320.0, 320.0, -60.0, 690.5]
+    for pt in ((1, 5, 11, 4, 1.0), (1, 5, 6, 4, 0.7)):    # S = 55, h = 150 / S = 30 (landmark pairs), h = 105
+        op = orc.HoGParam(*pt)
+        gpu_ctx.set_model_geometry(L, [0], [1], [HoGParam(*pt)])
+        gpu_ctx.upload_images([img, img])
+        gpu_ctx.set_sample_image_index(None)
+        gpu_ctx.set_x(x)
+        got = gpu_ctx.hog_features(0, fetch=True)
+        want, widx = orc.hog_features_batch(np.stack([img, img]), None, x, [0], [1], op, want_idx=True)
+        gidx = gpu_ctx.patch_indices()
+        assert np.array_equal(gidx, widx) and gidx[0, 0] == (150 if pt[2] == 11 else 105)
+        check_features(hog_mode, got, want)
+
+
 def test_large_roi_uses_generic_kernel(gpu_ctx, faces):
     """S = 5*16 = 80 > 64 lanes: served by the generic reference-order kernel (sdm_hog.hip), bit-exact."""
     images, _, _, _, x0 = faces
