@@ -131,7 +131,11 @@ struct sdm_ctx {
     bool timing = false;
     float t_ms[SDM_T_COUNT] = {0};
     int t_n[SDM_T_COUNT] = {0};
-    struct Pending { int slot; hipEvent_t a, b; };
+    struct Pending { int slot; hipEvent_t a, b; bool a_shared; };
+    // inside sdm_detect_batch consecutive timed stages share one event (stop of one = start of the next): every recorded
+    // event is a pipeline bubble of a few microseconds between two kernels
+    hipEvent_t last_stop = nullptr;
+    bool ev_fresh = false, chain_timers = false;
     std::vector<Pending> pending;
     std::vector<hipEvent_t> pool;
 };
@@ -141,12 +145,13 @@ namespace {
 int Mp_of(int M) { return round_up(M, 16); }
 
 struct Timer {
-    sdm_ctx* c; int slot; hipEvent_t a = nullptr, b = nullptr;
+    sdm_ctx* c; int slot; hipEvent_t a = nullptr, b = nullptr; bool a_shared = false;
     Timer(sdm_ctx* ctx, int s) : c(ctx), slot(s)
     {
         if (!c->timing) return;
-        a = take(); b = take();
-        hipError_t e = hipEventRecord(a, c->stream); (void)e;
+        if (c->chain_timers && c->ev_fresh) { a = c->last_stop; a_shared = true; }      // nothing was enqueued since that stop
+        else { a = take(); hipError_t e = hipEventRecord(a, c->stream); (void)e; }
+        b = take();
     }
     hipEvent_t take()
     {
@@ -157,7 +162,8 @@ struct Timer {
     {
         if (!c->timing) return;
         hipError_t e = hipEventRecord(b, c->stream); (void)e;
-        c->pending.push_back({slot, a, b});
+        c->pending.push_back({slot, a, b, a_shared});
+        c->last_stop = b; c->ev_fresh = true;
     }
 };
 
@@ -167,9 +173,11 @@ void drain_timing(sdm_ctx* c)
         hipError_t e = hipEventSynchronize(p.b); (void)e;
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { c->t_ms[p.slot] += ms; c->t_n[p.slot] += 1; }
-        c->pool.push_back(p.a); c->pool.push_back(p.b);
+        if (!p.a_shared) c->pool.push_back(p.a);
+        c->pool.push_back(p.b);
     }
     c->pending.clear();
+    c->ev_fresh = false;
 }
 
 int check_status(sdm_ctx* c)
@@ -224,6 +232,7 @@ int do_hog(sdm_ctx* c, int level)
     if (c->feat_level >= 0 && level_F(c, c->feat_level) != level_F(c, level)) {
         // a different level geometry leaves stale columns beyond its own F: clear the rows once
         HIP_TRY(hipMemsetAsync(c->feat.p, 0, (size_t)c->N * c->ldf * sizeof(float), c->stream));
+        c->ev_fresh = false;      // (untimed work: the next timed stage records its own start)
     }
     {
         Timer t(c, SDM_T_HOG);
@@ -239,6 +248,7 @@ int do_hog(sdm_ctx* c, int level)
         if (c->tmpl_N != c->N || c->tmpl_F != level_F(c, level))
             return fail(SDM_ERR_INVALID, "templates do not match the sample count / feature dimension of this level");
         sdm_launch_subtract_templates(c->feat.p, c->ldf, c->tmpl.p, c->N, c->tmpl_F, c->stream);
+        c->ev_fresh = false;
     }
     HIP_TRY(hipGetLastError());
     c->feat_level = level;
@@ -689,11 +699,14 @@ int sdm_detect_batch(sdm_ctx* c, float* x_host)
 {
     if (!c) return fail(SDM_ERR_INVALID, "null context");
     HIP_TRY(hipSetDevice(c->device));
-    for (int l = 0; l < (int)c->levels.size(); ++l) {
-        int rc = do_hog(c, l);
-        if (rc) return rc;
-        if ((rc = do_apply(c, l))) return rc;
+    c->chain_timers = true; c->ev_fresh = false;
+    int rc = SDM_OK;
+    for (int l = 0; l < (int)c->levels.size() && !rc; ++l) {
+        rc = do_hog(c, l);
+        if (!rc) rc = do_apply(c, l);
     }
+    c->chain_timers = false; c->ev_fresh = false;
+    if (rc) return rc;
     if (x_host) return sdm_get_x(c, x_host);
     return SDM_OK;
 }
