@@ -7,16 +7,16 @@
 // ONE lane per 3 cycles: 192 cycles per wave-instruction, measured with scripts/ubench/lds_atomic*.hip)
 // and by ~11k VALU instructions per patch.
 //
-//  * crop + cv::resize + u8->f32 are fused into the gradient loop: every lane keeps three resized rows of
-//    its column in registers (a rolling window), left/right neighbours come through DPP wave shifts, the
-//    resized ROI never touches LDS; the four source bytes of the next output row are prefetched while the
-//    current row is processed;
-//  * everything that depends only on the column (resize taps, cell index, bilinear weights) lives in
-//    registers for the whole patch; everything that depends only on the row is read once per row from a
-//    small LDS table and moved to scalar registers;
-//  * the histogram is padded by one cell on every side so that the four bilinear updates need no bounds
-//    predicates;
-//  * accumulation has two modes (template ACC):
+//  * crop + cv::resize + u8->f32 are fused into the gradient loop: every lane keeps the two previous resized rows of
+//    its column in registers, left/right neighbours come through DPP wave shifts, the resized ROI never touches
+//    LDS; the two source bytes of a lane's horizontal taps arrive as ONE 16-bit load per source row (requested two
+//    output rows ahead), the horizontal pass is v_perm_b32 + v_dot2_u32_u16, the vertical pass two v_mul_hi_u32_u24;
+//  * everything that depends only on the column (resize taps, cell index, bilinear weights) lives in registers for
+//    the whole patch; everything that depends only on the row sits in a register of lane `row` and is moved to
+//    scalar registers with v_readlane -- or, for the level constants, comes from the kernel arguments by scalar load;
+//  * in the two atomic modes the histogram is padded by one cell on every side so that the four bilinear updates
+//    need no bounds predicates;
+//  * accumulation has three modes (template ACC):
 //      ACC_EXACT_ORDER  ds_add_f32 in the reference's raster order -> histogram bit-identical to hog.c
 //                       (what sdm_hog.hip does; kept for validation, ~3 cycles per contributing pixel);
 //      ACC_FIXED64      every f32 contribution (g*wx)*wy is converted EXACTLY to 2^-36 fixed point (one
@@ -724,9 +724,6 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
     // lane (li, lq) feeds A[row li][k lq] = col[bin li][x = 4 ks + lq], B[k lq][col li] = W[x][li] and receives
     // D[row 4 lq + e][col li]; two accumulators per tile halve the dependent chain.
     auto fold_band = [&](const int b) __attribute__((always_inline)) {
-#ifdef HF_DBG_NOFOLD
-        return;
-#endif
         constexpr int NTB = (2 * TO + 15) / 16 > 0 ? (2 * TO + 15) / 16 : 1;
         const int sl = b & 1;
         const int li = lane & 15, lq = lane >> 4;
