@@ -93,6 +93,7 @@ struct sdm_ctx {
                                   // loads need w >= 2, its packed row tables h < 2^16 -> the generic kernel runs instead
     DevBuf<int> img_idx;
     bool idx_identity = true;
+    int n_idx = 0, max_idx = -1;   // length and largest entry of the sample -> image index (checked against N / n_images per launch)
 
     // samples
     int N = 0;
@@ -221,14 +222,26 @@ int ensure_sample_buffers(sdm_ctx* c, int N)
     return SDM_OK;
 }
 
+// The kernels read img_idx[s] for every s < N and use it as an image number: both bounds are checked at every launch,
+// because the index, the images and x may be set in any order.
+int check_sample_index(const sdm_ctx* c)
+{
+    if (c->idx_identity && c->N > c->n_images)
+        return fail(SDM_ERR_INVALID, "more samples than images and no sample->image index set");
+    if (!c->idx_identity && c->N > c->n_idx)
+        return fail(SDM_ERR_INVALID, "sample->image index is shorter than the sample count");
+    if (!c->idx_identity && c->max_idx >= c->n_images)
+        return fail(SDM_ERR_INVALID, "sample->image index refers to an image beyond the current image set");
+    return SDM_OK;
+}
+
 int do_hog(sdm_ctx* c, int level)
 {
     if (!c->img_base) return fail(SDM_ERR_INVALID, "no images set");
     if (c->N <= 0) return fail(SDM_ERR_INVALID, "no samples set (sdm_set_x)");
     if (c->levels[level].fixed_h == 0 && (c->eyes.nre <= 0 || c->eyes.nle <= 0))
         return fail(SDM_ERR_INVALID, "HOG features need eye landmark indices (IED-adaptive patch size)");
-    if (c->idx_identity && c->N > c->n_images)
-        return fail(SDM_ERR_INVALID, "more samples than images and no sample->image index set");
+    { const int rci = check_sample_index(c); if (rci) return rci; }
     if (c->feat_level >= 0 && level_F(c, c->feat_level) != level_F(c, level)) {
         // a different level geometry leaves stale columns beyond its own F: clear the rows once
         HIP_TRY(hipMemsetAsync(c->feat.p, 0, (size_t)c->N * c->ldf * sizeof(float), c->stream));
@@ -364,16 +377,31 @@ int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int*
     if (2 * L > 144) return fail(SDM_ERR_INVALID, "at most 72 landmarks (2L <= 144) supported");
     for (int i = 0; i < nre; ++i) if (re[i] < 0 || re[i] >= L) return fail(SDM_ERR_INVALID, "right eye index out of range");
     for (int i = 0; i < nle; ++i) if (le[i] < 0 || le[i] >= L) return fail(SDM_ERR_INVALID, "left eye index out of range");
+    // The same geometry again (every test()/detect() call of the host layers binds it): nothing to do -- regressors,
+    // feature rows and the verified binning shortcuts stay resident.
+    if (c->L == L && (int)c->params.size() == n_levels && c->eyes.nre == nre && c->eyes.nle == nle) {
+        bool same = true;
+        for (int i = 0; i < nre && same; ++i) same = c->eyes.re[i] == re[i];
+        for (int i = 0; i < nle && same; ++i) same = c->eyes.le[i] == le[i];
+        for (int l = 0; l < n_levels && same; ++l)
+            same = c->params[l].variant == levels[l].variant && c->params[l].num_cells == levels[l].num_cells &&
+                   c->params[l].cell_size == levels[l].cell_size && c->params[l].num_bins == levels[l].num_bins &&
+                   c->params[l].relative_patch_size == levels[l].relative_patch_size;
+        if (same) return SDM_OK;
+    }
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->L = L; c->M = 2 * L;
-    c->eyes.nre = nre; c->eyes.nle = nle;
-    c->eyes.inv_nre = (nre > 0 && (nre & (nre - 1)) == 0) ? 1.0f / (float)nre : 0.0f;
-    c->eyes.inv_nle = (nle > 0 && (nle & (nle - 1)) == 0) ? 1.0f / (float)nle : 0.0f;
-    for (int i = 0; i < nre; ++i) c->eyes.re[i] = re[i];
-    for (int i = 0; i < nle; ++i) c->eyes.le[i] = le[i];
-    c->levels.clear(); c->params.clear(); c->fast_kernel.clear(); c->fast_bins.clear();
-    c->Fmax = 0;
+    // Everything is built into locals and committed only when every level has passed: an error leaves the context as it was.
+    EyeIdxDev eyes{};
+    eyes.nre = nre; eyes.nle = nle;
+    eyes.inv_nre = (nre > 0 && (nre & (nre - 1)) == 0) ? 1.0f / (float)nre : 0.0f;
+    eyes.inv_nle = (nle > 0 && (nle & (nle - 1)) == 0) ? 1.0f / (float)nle : 0.0f;
+    for (int i = 0; i < nre; ++i) eyes.re[i] = re[i];
+    for (int i = 0; i < nle; ++i) eyes.le[i] = le[i];
+    std::vector<HogLevelDev> n_levels_dev;
+    std::vector<sdm_hog_param> n_params;
+    std::vector<int> n_fast_kernel, n_fast_bins;
+    int Fmax = 0;
     for (int l = 0; l < n_levels; ++l) {
         const sdm_hog_param& p = levels[l];
         if (p.variant != SDM_VARIANT_DALALTRIGGS && p.variant != SDM_VARIANT_UOCTTI)
@@ -416,24 +444,36 @@ int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int*
         for (int hh = 1; hh < SDM_SCALE_TAB; ++hh) lv.scale_tab[hh] = 1.0 / ((double)lv.S / (double)(2 * hh));
         lv.scale_tab[0] = 1.0 / ((double)lv.S / 1.0);      // an empty patch (h <= 0) is given a 1-pixel source
         if (sdm_hog_lds_bytes(lv, 4) > 160 * 1024) return fail(SDM_ERR_INVALID, "HOG geometry exceeds the LDS budget");
-        c->levels.push_back(lv); c->params.push_back(p);
+        n_levels_dev.push_back(lv); n_params.push_back(p);
         {
-            // exhaustive on-device check of the orientation shortcut for this level's orientation count
-            int mism[2] = {1, 1};
-            ScopedBuf<int> dm;
-            int rcv = dm.ensure(2, true, c->stream);
-            if (rcv) return rcv;
-            sdm_launch_verify_fast_bins(lv, dm.p, c->stream);
-            HIP_TRY(hipMemcpyAsync(mism, dm.p, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            dm.release();
-            // 2 = sector count, 1 = un-normalised arg-max, 0 = reference arithmetic
-            c->fast_bins.push_back(mism[1] == 0 ? 2 : (mism[0] == 0 ? 1 : 0));
-            c->fast_kernel.push_back(sdm_hog_fast_supported(lv) ? 1 : 0);
+            // exhaustive on-device check of the orientation shortcut for this level's orientation count (levels that share
+            // an orientation count share the verdict)
+            int verdict = -1;
+            for (int q = 0; q < l && verdict < 0; ++q)
+                if (n_levels_dev[q].O == lv.O) verdict = n_fast_bins[q];
+            if (verdict < 0) {
+                int mism[2] = {1, 1};
+                ScopedBuf<int> dm;
+                int rcv = dm.ensure(2, true, c->stream);
+                if (rcv) return rcv;
+                sdm_launch_verify_fast_bins(lv, dm.p, c->stream);
+                HIP_TRY(hipMemcpyAsync(mism, dm.p, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                dm.release();
+                // 2 = sector count, 1 = un-normalised arg-max, 0 = reference arithmetic
+                verdict = mism[1] == 0 ? 2 : (mism[0] == 0 ? 1 : 0);
+            }
+            n_fast_bins.push_back(verdict);
+            n_fast_kernel.push_back(sdm_hog_fast_supported(lv) ? 1 : 0);
         }
         const int F = L * lv.P + (lv.fixed_h > 0 ? 0 : 1);
-        if (F > c->Fmax) c->Fmax = F;
+        if (F > Fmax) Fmax = F;
     }
+    // ---- commit ----
+    c->L = L; c->M = 2 * L;
+    c->eyes = eyes;
+    c->levels.swap(n_levels_dev); c->params.swap(n_params); c->fast_kernel.swap(n_fast_kernel); c->fast_bins.swap(n_fast_bins);
+    c->Fmax = Fmax;
     c->rhs_tiles = (round_up(c->M, 16) + 127) / 128;
     c->ldf = (long long)round_up(c->Fmax, 128) + 128 * c->rhs_tiles;
     for (auto& r : c->Rt) r.release();
@@ -529,16 +569,19 @@ int sdm_set_images_device(sdm_ctx* c, const uint8_t* dev_base, int n, int w, int
 int sdm_set_sample_image_index(sdm_ctx* c, const int* idx, int n)
 {
     if (!c) return fail(SDM_ERR_INVALID, "null context");
-    if (!idx) { c->idx_identity = true; return SDM_OK; }
+    if (!idx) { c->idx_identity = true; c->n_idx = 0; c->max_idx = -1; return SDM_OK; }
     if (n <= 0) return fail(SDM_ERR_INVALID, "bad sample count");
-    for (int i = 0; i < n; ++i)
+    int mx = -1;
+    for (int i = 0; i < n; ++i) {
         if (idx[i] < 0 || (c->n_images > 0 && idx[i] >= c->n_images)) return fail(SDM_ERR_INVALID, "image index out of range");
+        if (idx[i] > mx) mx = idx[i];
+    }
     HIP_TRY(hipSetDevice(c->device));
     int rc = c->img_idx.ensure(n);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(c->img_idx.p, idx, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->idx_identity = false;
+    c->idx_identity = false; c->n_idx = n; c->max_idx = mx;
     return SDM_OK;
 }
 
@@ -902,6 +945,7 @@ int sdm_debug_patch(sdm_ctx* c, int level, int sample, int landmark, uint8_t* rs
     if (!c || level < 0 || level >= (int)c->levels.size()) return fail(SDM_ERR_INVALID, "bad level");
     if (sample < 0 || sample >= c->N || landmark < 0 || landmark >= c->L) return fail(SDM_ERR_INVALID, "bad patch");
     if (!c->img_base) return fail(SDM_ERR_INVALID, "no images set");
+    { const int rci = check_sample_index(c); if (rci) return rci; }
     HIP_TRY(hipSetDevice(c->device));
     const HogLevelDev& lv = c->levels[level];
     const size_t nS = (size_t)lv.S * lv.S, nH = (size_t)2 * lv.O * lv.C * lv.C, nP = lv.P;
@@ -924,6 +968,7 @@ int sdm_debug_hog_profile(sdm_ctx* c, int level, unsigned long long* out8)
 {
     if (!c || level < 0 || level >= (int)c->levels.size() || !out8) return fail(SDM_ERR_INVALID, "bad arguments");
     if (!c->img_base || c->N <= 0) return fail(SDM_ERR_INVALID, "no images / samples set");
+    { const int rci = check_sample_index(c); if (rci) return rci; }
     HIP_TRY(hipSetDevice(c->device));
     ScopedBuf<unsigned long long> d;
     int rc = d.ensure(8, true, c->stream);

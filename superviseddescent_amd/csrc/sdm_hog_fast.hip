@@ -44,6 +44,9 @@
 
 #pragma clang fp contract(off)
 
+#ifndef SDM_EXP_BOOLBIN
+#define SDM_EXP_BOOLBIN 1
+#endif
 #define HF_WAVES 4
 #define HF_PREFETCH 2   /* rows in flight = rows per unrolled group (the slot of row y is y & 1) */
 #define ACC_EXACT_ORDER 0
@@ -176,6 +179,22 @@ __device__ inline void bin_sector(float gx, float gy, const HogLevelDev& lv, int
     else bin = d >= 2 * O ? d - 2 * O : d;
 }
 
+// The same for 4 orientations, as the three bits of the directed bin (8 bins of 45 degrees).  With A = |gy| > |gx| t0,
+// B = |gy| > |gx| t1 (B implies A: m = A + B), X = gx < 0, Y = gy < 0 and s = X xor Y (= fx < 0 above whenever it matters:
+// for gx == 0 both boundaries are exceeded, m = 2, and d = 2 either way):  d = s ? 4 - m : m has bit0 = A & ~B,
+// bit1 = (bit0 & s) | B, bit2 = s & ~A, and bin = (d + 4 Y) mod 8 only flips bit2.  Checked against bin_sector for all
+// 511 x 511 gradients by verify_fast_bins_kernel.
+__device__ inline void bin_sector4_bits(float gx, float gy, const HogLevelDev& lv, bool& b0, bool& b1, bool& b2)
+{
+    const float a = __builtin_fabsf(gx), b = __builtin_fabsf(gy);
+    const bool A = b > a * lv.sector_t[0], B = b > a * lv.sector_t[1];
+    const bool X = gx < 0.0f, Y = gy < 0.0f;
+    const bool s = X != Y;
+    b0 = A != B;
+    b1 = (b0 && s) || B;
+    b2 = (s && !A) != Y;
+}
+
 // per-wave LDS layout.  Region A lives for the whole patch, region B is first the rolling private
 // accumulators of the row loop and afterwards the scratch of the normalisation phase.
 struct FastLds {
@@ -212,7 +231,24 @@ __host__ __device__ inline size_t fast_copies_bytes(int C, int O, bool pair)
 
 // ---- ACC_COLUMNS per-wave layout: [ column rows f32 [2O][ST][2 band slots] | later: nrm, fac, desc of the finish phase ]
 //      [ finished histograms f32 [patches][2O][C*C] ] ----
-__host__ __device__ inline int fast_columns_stride(int cell, int C, bool pair) { return pair ? 64 : ((C * cell + 7) & ~7); }
+// pixel columns folded per band (a multiple of 8: two MFMA k-steps of 4 columns per trip) and the stride between the
+// column rows of two bins.  The stride is padded so that 2 * stride = 20 (mod 32) dwords: the fold reads the 16 bin rows of
+// one pixel column with ONE ds_read_b32 (banks = dword mod 32) -- with the unpadded strides 56 / 40 / 64 the sixteen rows
+// fell into 2 / 2 / 1 banks (8- and 16-way conflicts, 58 % of all LDS cycles in the round-1 counters), now into 8
+// (2-way, which a 32-bit LDS access hides) -- and so that the row loop's per-lane 8-byte read-modify-write of [bin][x]
+// (banks = dword mod 64) only collides for lanes >= 6 columns apart whose bins differ.
+#ifndef SDM_EXP_PAD
+#define SDM_EXP_PAD 1
+#endif
+__host__ __device__ inline int fast_columns_k(int cell, int C, bool pair) { return pair ? 64 : ((C * cell + 7) & ~7); }
+__host__ __device__ inline int fast_columns_stride(int cell, int C, bool pair)
+{
+    const int k = fast_columns_k(cell, C, pair);
+    if (!SDM_EXP_PAD) return k;
+    int st = k + 2;
+    while ((2 * st) % 32 != 20 && (2 * st) % 32 != 12) st += 2;
+    return st;
+}
 __host__ __device__ inline size_t fast_columns_rows_bytes(int cell, int C, int O, bool pair)
 {
     return al16((size_t)2 * O * fast_columns_stride(cell, C, pair) * 8);
@@ -614,7 +650,7 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
 
     mark(0);   // geometry + per-coordinate tables
     float* colrows = (float*)lds_base;      // ACC_COLUMNS: [2O][ST][2 band slots]
-    const int ST = fast_columns_stride(cell, C, PAIR);
+    const int ST = fast_columns_stride(cell, C, PAIR), KST = fast_columns_k(cell, C, PAIR);
     float* chist = (float*)(lds_base + fast_columns_hist_off(cell, C, O, D, PAIR));    // [patch][2O][CC]
     const int chist_stride = (int)(fast_columns_hist_bytes(C, O) / 4);
     if (ACC == ACC_COLUMNS) {
@@ -717,6 +753,8 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
     // (lanes beyond the ROI share column 0, which is never active: its sums are finite garbage with fold weight 0)
     const unsigned col_off = (unsigned)(PAIR ? lane : (col < S ? col : 0)) * 8u;
     const unsigned bin_stride = (unsigned)(ST * 8);
+    unsigned col_off1 = col_off + bin_stride;      // (opaque: the select between the two bases is then ONE v_cndmask)
+    asm volatile("" : "+v"(col_off1));
     f32x2* pend_p = (f32x2*)((unsigned char*)colrows + col_off);
     f32x2 pend_v = {0.0f, 0.0f};
     int prev_by = -1;
@@ -741,7 +779,7 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
         // the accumulators in place -- guarding unrolled steps individually makes the compiler shuttle them through VGPRs)
         // (ST is a multiple of 8: an even number of k steps, two per trip, one accumulator each; a plain counted loop keeps
         // the accumulators in place -- guarding unrolled steps individually makes the compiler shuttle them through VGPRs)
-        for (int kp = 0; kp < ST / 8; ++kp) {
+        for (int kp = 0; kp < KST / 8; ++kp) {
             const float bw0 = bp[0], bw1 = bp[64];
 #pragma unroll
             for (int t = 0; t < NTB; ++t) {
@@ -798,7 +836,15 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
             const float g2 = gx * gx + gy * gy;
             float g = FASTBIN == 2 ? sqrt_int_up(g2) : (FASTBIN == 1 ? sqrt_int_exact(g2) : sqrtf(g2));
             int bin;
-            if (FASTBIN == 2) {
+            unsigned bin_off = 0;      // ACC_COLUMNS: byte offset of the bin's column row
+            if (FASTBIN == 2 && TO == 4 && ACC == ACC_COLUMNS && SDM_EXP_BOOLBIN) {
+                // 4 orientations = 8 directed bins of 45 degrees: the three bits of the bin as lane masks (the compiler keeps
+                // them in scalar registers and combines them on the scalar unit), see bin_sector4_bits
+                bool b0, b1, b2;
+                bin_sector4_bits(gx, gy, lv, b0, b1, b2);
+                bin_off = (b0 ? col_off1 : col_off) + (b1 ? 2u * bin_stride : 0u) + (b2 ? 4u * bin_stride : 0u);
+                bin = 0;
+            } else if (FASTBIN == 2) {
                 bin_sector<TO>(gx, gy, lv, O, bin);
             } else if (FASTBIN == 1) {
                 float best = 0.0f;
@@ -842,7 +888,8 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
                 }
                 // this row: g * (slot weights) into the two band slots of this lane's own column, next iteration
                 // (24-bit multiply-add on the bin + the lane's byte offset)
-                pend_p = (f32x2*)((unsigned char*)colrows + (__umul24((unsigned)bin, bin_stride) + col_off));
+                if (FASTBIN == 2 && TO == 4 && SDM_EXP_BOOLBIN) pend_p = (f32x2*)((unsigned char*)colrows + bin_off);
+                else pend_p = (f32x2*)((unsigned char*)colrows + (__umul24((unsigned)bin, bin_stride) + col_off));
                 pend_v = (f32x2){ws0, ws1} * g;
             } else {
             // (grad * wx) * wy, hog.c:714-723: six f32 products as three packed multiplies
@@ -972,7 +1019,12 @@ __global__ void verify_fast_bins_kernel(HogLevelDev lv, int* __restrict__ mismat
     const bool sqrt1_ok = __builtin_bit_cast(int, sqrt_int_up(g2)) == want;
     // mode 1: un-normalised arg-max + two-sided sqrt;  mode 2: sector count + one-sided sqrt, where a pixel the
     // reference skips (a == -1) may carry any valid bin as long as its magnitude is exactly 0
-    const bool sector_ok = (a == c) || (a == -1 && g == 0.0f && c >= 0 && c < 2 * lv.O);
+    bool sector_ok = (a == c) || (a == -1 && g == 0.0f && c >= 0 && c < 2 * lv.O);
+    if (lv.O == 4) {
+        bool b0, b1, b2;
+        bin_sector4_bits(gx, gy, lv, b0, b1, b2);
+        sector_ok = sector_ok && ((int)b0 + 2 * (int)b1 + 4 * (int)b2 == c);
+    }
     if (a != b || !sqrt2_ok) atomicAdd(mismatches, 1);
     if (!sector_ok || !sqrt1_ok) atomicAdd(mismatches + 1, 1);
 }
