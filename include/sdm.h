@@ -203,6 +203,16 @@ int sdm_debug_patch(sdm_ctx* ctx, int level, int sample, int landmark, uint8_t* 
  * [0] geometry/tables [1] histogram clear [2] row loop [3] barrier [4] normalisation [5] output stores, [7] waves. */
 int sdm_debug_hog_profile(sdm_ctx* ctx, int level, unsigned long long* out8);
 int sdm_debug_gradient_table(sdm_ctx* ctx, int level, float* g_511x511, int* bin_511x511);
+/* Lane packing of the HOG launch (default on; also SDM_HOG_NO_PACK=1 in the environment at sdm_create): in SDM_HOG_COLUMNS
+ * mode a wave walks a GROUP of patches of one sample in passes of 64 pixel columns instead of one patch per wave (a 50-column
+ * ROI then fills the wave).  Same integer decisions; a patch cut by a pass boundary sums its cells from two partial folds.
+ * Off = one patch (or one landmark pair) per wave, for A/B comparison in tests. */
+int sdm_debug_set_hog_packing(sdm_ctx* ctx, int on);
+/* The packing plan of a level geometry (host only, no device needed): info5 = {G, P, n_main, Gt, Pt} (G == 0: no packed
+ * instance for this geometry); lane_tab [passes][64], wb [passes][64][16], pass_info [passes][4] as documented in
+ * superviseddescent_amd/csrc/sdm_kernels.h (HogPlanDev); passes = P + Pt <= max_passes. */
+int sdm_debug_hog_plan(int num_cells, int cell_size, int num_bins, int num_landmarks, int* info5, unsigned* lane_tab,
+                       float* wb, int* pass_info, int max_passes);
 
 #ifdef __cplusplus
 }

@@ -7,6 +7,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -78,6 +79,10 @@ struct sdm_ctx {
     std::vector<sdm_hog_param> params;
     std::vector<int> fast_kernel;   // per level: fused S<=64 kernel usable
     std::vector<int> fast_bins;     // per level: un-normalised arg-max verified on all 511x511 gradients
+    // per level: lane-packed launch plan (sdm_hog_fast.hip::hog_packed_kernel), device tables owned here
+    struct Plan { bool ok = false; HogPlanDev dev{}; DevBuf<unsigned> lane_tab; DevBuf<float> wb; DevBuf<int> pass_info; };
+    std::vector<Plan> plans;
+    bool packing = true;            // sdm_debug_set_hog_packing / SDM_HOG_NO_PACK=1: run the one-patch-per-wave kernel instead
     int hog_mode = SDM_HOG_COLUMNS;
     int Fmax = 0;
     long long ldf = 0;      // feature row stride: round_up(Fmax,128) + 128*rhs_tiles (tail tiles = training targets)
@@ -249,7 +254,12 @@ int do_hog(sdm_ctx* c, int level)
     }
     {
         Timer t(c, SDM_T_HOG);
-        if (c->fast_kernel[level] && !c->narrow_images)
+        if (c->fast_kernel[level] && !c->narrow_images && c->packing && c->hog_mode == SDM_HOG_COLUMNS &&
+            c->fast_bins[level] == 2 && c->plans[level].ok)
+            sdm_launch_hog_packed(image_set(c), c->idx_identity ? nullptr : c->img_idx.p, c->x[c->cur].p, c->N, c->L,
+                                  c->eyes, c->levels[level], c->plans[level].dev, c->feat.p, c->ldf, c->patch_idx.p,
+                                  c->status.p, c->stream);
+        else if (c->fast_kernel[level] && !c->narrow_images)
             sdm_launch_hog_fast(image_set(c), c->idx_identity ? nullptr : c->img_idx.p, c->x[c->cur].p, c->N, c->L,
                                 c->eyes, c->levels[level], c->feat.p, c->ldf, c->patch_idx.p, c->status.p,
                                 c->hog_mode /* = the kernel's ACC_* value */, c->fast_bins[level], c->stream);
@@ -326,6 +336,7 @@ sdm_ctx* sdm_create(int device)
         fail(SDM_ERR_HIP, "hipStreamCreate failed"); delete c; return nullptr;
     }
     if (c->status.ensure(1, true, c->stream) || c->lambda_dev.ensure(1, true, c->stream)) { delete c; return nullptr; }
+    { const char* np = getenv("SDM_HOG_NO_PACK"); c->packing = !(np && np[0] == '1'); }
     return c;
 }
 
@@ -346,6 +357,7 @@ void sdm_destroy(sdm_ctx* c)
     c->xstar.release(); c->tmpl.release(); c->feat.release(); c->patch_idx.release(); c->status.release();
     c->partial.release(); c->G.release(); c->gpack.release(); c->fro.release(); c->Rsol.release(); c->winv.release(); c->lambda_dev.release();
     for (auto& r : c->Rt) r.release();
+    for (auto& q : c->plans) { q.lane_tab.release(); q.wb.release(); q.pass_info.release(); }
     if (c->own_stream) e = hipStreamDestroy(c->stream);
     delete c;
 }
@@ -469,7 +481,29 @@ int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int*
         const int F = L * lv.P + (lv.fixed_h > 0 ? 0 : 1);
         if (F > Fmax) Fmax = F;
     }
+    // lane-packed launch plans (tables in HBM, a few KB per level)
+    std::vector<sdm_ctx::Plan> n_plans(n_levels);
+    for (int l = 0; l < n_levels; ++l) {
+        HogPlanHost hp;
+        if (!n_fast_kernel[l] || n_fast_bins[l] != 2 || !sdm_hog_plan_build(n_levels_dev[l], L, hp)) continue;
+        sdm_ctx::Plan& pl = n_plans[l];
+        int rcp;
+        if ((rcp = pl.lane_tab.ensure(hp.lane_tab.size())) || (rcp = pl.wb.ensure(hp.wb.size())) ||
+            (rcp = pl.pass_info.ensure(hp.pass_info.size()))) {
+            for (auto& q : n_plans) { q.lane_tab.release(); q.wb.release(); q.pass_info.release(); }
+            return rcp;
+        }
+        HIP_TRY(hipMemcpyAsync(pl.lane_tab.p, hp.lane_tab.data(), hp.lane_tab.size() * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(pl.wb.p, hp.wb.data(), hp.wb.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(pl.pass_info.p, hp.pass_info.data(), hp.pass_info.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));      // (the host vectors go out of scope)
+        pl.dev.G = hp.G; pl.dev.P = hp.P; pl.dev.n_main = hp.n_main; pl.dev.Gt = hp.Gt; pl.dev.Pt = hp.Pt;
+        pl.dev.lane_tab = pl.lane_tab.p; pl.dev.wb = pl.wb.p; pl.dev.pass_info = pl.pass_info.p;
+        pl.ok = true;
+    }
     // ---- commit ----
+    for (auto& q : c->plans) { q.lane_tab.release(); q.wb.release(); q.pass_info.release(); }
+    c->plans.swap(n_plans);
     c->L = L; c->M = 2 * L;
     c->eyes = eyes;
     c->levels.swap(n_levels_dev); c->params.swap(n_params); c->fast_kernel.swap(n_fast_kernel); c->fast_bins.swap(n_fast_bins);
@@ -980,6 +1014,39 @@ int sdm_debug_hog_profile(sdm_ctx* c, int level, unsigned long long* out8)
     HIP_TRY(hipStreamSynchronize(c->stream));
     d.release();
     c->feat_level = level;
+    return SDM_OK;
+}
+
+int sdm_debug_set_hog_packing(sdm_ctx* c, int on)
+{
+    if (!c) return fail(SDM_ERR_INVALID, "null context");
+    c->packing = on != 0;
+    return SDM_OK;
+}
+
+int sdm_debug_hog_plan(int num_cells, int cell_size, int num_bins, int num_landmarks, int* info5, unsigned* lane_tab,
+                       float* wb, int* pass_info, int max_passes)
+{
+    HogLevelDev lv;
+    memset(&lv, 0, sizeof(lv));
+    lv.variant = SDM_VARIANT_UOCTTI; lv.C = num_cells; lv.cell = cell_size; lv.O = num_bins; lv.S = num_cells * cell_size;
+    for (int d = 0; d < 64 && d < lv.S; ++d) {      // as sdm_set_model_geometry
+        const float hx = (float)((d + 0.5) / (double)lv.cell - 0.5);
+        int b = (int)hx;
+        if (!(hx >= 0.0f || (float)b == hx)) b -= 1;
+        const float w2 = hx - (float)b;
+        memcpy(&lv.row_tab[d][2], &b, sizeof(int));
+        lv.row_tab[d][3] = w2;
+    }
+    HogPlanHost hp;
+    if (!info5) return fail(SDM_ERR_INVALID, "bad arguments");
+    if (!sdm_hog_plan_build(lv, num_landmarks, hp)) { info5[0] = 0; return SDM_OK; }
+    info5[0] = hp.G; info5[1] = hp.P; info5[2] = hp.n_main; info5[3] = hp.Gt; info5[4] = hp.Pt;
+    const int np = hp.P + hp.Pt;
+    if (np > max_passes) return fail(SDM_ERR_INVALID, "plan has more passes than the output buffers hold");
+    if (lane_tab) memcpy(lane_tab, hp.lane_tab.data(), hp.lane_tab.size() * sizeof(unsigned));
+    if (wb) memcpy(wb, hp.wb.data(), hp.wb.size() * sizeof(float));
+    if (pass_info) memcpy(pass_info, hp.pass_info.data(), hp.pass_info.size() * sizeof(int));
     return SDM_OK;
 }
 

@@ -41,6 +41,8 @@
 //  * blockIdx is remapped so that the 22/68 patches of one face run on one XCD (its image is then fetched
 //    from HBM into one L2 instead of eight).
 #include "sdm_kernels.h"
+#include <string.h>
+#include <vector>
 
 #pragma clang fp contract(off)
 
@@ -1002,6 +1004,341 @@ hog_fast_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float* 
     if (lv.fixed_h == 0 && iw == Lw - 1 && (threadIdx.x & 63) == 0) row[(long long)L * lv.P] = 1.0f;
 }
 
+
+// =====================================================================================================================
+// Lane-packed kernel (ACC_COLUMNS arithmetic, 4 orientations, 5 x 5 cells): one wave walks a GROUP of patches of one sample
+// in passes of 64 pixel columns (HogPlanDev, sdm_kernels.h).  Per group: inter-eye distance, patch half-width, resize
+// scale and the per-coordinate tap tables ONCE (they are the same for every landmark of a sample, adaptive_vlhog.hpp:123);
+// per pass: every lane fetches the taps of ITS column from the lane that computed that coordinate (ds_bpermute), applies
+// its own patch's image borders, and the row loop of hog_patch_fast's two-patch form runs unchanged -- each lane adds
+// g * wy to its own pixel column [bin][lane][band slot]; the band folds multiply the 64 columns by the pass's weight
+// table (16 registers per lane, loaded per pass) on the matrix cores and ADD the cells to the histograms of the up to
+// three patches the pass touches (a patch cut by a pass boundary gets its cells from two passes).  A patch is normalised
+// and stored as soon as its last column has been folded; its histogram slot is then free for the patch three further on.
+// Same integer decisions and the same f32 operations per accumulator as hog_patch_fast<ACC_COLUMNS>, except that the cells
+// of a cut patch are the sum of two partial folds.
+#define HP_WAVES 4
+#define HP_ST 70                    /* = fast_columns_stride(.., pair): 64 pixel columns + padding (2 * 70 = 12 mod 32 dwords) */
+#define HP_HIST_SLOTS 3
+#define HP_ROWS_BYTES(O) ((size_t)2 * (O) * HP_ST * 8)
+#define HP_HIST_BYTES(O, CC) ((size_t)2 * (O) * (CC) * 4)
+__host__ __device__ inline size_t packed_scratch_bytes(int C) { return al16((size_t)C * C * 4) + al16((size_t)(C + 1) * (C + 1) * 8); }
+__host__ __device__ inline size_t packed_lds_bytes(int C, int O)
+{
+    return al16(HP_ROWS_BYTES(O)) + HP_HIST_SLOTS * al16(HP_HIST_BYTES(O, C * C)) + packed_scratch_bytes(C);
+}
+
+// hog_finish_lean with the descriptor written straight to the feature row (no staging copy: 2 KB less LDS per wave)
+template <int TO, int TC>
+__device__ void hog_finish_direct(const float* hist, unsigned char* scratch, float* __restrict__ out_desc,
+                                  const HogLevelDev& lv, int lane)
+{
+    typedef double FT;
+    constexpr int O = TO, C = TC, CC = C * C, CB = C + 1;
+    float* nrm = (float*)scratch;
+    FT* fac = (FT*)(scratch + al16((size_t)CC * 4));
+    for (int c = lane; c < CC; c += 64) {                       // cell norms (hog.c:875-890)
+        float n = 0.0f;
+        for (int k = 0; k < O; ++k) {
+            const float hs = hist[c + k * CC] + hist[c + (k + O) * CC];
+            n += hs * hs;
+        }
+        nrm[c] = n;
+    }
+    wave_sync();
+    for (int t = lane; t < CB * CB; t += 64) {                  // block factors (hog.c:930-981): see hog_finish_patch
+        const int byb = t / CB, bxb = t - byb * CB;
+        const int xa = bxb - 1 > 0 ? bxb - 1 : 0, xb = bxb < C - 1 ? bxb : C - 1;
+        const int ya = byb - 1 > 0 ? byb - 1 : 0, yb = byb < C - 1 ? byb : C - 1;
+        const FT na = nrm[xa + ya * C], nb = nrm[xb + ya * C];
+        const FT nc = nrm[xa + yb * C], nd = nrm[xb + yb * C];
+        fac[t] = (FT)1.0 / (FT)sqrt(na + nb + nc + nd + (FT)1e-4);
+    }
+    wave_sync();
+#define CL02(v) __builtin_fmin(0.2, (v))
+    for (int t = lane; t < O * CC; t += 64) {                   // hog.c:985-1033, Matlab order of adaptive_vlhog.hpp:166-175
+        const int k = t / CC, c = t - k * CC;
+        const int y = c / C, x = c - y * C, ct = x * C + y;
+        const FT ha = hist[c + k * CC], hb = hist[c + (k + O) * CC];
+        const FT f1 = fac[x + y * CB], f2 = fac[x + 1 + y * CB];
+        const FT f3 = fac[x + (y + 1) * CB], f4 = fac[x + 1 + (y + 1) * CB];
+        FT ha1 = f1 * ha, ha2 = f2 * ha, ha3 = f3 * ha, ha4 = f4 * ha;
+        FT hb1 = f1 * hb, hb2 = f2 * hb, hb3 = f3 * hb, hb4 = f4 * hb;
+        FT hc1 = ha1 + hb1, hc2 = ha2 + hb2, hc3 = ha3 + hb3, hc4 = ha4 + hb4;
+        ha1 = CL02(ha1); ha2 = CL02(ha2); ha3 = CL02(ha3); ha4 = CL02(ha4);
+        hb1 = CL02(hb1); hb2 = CL02(hb2); hb3 = CL02(hb3); hb4 = CL02(hb4);
+        hc1 = CL02(hc1); hc2 = CL02(hc2); hc3 = CL02(hc3); hc4 = CL02(hc4);
+        if (lv.variant == 1) {
+            out_desc[ct + k * CC] = (float)((FT)0.5 * (ha1 + ha2 + ha3 + ha4));
+            out_desc[ct + (k + O) * CC] = (float)((FT)0.5 * (hb1 + hb2 + hb3 + hb4));
+            out_desc[ct + (k + 2 * O) * CC] = (float)((FT)0.5 * (hc1 + hc2 + hc3 + hc4));
+        } else {
+            out_desc[ct + k * CC] = (float)hc1;
+            out_desc[ct + (k + O) * CC] = (float)hc2;
+            out_desc[ct + (k + 2 * O) * CC] = (float)hc3;
+            out_desc[ct + (k + 3 * O) * CC] = (float)hc4;
+        }
+    }
+    if (lv.variant == 1) {                                      // texture sums (hog.c:1020-1023, 1047-1052)
+        const float tex = 1.0f / sqrtf(18.0f);
+        for (int t = lane; t < 4 * CC; t += 64) {
+            const int j = t / CC, c = t - j * CC;
+            const int y = c / C, x = c - y * C, ct = x * C + y;
+            const FT fj = fac[x + (j & 1) + (y + (j >> 1)) * CB];
+            FT acc = 0;
+            for (int k = 0; k < O; ++k) {
+                const FT ha = hist[c + k * CC], hb = hist[c + (k + O) * CC];
+                const FT haj = fj * ha, hbj = fj * hb;
+                acc += CL02(haj + hbj);
+            }
+            out_desc[ct + (3 * O + j) * CC] = (float)(tex * acc);
+        }
+    }
+#undef CL02
+    wave_sync();
+}
+
+template <int TO, int TC>
+__global__ void __launch_bounds__(HP_WAVES * 64)
+hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float* __restrict__ x, int N, int L,
+                  EyeIdxDev eyes, HogLevelDev lv, HogPlanDev plan, float* __restrict__ feat, long long ldf,
+                  int* __restrict__ idx_out, int* __restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int O = TO, C = TC, CC = C * C;
+    constexpr int ST = HP_ST;
+    static_assert(2 * TO <= 16 && SDM_PLAN_MAX_SEG * TC <= 16, "one 16 x 16 matrix-core tile: 2O bin rows, 3 patches x C cell columns");
+    const int lane = threadIdx.x & 63;
+    const int wave = uni(threadIdx.x >> 6);
+    // XCD-aware remap (bijective): the workgroups the dispatcher places on XCD b % 8 take a contiguous run of groups, so the
+    // groups of one sample meet in one L2
+    const unsigned nb = gridDim.x, bid = blockIdx.x;
+    const unsigned q8 = nb / 8, r8 = nb % 8, xcd = bid % 8;
+    const unsigned blk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / 8;
+    const int gpf = plan.n_main + (plan.Gt > 0 ? 1 : 0);            // groups per sample
+    const long long wid = (long long)blk * HP_WAVES + wave;
+    if (wid >= (long long)N * gpf) return;                           // (no workgroup barrier anywhere below)
+    const int s = (int)(wid / gpf), g = (int)(wid - (long long)s * gpf);
+    const bool main_group = g < plan.n_main;
+    const int lm0 = main_group ? g * plan.G : plan.n_main * plan.G;   // first landmark of the group
+    const int npass = main_group ? plan.P : plan.Pt;
+    const int pass0 = main_group ? 0 : plan.P;
+    const int S = lv.S;
+
+    unsigned char* lds = smem + (size_t)wave * packed_lds_bytes(C, O);
+    float* colrows = (float*)lds;                                                    // [2O][ST][2 band slots]
+    float* hist = (float*)(lds + al16(HP_ROWS_BYTES(O)));                            // [3][2O][CC]
+    constexpr int HSTR = (2 * O * CC * 4 + 15) / 16 * 4;      // floats per histogram slot (16-byte multiple)
+    unsigned char* scratch = lds + al16(HP_ROWS_BYTES(O)) + HP_HIST_SLOTS * al16(HP_HIST_BYTES(O, CC));
+
+    const int im = uni(img_idx ? img_idx[s] : s);
+    const float* xr = x + (long long)s * 2 * L;
+    float* out_row = feat + (long long)s * ldf;
+    int* idx_row = idx_out ? idx_out + (long long)s * (1 + 2 * L) : nullptr;
+
+    // ---- group geometry (wave-uniform; adaptive_vlhog.hpp:123) ----------------------------------------------------------
+    const int h = lv.fixed_h > 0 ? lv.fixed_h : uni((int)round((double)lv.rel * ied_of(xr, L, eyes) / 2));
+    const bool empty = h <= 0;
+    if (empty && lane == 0) atomicOr(status, SDM_DEV_ERR_EMPTY_PATCH);
+    const int sw = empty ? 1 : 2 * h;
+    const bool area2 = (sw == 2 * S);
+    const double scale = (h < SDM_SCALE_TAB) ? lv.scale_tab[h > 0 ? h : 0] : 1.0 / ((double)S / (double)sw);
+    const uint8_t* img = imgs.base + imgs.offset[im];
+    const int iw = imgs.w[im], ih = imgs.h[im], istride = imgs.stride[im];
+    const __amdgpu_buffer_rsrc_t img_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)img, 0, ih * istride, 0x00020000);
+
+    // ---- per-coordinate taps of cv::resize: lane d computes coordinate d once (shared by rows and columns, by all patches) ----
+    int tab_s, tab_w;                 // unclamped source index floor((d + 0.5) scale - 0.5), 11-bit weights c0 | c1 << 16
+    int row_src, row_beta;            // vertical taps of row d: source rows RELATIVE to the patch origin, clipped to the patch
+    {
+        const int d = lane < S ? lane : S - 1;
+        float f = (float)((d + 0.5) * scale - 0.5);
+        const int s0 = (int)floorf(f);
+        f -= (float)s0;
+        const int c0 = sat_short_f((1.f - f) * 2048.0f), c1 = sat_short_f(f * 2048.0f);
+        int sy0 = s0 < 0 ? 0 : (s0 > sw - 1 ? sw - 1 : s0);
+        int sy1 = s0 + 1 < 0 ? 0 : (s0 + 1 > sw - 1 ? sw - 1 : s0 + 1);
+        if (area2) { sy0 = 2 * d; sy1 = 2 * d + 1; }
+        row_src = sy0 | (sy1 << 16);
+        row_beta = area2 ? (1024 | (1024 << 16)) : ((c0 & 0xffff) | (c1 << 16));
+        tab_s = s0;
+        tab_w = (c0 & 0xffff) | (c1 << 16);
+    }
+
+    // ---- clear the column rows and the histogram slots --------------------------------------------------------------------
+    {
+        const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int i = lane; i < (int)((al16(HP_ROWS_BYTES(O)) + HP_HIST_SLOTS * al16(HP_HIST_BYTES(O, CC))) / 16); i += 64) ((f32x4*)lds)[i] = z4;
+    }
+    wave_sync();
+
+    unsigned spread_sel = HF_SPREAD_SEL;
+    asm volatile("" : "+v"(spread_sel));
+    const int li = lane & 15, lq = lane >> 4;
+
+    for (int t = 0; t < npass; ++t) {
+        const int pt = pass0 + t;
+        // ---- this lane's column in this pass -----------------------------------------------------------------------------
+        const unsigned desc = plan.lane_tab[pt * 64 + lane];
+        const int slot = (int)(desc & 0xffu), col = (int)((desc >> 8) & 0xffu);
+        const bool in_use = (desc >> 17) & 1u;
+        const int cs = __builtin_amdgcn_ds_bpermute(col * 4, tab_s);
+        const int cw = __builtin_amdgcn_ds_bpermute(col * 4, tab_w);
+        const int lm = lm0 + slot;                                   // (< L by construction of the plan, also for lanes not in use)
+        const int cx = __float2int_rn(xr[lm]), cy = __float2int_rn(xr[lm + L]);      // cvRound, adaptive_vlhog.hpp:132-133
+        const int x0 = cx - h, y0 = cy - h;
+        int pl; unsigned wpk;
+        {
+            // horizontal taps: clamped in the table (cv::resize); columns on the black canvas get weight 0
+            int sx = cs, a0 = (short)(cw & 0xffff), a1 = cw >> 16;
+            if (sx < 0) { sx = 0; a0 = 2048; a1 = 0; }
+            if (sx >= sw - 1) { sx = sw - 1; a0 = 2048; a1 = 0; }
+            if (area2) { sx = 2 * col; a0 = 1024; a1 = 1024; }
+            const int sx1 = (sx + 1 < sw) ? sx + 1 : sx;
+            int px0 = x0 + sx, px1 = x0 + sx1;
+            if (px0 < 0 || px0 >= iw || empty || !in_use) a0 = 0;
+            if (px1 < 0 || px1 >= iw || empty || !in_use) a1 = 0;
+            px0 = px0 < 0 ? 0 : (px0 > iw - 1 ? iw - 1 : px0);
+            px1 = px1 < 0 ? 0 : (px1 > iw - 1 ? iw - 1 : px1);
+            // two live taps are neighbours: ONE 16-bit load; a single live tap is paired with a zero-weight neighbour inside the row
+            if (a0 != 0 && a1 != 0) {
+                pl = px0; wpk = (unsigned)a0 | ((unsigned)a1 << 16);
+            } else {
+                const int p1 = a0 != 0 ? px0 : px1;
+                const unsigned w1 = (unsigned)(a0 != 0 ? a0 : a1);
+                if (p1 + 1 <= iw - 1 || p1 == 0) { pl = p1; wpk = w1; }
+                else { pl = p1 - 1; wpk = w1 << 16; }
+            }
+        }
+        const u16x2 wpk2 = __builtin_bit_cast(u16x2, wpk);
+        // rows above or below the image fall outside the buffer's num_records: the hardware range check returns 0 (black canvas)
+        const int vb = pl + y0 * istride;
+        // ---- fold weights of the pass (matrix-core B operand) and the histogram cell column this lane receives ------------------
+        f32x4 wq[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wq[i] = ((const f32x4*)(plan.wb + ((size_t)pt * 64 + lane) * 16))[i];
+        const int* pinfo = plan.pass_info + pt * 4;
+        const int sg = li < C ? 0 : (li < 2 * C ? 1 : (li < 3 * C ? 2 : 3));
+        const int seg_slot = sg == 0 ? pinfo[0] : (sg == 1 ? pinfo[1] : (sg == 2 ? pinfo[2] : -1));
+        const bool recv = seg_slot >= 0 && lq < (2 * O + 3) / 4;           // rows 4 lq + e < 2O exist
+        float* hrecv = hist + (seg_slot >= 0 ? seg_slot % HP_HIST_SLOTS : 0) * HSTR + (4 * lq) * CC + (li - sg * C);
+        const int done = pinfo[3];
+
+        // ---- row loop ----------------------------------------------------------------------------------------------------------
+        auto issue_row = [&](int y, unsigned short& q0, unsigned short& q1, int& bb) {
+            const int src = __builtin_amdgcn_readlane(row_src, y);
+            bb = __builtin_amdgcn_readlane(row_beta, y);
+            const int r0 = (src & 0xffff) * istride, r1 = (src >> 16) * istride;     // scalar
+            q0 = __builtin_amdgcn_raw_buffer_load_b16(img_rsrc, vb + r0, 0, 0);
+            q1 = __builtin_amdgcn_raw_buffer_load_b16(img_rsrc, vb + r1, 0, 0);
+        };
+        auto horizontal = [&](unsigned short q0, unsigned short q1, int& H0, int& H1) {
+            H0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, spread_bytes(q0, spread_sel)), wpk2, 0u, false);
+            H1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, spread_bytes(q1, spread_sel)), wpk2, 0u, false);
+        };
+        auto vertical = [&](int H0, int H1, int beta) -> float {
+            const unsigned b0 = (unsigned)(beta & 0xffff) << 12, b1 = (unsigned)(beta >> 16) << 12;      // scalar
+            const int out = (int)((mul_hi_u24(b0, (unsigned)H0 & ~15u) + mul_hi_u24(b1, (unsigned)H1 & ~15u) + 2u) >> 2);
+            return (float)out;
+        };
+        float rm2 = 0.0f, rm1 = 0.0f;
+        constexpr unsigned bin_stride = ST * 8;
+        unsigned char* const cbase0 = (unsigned char*)colrows + lane * 8;
+        unsigned col_off1 = bin_stride;
+        asm volatile("" : "+v"(col_off1));
+        unsigned char* const cbase1 = cbase0 + col_off1;
+        f32x2* pend_p = (f32x2*)cbase0;
+        f32x2 pend_v = {0.0f, 0.0f};
+        int prev_by = -1;
+        // fold band b (slot b & 1): hist[patch of n][bin][b][cell of n] += sum_x col[bin][x] W[x][n], clear the slot
+        auto fold_band = [&](const int b) __attribute__((always_inline)) {
+            const int sl = b & 1;
+            wave_sync();
+            f32x4 fa0 = {0.0f, 0.0f, 0.0f, 0.0f}, fa1 = fa0;
+            const float* ap = colrows + ((li < 2 * O ? li : 2 * O - 1) * ST + lq) * 2 + sl;
+#pragma unroll
+            for (int ks = 0; ks < 16; ks += 2) {
+                const float a0v = ap[8 * ks], a1v = ap[8 * ks + 8];
+                fa0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v, wq[ks >> 2][ks & 3], fa0, 0, 0, 0);
+                fa1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v, wq[(ks + 1) >> 2][(ks + 1) & 3], fa1, 0, 0, 0);
+            }
+            // every lane clears the slot of its own pixel column (the LDS unit executes this wave's accesses in order)
+            float* cz = (float*)cbase0 + sl;
+#pragma unroll
+            for (int k = 0; k < 2 * O; ++k) cz[k * ST * 2] = 0.0f;
+            if (recv) {
+                float* hf = hrecv + b * C;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * lq + e < 2 * O) hf[e * CC] += fa0[e] + fa1[e];
+            }
+            wave_sync();
+        };
+        unsigned short q0[2], q1[2];
+        int qbeta[2];
+        issue_row(0, q0[0], q1[0], qbeta[0]);
+        issue_row(1, q0[1], q1[1], qbeta[1]);
+        auto row_step = [&](const int j, const int y, const bool grad) __attribute__((always_inline)) {
+            int H0, H1;
+            horizontal(q0[j], q1[j], H0, H1);
+            const int cbeta = qbeta[j];
+            issue_row(y + 2, q0[j], q1[j], qbeta[j]);      // (past the last row: v_readlane wraps, a harmless extra load)
+            f32x2 qv = {0.0f, 0.0f};
+            if (grad) qv = *pend_p;
+            const float r0 = vertical(H0, H1, cbeta);
+            if (grad) {
+                const int yy = y - 1;                      // gradient of row y - 1 (hog.c:616-672)
+                const float gx = from_right(rm1) - from_left(rm1);
+                const float gy = r0 - rm2;
+                const float g2 = gx * gx + gy * gy;
+                const float gm = sqrt_int_up(g2);
+                bool b0, b1, b2;
+                bin_sector4_bits(gx, gy, lv, b0, b1, b2);
+                *pend_p = qv + pend_v;
+                const float* rt = lv.row_tab[yy];
+                const float ws0 = rt[0], ws1 = rt[1];
+                const int cby = __builtin_bit_cast(int, rt[2]);
+                if (cby != prev_by) {
+                    if (prev_by >= 0) fold_band(prev_by);
+                    prev_by = cby;
+                }
+                pend_p = (f32x2*)((b0 ? cbase1 : cbase0) + ((b1 ? 2u * bin_stride : 0u) + (b2 ? 4u * bin_stride : 0u)));
+                pend_v = (f32x2){ws0, ws1} * gm;
+            }
+            rm2 = rm1; rm1 = r0;
+        };
+        row_step(0, 0, false);
+        row_step(1, 1, false);
+        int yrow = 2;
+        for (; yrow + 1 < S; yrow += 2) {
+            row_step(0, yrow, true);
+            row_step(1, yrow + 1, true);
+        }
+        if (yrow < S) row_step(0, yrow, true);
+        *pend_p += pend_v;
+        if (prev_by >= 0) fold_band(prev_by);
+        if (prev_by + 1 <= C - 1) fold_band(prev_by + 1);
+        wave_sync();
+
+        // ---- patches whose last column was in this pass: normalise, store, free the histogram slot -----------------------------
+        const int dfirst = done & 0xff, dcount = done >> 8;
+        for (int j = 0; j < dcount; ++j) {
+            const int ps = dfirst + j, lmp = lm0 + ps;
+            float* hp = hist + (ps % HP_HIST_SLOTS) * HSTR;
+            hog_finish_direct<TO, TC>(hp, scratch, out_row + (long long)lmp * lv.P, lv, lane);
+            for (int i = lane; i < HSTR / 4; i += 64) ((f32x4*)hp)[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            if (idx_row && lane == 0) {
+                if (lmp == 0) idx_row[0] = h;
+                idx_row[1 + lmp] = __float2int_rn(xr[lmp]);
+                idx_row[1 + L + lmp] = __float2int_rn(xr[lmp + L]);
+            }
+            // bias, adaptive_vlhog.hpp:182-183 (the non-adaptive example transform has none)
+            if (lmp == L - 1 && lv.fixed_h == 0 && lane == 0) out_row[(long long)L * lv.P] = 1.0f;
+            wave_sync();
+        }
+    }
+}
+
 // count the (gx, gy) pairs for which the un-normalised arg-max disagrees with the reference arithmetic
 __global__ void verify_fast_bins_kernel(HogLevelDev lv, int* __restrict__ mismatches)
 {
@@ -1030,6 +1367,112 @@ __global__ void verify_fast_bins_kernel(HogLevelDev lv, int* __restrict__ mismat
 }
 
 }  // namespace
+
+
+// ---- lane-packed launch plan (host) ---------------------------------------------------------------------------------
+namespace {
+struct PlanLane { int slot, col, active, seg; };
+// greedy packing of `npatch` patches of S columns into passes of 64 lanes (see HogPlanDev)
+int plan_pack(int S, int npatch, std::vector<std::vector<PlanLane>>& passes)
+{
+    passes.clear();
+    std::vector<PlanLane> cur;
+    int segs = 0;
+    auto flush = [&]() { if (!cur.empty()) passes.push_back(cur); cur.clear(); segs = 0; };
+    for (int p = 0; p < npatch; ++p) {
+        int c = 0;
+        bool continued = false;
+        for (;;) {
+            const int free_l = 64 - (int)cur.size(), need = S - c;
+            if (segs == SDM_PLAN_MAX_SEG || free_l == 0) { flush(); continue; }
+            if (need <= free_l) {
+                for (int col = c; col < S; ++col)
+                    cur.push_back({p, col, (col >= 1 && col <= S - 2 && !(continued && col == c)) ? 1 : 0, segs});
+                ++segs;
+                break;
+            }
+            if (free_l >= 3) {
+                // cut: the last placed column is only the right neighbour of the one before it; the next pass starts one
+                // column earlier, which there is only the left neighbour
+                const int e = c + free_l - 1;
+                for (int col = c; col <= e; ++col)
+                    cur.push_back({p, col, (col >= 1 && col <= S - 2 && col != e && !(continued && col == c)) ? 1 : 0, segs});
+                c = e - 1;
+                continued = true;
+                flush();
+                continue;
+            }
+            flush();      // fewer than 3 free lanes: no column could contribute
+        }
+    }
+    flush();
+    return (int)passes.size();
+}
+}  // namespace
+
+bool sdm_hog_plan_build(const HogLevelDev& lv, int L, HogPlanHost& out)
+{
+    out = HogPlanHost();
+    if (!(lv.O == 4 && lv.C == 5 && lv.cell <= 12 && lv.S >= 4 && lv.S <= 64 && L >= 1)) return false;
+    const int S = lv.S;
+    std::vector<std::vector<PlanLane>> tmp;
+    // group size: fewest passes per sample; among equals at least two passes per wave (the per-group set-up is then shared),
+    // then the smaller group
+    int bestG = 1; long long bestCost = -1; bool bestMulti = false;
+    for (int G = 1; G <= 8 && G <= L; ++G) {
+        const int P = plan_pack(S, G, tmp);
+        const int nm = L / G, Gt = L - nm * G;
+        const long long cost = (long long)nm * P + (Gt ? plan_pack(S, Gt, tmp) : 0);
+        const bool multi = P >= 2;
+        if (bestCost < 0 || cost < bestCost || (cost == bestCost && multi && !bestMulti)) { bestG = G; bestCost = cost; bestMulti = multi; }
+    }
+    out.G = bestG; out.n_main = L / bestG; out.Gt = L - out.n_main * bestG;
+    std::vector<std::vector<PlanLane>> main_p, tail_p;
+    out.P = plan_pack(S, out.G, main_p);
+    out.Pt = out.Gt ? plan_pack(S, out.Gt, tail_p) : 0;
+    const int NP = out.P + out.Pt;
+    out.lane_tab.assign((size_t)NP * 64, 0u);
+    out.wb.assign((size_t)NP * 64 * 16, 0.0f);
+    out.pass_info.assign((size_t)NP * 4, -1);
+    for (int pt = 0; pt < NP; ++pt) {
+        const std::vector<PlanLane>& pl = pt < out.P ? main_p[pt] : tail_p[pt - out.P];
+        float W[64][16];
+        memset(W, 0, sizeof(W));
+        int dfirst = 0, dcount = 0;
+        for (int x = 0; x < 64; ++x) {
+            PlanLane a = x < (int)pl.size() ? pl[x] : PlanLane{pl.back().slot, 0, 0, 3};
+            const bool in_use = x < (int)pl.size();
+            out.lane_tab[(size_t)pt * 64 + x] = (unsigned)a.slot | ((unsigned)a.col << 8) | ((unsigned)a.active << 16) |
+                                               ((unsigned)(in_use ? 1 : 0) << 17) | ((unsigned)a.seg << 20);
+            if (!in_use) continue;
+            out.pass_info[(size_t)pt * 4 + a.seg] = a.slot;
+            if (a.col == S - 1) { if (dcount == 0) dfirst = a.slot; ++dcount; }
+            if (a.active) {
+                int b; memcpy(&b, &lv.row_tab[a.col][2], sizeof(int));      // cell index floor(hx), hog.c:697-704
+                const float w2 = lv.row_tab[a.col][3], w1 = (float)(1.0 - w2);
+                if (b >= 0) W[x][a.seg * lv.C + b] = w1;
+                if (b + 1 <= lv.C - 1) W[x][a.seg * lv.C + b + 1] = w2;
+            }
+        }
+        out.pass_info[(size_t)pt * 4 + 3] = dfirst | (dcount << 8);
+        for (int l = 0; l < 64; ++l)
+            for (int ks = 0; ks < 16; ++ks) out.wb[((size_t)pt * 64 + l) * 16 + ks] = W[4 * ks + (l >> 4)][l & 15];
+    }
+    return true;
+}
+
+void sdm_launch_hog_packed(const ImageSetDev& imgs, const int* img_idx, const float* x, int N, int L,
+                           const EyeIdxDev& eyes, const HogLevelDev& lv, const HogPlanDev& plan, float* feat, long long ldf,
+                           int* idx_out, int* status, hipStream_t stream)
+{
+    const int gpf = plan.n_main + (plan.Gt > 0 ? 1 : 0);
+    const long long total = (long long)N * gpf;
+    if (total <= 0) return;
+    const unsigned grid = (unsigned)((total + HP_WAVES - 1) / HP_WAVES);
+    const size_t lds = packed_lds_bytes(5, 4) * HP_WAVES;
+    hipLaunchKernelGGL((hog_packed_kernel<4, 5>), dim3(grid), dim3(HP_WAVES * 64), lds, stream, imgs, img_idx, x, N, L, eyes, lv, plan,
+                       feat, ldf, idx_out, status);
+}
 
 bool sdm_hog_fast_supported(const HogLevelDev& lv)
 {

@@ -78,6 +78,38 @@ void sdm_launch_hog_fast(const ImageSetDev& imgs, const int* img_idx, const floa
                          const EyeIdxDev& eyes, const HogLevelDev& lv, float* feat, long long ldf, int* idx_out,
                          int* status, int acc_mode, int fast_bins, hipStream_t stream);
 
+// ---- lane-packed launch plan of one level (sdm_hog_fast.hip::hog_packed_kernel) --------------------------------------
+// The L patches of a sample are split into groups of G consecutive landmarks (n_main groups, then one tail group of
+// Gt = L - n_main * G patches, 0 = none).  One wave walks a group in P (Pt) passes; in a pass every lane owns one pixel
+// column of one patch of the group, so a 50-column ROI no longer leaves 14 lanes idle: five of them share four passes.
+// A patch cut by a pass boundary repeats one column on either side of the cut (the gradient's left / right neighbour).
+//   lane_tab[pass][lane]  patch slot in the group | column << 8 | contributes << 16 | lane in use << 17 | segment << 20
+//   wb[pass][lane][16]    the fold weights W[x][n] (hog.c:697-704; n = segment * C + cell column) in the order the
+//                         matrix-core B operand wants them: entry ks of lane l is W[4 ks + (l >> 4)][l & 15]
+//   pass_info[pass][4]    patch slot of segment 0, 1, 2 (-1 = none), first completed patch slot | count << 8
+// Passes of the main groups come first (P of them), then the tail group's Pt.
+#define SDM_PLAN_MAX_SEG 3
+struct HogPlanDev {
+    int G, P, n_main, Gt, Pt;
+    const unsigned* lane_tab;
+    const float* wb;
+    const int* pass_info;
+};
+#ifdef __cplusplus
+#include <vector>
+struct HogPlanHost {
+    int G = 0, P = 0, n_main = 0, Gt = 0, Pt = 0;
+    std::vector<unsigned> lane_tab;
+    std::vector<float> wb;
+    std::vector<int> pass_info;
+};
+// false when the level has no packed instance (then sdm_launch_hog_fast runs it)
+bool sdm_hog_plan_build(const HogLevelDev& lv, int L, HogPlanHost& out);
+#endif
+void sdm_launch_hog_packed(const ImageSetDev& imgs, const int* img_idx, const float* x, int N, int L,
+                           const EyeIdxDev& eyes, const HogLevelDev& lv, const HogPlanDev& plan, float* feat, long long ldf,
+                           int* idx_out, int* status, hipStream_t stream);
+
 void sdm_launch_hog_fast_profile(const ImageSetDev& imgs, const int* img_idx, const float* x, int N, int L,
                                  const EyeIdxDev& eyes, const HogLevelDev& lv, float* feat, long long ldf,
                                  int* status, unsigned long long* prof_dev, hipStream_t stream);

@@ -316,11 +316,32 @@ class Context:
         names = ["setup", "clear", "rows", "barrier", "normalise", "store"]
         return {names[i]: out[i] / n for i in range(6)}, n
 
+    def set_hog_packing(self, on: bool):
+        """Lane packing of the HOG launch (include/sdm.h: sdm_debug_set_hog_packing); on by default."""
+        check(self._lib.sdm_debug_set_hog_packing(self._h, int(on)))
+
     def debug_gradient_table(self, level: int):
         g = np.empty((511, 511), np.float32)
         b = np.empty((511, 511), np.int32)
         check(self._lib.sdm_debug_gradient_table(self._h, level, _fp(g), _ip(b)))
         return g, b
+
+
+def hog_plan(num_cells: int, cell_size: int, num_bins: int, num_landmarks: int, max_passes: int = 64):
+    """The lane-packing plan of a level geometry (host only; csrc/sdm_kernels.h: HogPlanDev).  Returns None when the
+    geometry has no packed kernel instance, else a dict with G, P, n_main, Gt, Pt and the three tables."""
+    L = _lib.lib()
+    info = np.zeros(5, np.int32)
+    lane_tab = np.zeros((max_passes, 64), np.uint32)
+    wb = np.zeros((max_passes, 64, 16), np.float32)
+    pass_info = np.zeros((max_passes, 4), np.int32)
+    check(L.sdm_debug_hog_plan(num_cells, cell_size, num_bins, num_landmarks, _ip(info), lane_tab.ctypes.data,
+                               wb.ctypes.data, pass_info.ctypes.data, max_passes))
+    if info[0] == 0:
+        return None
+    n = int(info[1] + info[4])
+    return {"G": int(info[0]), "P": int(info[1]), "n_main": int(info[2]), "Gt": int(info[3]), "Pt": int(info[4]),
+            "lane_tab": lane_tab[:n], "wb": wb[:n], "pass_info": pass_info[:n]}
 
 
 # --------------------------------------------------------------------------------------------------
