@@ -1,0 +1,11 @@
+#!/bin/bash
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+O=gpurun_out/r2_run5; mkdir -p $O
+export SDM_HOG_MODES=2
+timeout 600 python -m pytest tests/test_gpu_packing.py tests/test_gpu_parity.py -x -q > $O/pytest.txt 2>&1
+tail -n 5 $O/pytest.txt
+for rep in 1 2; do
+timeout 200 python scripts/gpu_hogtime.py 2>&1 | grep "mode 2"
+for v in pka pkb pkd; do SDM_HIP_LIB=$PWD/exp/libsdm_$v.so timeout 200 python scripts/gpu_hogtime.py 2>&1 | grep "mode 2"; done
+done
+SDM_HOG_NO_PACK=1 timeout 200 python scripts/gpu_hogtime.py 2>&1 | grep "mode 2"

@@ -497,7 +497,7 @@ int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int*
         HIP_TRY(hipMemcpyAsync(pl.wb.p, hp.wb.data(), hp.wb.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(pl.pass_info.p, hp.pass_info.data(), hp.pass_info.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));      // (the host vectors go out of scope)
-        pl.dev.G = hp.G; pl.dev.P = hp.P; pl.dev.n_main = hp.n_main; pl.dev.Gt = hp.Gt; pl.dev.Pt = hp.Pt;
+        pl.dev.G = hp.G; pl.dev.P = hp.P; pl.dev.n_main = hp.n_main; pl.dev.Gt = hp.Gt; pl.dev.Pt = hp.Pt; pl.dev.hist_slots = hp.hist_slots;
         pl.dev.lane_tab = pl.lane_tab.p; pl.dev.wb = pl.wb.p; pl.dev.pass_info = pl.pass_info.p;
         pl.ok = true;
     }

@@ -42,6 +42,7 @@
 //    from HBM into one L2 instead of eight).
 #include "sdm_kernels.h"
 #include <string.h>
+#include <type_traits>
 #include <vector>
 
 #pragma clang fp contract(off)
@@ -64,6 +65,8 @@ typedef unsigned long long u64;
 typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
 
 __device__ inline double ied_of(const float* __restrict__ xr, int L, const EyeIdxDev& e)
 {
@@ -341,6 +344,14 @@ __device__ inline unsigned mul_hi_u24(unsigned a, unsigned b)
 {
     unsigned r;
     asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "s"(a), "v"(b));
+    return r;
+}
+
+// (the same with the weight in a vector register: the packed kernel reads it from its per-row table in LDS)
+__device__ inline unsigned mul_hi_u24_vv(unsigned a, unsigned b)
+{
+    unsigned r;
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
 
@@ -1018,14 +1029,33 @@ hog_fast_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float* 
 // Same integer decisions and the same f32 operations per accumulator as hog_patch_fast<ACC_COLUMNS>, except that the cells
 // of a cut patch are the sum of two partial folds.
 #define HP_WAVES 4
-#define HP_ST 70                    /* = fast_columns_stride(.., pair): 64 pixel columns + padding (2 * 70 = 12 mod 32 dwords) */
-#define HP_HIST_SLOTS 3
+#ifndef HP_ST
+#define HP_ST 66                    /* column-row stride: 64 pixel columns + 2 (2 * 66 = 4 mod 32 dwords: the sixteen bin rows of a fold read fall into 8 banks) */
+#endif
+#ifndef HP_MINW
+#define HP_MINW 6                   /* __launch_bounds__ minimum waves per SIMD: <= 80 registers, with 6.6 KB of LDS per wave six waves fit */
+#endif
+#ifndef HP_OVERLAY
+#define HP_OVERLAY 1                /* the finish scratch overlays the (all-zero between passes) column rows */
+#endif
+#ifndef HP_PKFMA
+#define HP_PKFMA 1                  /* column sums by fused multiply-add (one v_pk_fma_f32 instead of a multiply and an add per pixel) */
+#endif
+#ifndef HP_PREF_MULTI
+#define HP_PREF_MULTI 0             /* plan: among equally dense group sizes prefer one with at least two passes per wave (measured: the smaller group wins, 1.54 -> 1.50 ms) */
+#endif
+#ifndef HP_ABL
+#define HP_ABL 0                    /* experiments: 1 no folds, 2 no finish, 3 no column read-modify-write, 4 no image loads, 5 no gradient */
+#endif
 #define HP_ROWS_BYTES(O) ((size_t)2 * (O) * HP_ST * 8)
 #define HP_HIST_BYTES(O, CC) ((size_t)2 * (O) * (CC) * 4)
 __host__ __device__ inline size_t packed_scratch_bytes(int C) { return al16((size_t)C * C * 4) + al16((size_t)(C + 1) * (C + 1) * 8); }
-__host__ __device__ inline size_t packed_lds_bytes(int C, int O)
+// per wave: [ column rows | per-row table of the vertical taps, S + 2 entries of 16 bytes | hist_slots histograms ]
+// (the finish scratch overlays the column rows, which are all zero between two passes)
+__host__ __device__ inline size_t packed_rowtab_bytes(int S) { return (size_t)(S + 2) * 16; }
+__host__ __device__ inline size_t packed_lds_bytes(int C, int O, int S, int hist_slots)
 {
-    return al16(HP_ROWS_BYTES(O)) + HP_HIST_SLOTS * al16(HP_HIST_BYTES(O, C * C)) + packed_scratch_bytes(C);
+    return al16(HP_ROWS_BYTES(O)) + packed_rowtab_bytes(S) + hist_slots * al16(HP_HIST_BYTES(O, C * C)) + (HP_OVERLAY ? 0 : packed_scratch_bytes(C));
 }
 
 // hog_finish_lean with the descriptor written straight to the feature row (no staging copy: 2 KB less LDS per wave)
@@ -1098,8 +1128,31 @@ __device__ void hog_finish_direct(const float* hist, unsigned char* scratch, flo
     wave_sync();
 }
 
+// cv::resize's taps of destination coordinate d for a 2h x 2h -> S x S bilinear 8-bit resize (resize.cpp, restated in
+// SURVEY.md row a-2r): unclamped source index s0 = floor((d + 0.5) scale - 0.5), the 11-bit weights c0, c1 of s0 and s0 + 1,
+// and the vertical form (rows clipped to the patch, the fraction kept; the exact-2x reduction as weights 1024 on rows 2d, 2d+1).
+struct ResizeTaps { int s0, c0, c1, sy0, sy1, b0, b1; };
+__device__ inline ResizeTaps resize_taps(int d, double scale, int sw, bool area2)
+{
+    ResizeTaps t;
+    float f = (float)((d + 0.5) * scale - 0.5);
+    t.s0 = (int)floorf(f);
+    f -= (float)t.s0;
+    t.c0 = sat_short_f((1.f - f) * 2048.0f);
+    t.c1 = sat_short_f(f * 2048.0f);
+    t.sy0 = t.s0 < 0 ? 0 : (t.s0 > sw - 1 ? sw - 1 : t.s0);
+    t.sy1 = t.s0 + 1 < 0 ? 0 : (t.s0 + 1 > sw - 1 ? sw - 1 : t.s0 + 1);
+    t.b0 = t.c0; t.b1 = t.c1;
+    if (area2) { t.sy0 = 2 * d; t.sy1 = 2 * d + 1; t.b0 = 1024; t.b1 = 1024; }
+    return t;
+}
+__device__ inline double resize_scale(const HogLevelDev& lv, int h, int sw)
+{
+    return (h < SDM_SCALE_TAB) ? lv.scale_tab[h > 0 ? h : 0] : 1.0 / ((double)lv.S / (double)sw);
+}
+
 template <int TO, int TC>
-__global__ void __launch_bounds__(HP_WAVES * 64)
+__global__ void __launch_bounds__(HP_WAVES * 64, HP_MINW)
 hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float* __restrict__ x, int N, int L,
                   EyeIdxDev eyes, HogLevelDev lv, HogPlanDev plan, float* __restrict__ feat, long long ldf,
                   int* __restrict__ idx_out, int* __restrict__ status)
@@ -1125,11 +1178,14 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
     const int pass0 = main_group ? 0 : plan.P;
     const int S = lv.S;
 
-    unsigned char* lds = smem + (size_t)wave * packed_lds_bytes(C, O);
+    const int nslots = plan.hist_slots;                                               // 2, or 3 for ROIs under 22 columns
+    unsigned char* lds = smem + (size_t)wave * packed_lds_bytes(C, O, S, nslots);
     float* colrows = (float*)lds;                                                    // [2O][ST][2 band slots]
-    float* hist = (float*)(lds + al16(HP_ROWS_BYTES(O)));                            // [3][2O][CC]
+    i32x4* rowtab = (i32x4*)(lds + al16(HP_ROWS_BYTES(O)));                          // [S + 2] {row offset 0, row offset 1, weight 0 << 12, weight 1 << 12}
+    float* hist = (float*)(lds + al16(HP_ROWS_BYTES(O)) + packed_rowtab_bytes(S));   // [nslots][2O][CC]
     constexpr int HSTR = (2 * O * CC * 4 + 15) / 16 * 4;      // floats per histogram slot (16-byte multiple)
-    unsigned char* scratch = lds + al16(HP_ROWS_BYTES(O)) + HP_HIST_SLOTS * al16(HP_HIST_BYTES(O, CC));
+    unsigned char* scratch = HP_OVERLAY ? lds : (unsigned char*)(hist + nslots * HSTR);
+    auto hist_slot = [&](int patch_slot) { return nslots == 2 ? (patch_slot & 1) : patch_slot % 3; };
 
     const int im = uni(img_idx ? img_idx[s] : s);
     const float* xr = x + (long long)s * 2 * L;
@@ -1142,33 +1198,39 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
     if (empty && lane == 0) atomicOr(status, SDM_DEV_ERR_EMPTY_PATCH);
     const int sw = empty ? 1 : 2 * h;
     const bool area2 = (sw == 2 * S);
-    const double scale = (h < SDM_SCALE_TAB) ? lv.scale_tab[h > 0 ? h : 0] : 1.0 / ((double)S / (double)sw);
+    const double scale = resize_scale(lv, h, sw);
     const uint8_t* img = imgs.base + imgs.offset[im];
     const int iw = imgs.w[im], ih = imgs.h[im], istride = imgs.stride[im];
     const __amdgpu_buffer_rsrc_t img_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)img, 0, ih * istride, 0x00020000);
 
     // ---- per-coordinate taps of cv::resize: lane d computes coordinate d once (shared by rows and columns, by all patches) ----
     int tab_s, tab_w;                 // unclamped source index floor((d + 0.5) scale - 0.5), 11-bit weights c0 | c1 << 16
-    int row_src, row_beta;            // vertical taps of row d: source rows RELATIVE to the patch origin, clipped to the patch
+    i32x4 row_ent;                    // vertical taps of row d as the row loop wants them: byte offsets of the two source rows
+                                      // RELATIVE to the patch origin (rows clipped to the patch), the two weights << 12
     {
-        const int d = lane < S ? lane : S - 1;
-        float f = (float)((d + 0.5) * scale - 0.5);
-        const int s0 = (int)floorf(f);
-        f -= (float)s0;
-        const int c0 = sat_short_f((1.f - f) * 2048.0f), c1 = sat_short_f(f * 2048.0f);
-        int sy0 = s0 < 0 ? 0 : (s0 > sw - 1 ? sw - 1 : s0);
-        int sy1 = s0 + 1 < 0 ? 0 : (s0 + 1 > sw - 1 ? sw - 1 : s0 + 1);
-        if (area2) { sy0 = 2 * d; sy1 = 2 * d + 1; }
-        row_src = sy0 | (sy1 << 16);
-        row_beta = area2 ? (1024 | (1024 << 16)) : ((c0 & 0xffff) | (c1 << 16));
-        tab_s = s0;
-        tab_w = (c0 & 0xffff) | (c1 << 16);
+        const ResizeTaps tp = resize_taps(lane < S ? lane : S - 1, scale, sw, area2);
+        tab_s = tp.s0;
+        tab_w = (tp.c0 & 0xffff) | (tp.c1 << 16);
+        row_ent = (i32x4){tp.sy0 * istride, tp.sy1 * istride, tp.b0 << 12, tp.b1 << 12};
     }
+    // (Measured and dropped: the vertical taps as one scalar 16-byte load per row from a per-level table [h][row] in HBM
+    // instead of two v_readlane + eight scalar decode instructions -- 1.50 -> 1.58 ms: the scalar cache misses of 24 waves
+    // per CU, each streaming the 1 KB of its own half-width, delay every other scalar load of the CU.)
 
     // ---- clear the column rows and the histogram slots --------------------------------------------------------------------
     {
         const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (int i = lane; i < (int)((al16(HP_ROWS_BYTES(O)) + HP_HIST_SLOTS * al16(HP_HIST_BYTES(O, CC))) / 16); i += 64) ((f32x4*)lds)[i] = z4;
+        for (int i = lane; i < (int)((al16(HP_ROWS_BYTES(O)) + packed_rowtab_bytes(S)) / 16) + nslots * (HSTR / 4); i += 64) ((f32x4*)lds)[i] = z4;
+    }
+    wave_sync();
+    // the per-row table: every lane reads entry y with ONE broadcast LDS read per row (no v_readlane, no scalar decoding);
+    // entries S and S + 1 (the row loop issues its loads two rows ahead) repeat the last row
+    if (lane < S + 2) rowtab[lane] = row_ent;
+    if (S + 2 > 64 && lane < S + 2 - 64) {
+        i32x4 last;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) last[k] = __builtin_amdgcn_readlane(row_ent[k], 63);
+        rowtab[64 + lane] = last;
     }
     wave_sync();
 
@@ -1221,24 +1283,24 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
         const int sg = li < C ? 0 : (li < 2 * C ? 1 : (li < 3 * C ? 2 : 3));
         const int seg_slot = sg == 0 ? pinfo[0] : (sg == 1 ? pinfo[1] : (sg == 2 ? pinfo[2] : -1));
         const bool recv = seg_slot >= 0 && lq < (2 * O + 3) / 4;           // rows 4 lq + e < 2O exist
-        float* hrecv = hist + (seg_slot >= 0 ? seg_slot % HP_HIST_SLOTS : 0) * HSTR + (4 * lq) * CC + (li - sg * C);
+        float* hrecv = hist + (seg_slot >= 0 ? hist_slot(seg_slot) : 0) * HSTR + (4 * lq) * CC + (li - sg * C);
         const int done = pinfo[3];
 
         // ---- row loop ----------------------------------------------------------------------------------------------------------
-        auto issue_row = [&](int y, unsigned short& q0, unsigned short& q1, int& bb) {
-            const int src = __builtin_amdgcn_readlane(row_src, y);
-            bb = __builtin_amdgcn_readlane(row_beta, y);
-            const int r0 = (src & 0xffff) * istride, r1 = (src >> 16) * istride;     // scalar
-            q0 = __builtin_amdgcn_raw_buffer_load_b16(img_rsrc, vb + r0, 0, 0);
-            q1 = __builtin_amdgcn_raw_buffer_load_b16(img_rsrc, vb + r1, 0, 0);
+        // the image loads of row y: the two source rows' byte offsets come from the row table (one broadcast 8-byte LDS read)
+        auto issue_row = [&](int y, unsigned short& q0, unsigned short& q1) {
+            const i32x2 rr = *(const i32x2*)&rowtab[y];
+            if (HP_ABL == 4) { q0 = (unsigned short)(vb + rr.x); q1 = (unsigned short)(vb + rr.y); return; }
+            q0 = __builtin_amdgcn_raw_buffer_load_b16(img_rsrc, vb + rr.x, 0, 0);
+            q1 = __builtin_amdgcn_raw_buffer_load_b16(img_rsrc, vb + rr.y, 0, 0);
         };
         auto horizontal = [&](unsigned short q0, unsigned short q1, int& H0, int& H1) {
             H0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, spread_bytes(q0, spread_sel)), wpk2, 0u, false);
             H1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, spread_bytes(q1, spread_sel)), wpk2, 0u, false);
         };
-        auto vertical = [&](int H0, int H1, int beta) -> float {
-            const unsigned b0 = (unsigned)(beta & 0xffff) << 12, b1 = (unsigned)(beta >> 16) << 12;      // scalar
-            const int out = (int)((mul_hi_u24(b0, (unsigned)H0 & ~15u) + mul_hi_u24(b1, (unsigned)H1 & ~15u) + 2u) >> 2);
+        auto vertical = [&](int H0, int H1, int y) -> float {
+            const i32x2 bb = *((const i32x2*)&rowtab[y] + 1);      // the row's two weights << 12
+            const int out = (int)((mul_hi_u24_vv((unsigned)bb.x, (unsigned)H0 & ~15u) + mul_hi_u24_vv((unsigned)bb.y, (unsigned)H1 & ~15u) + 2u) >> 2);
             return (float)out;
         };
         float rm2 = 0.0f, rm1 = 0.0f;
@@ -1249,18 +1311,27 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
         unsigned char* const cbase1 = cbase0 + col_off1;
         f32x2* pend_p = (f32x2*)cbase0;
         f32x2 pend_v = {0.0f, 0.0f};
+        float pend_g = 0.0f;
         int prev_by = -1;
         // fold band b (slot b & 1): hist[patch of n][bin][b][cell of n] += sum_x col[bin][x] W[x][n], clear the slot
         auto fold_band = [&](const int b) __attribute__((always_inline)) {
+            if (HP_ABL == 1) return;
             const int sl = b & 1;
             wave_sync();
             f32x4 fa0 = {0.0f, 0.0f, 0.0f, 0.0f}, fa1 = fa0;
             const float* ap = colrows + ((li < 2 * O ? li : 2 * O - 1) * ST + lq) * 2 + sl;
+            // the operand reads run two k-step pairs ahead of the products (the scheduling barriers keep that order: with the
+            // reads serialised behind the products every fold cost eight LDS round trips)
+            float a0v[3], a1v[3];
 #pragma unroll
-            for (int ks = 0; ks < 16; ks += 2) {
-                const float a0v = ap[8 * ks], a1v = ap[8 * ks + 8];
-                fa0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v, wq[ks >> 2][ks & 3], fa0, 0, 0, 0);
-                fa1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v, wq[(ks + 1) >> 2][(ks + 1) & 3], fa1, 0, 0, 0);
+            for (int i = 0; i < 2; ++i) { a0v[i] = ap[16 * i]; a1v[i] = ap[16 * i + 8]; }
+#pragma unroll
+            for (int kp = 0; kp < 8; ++kp) {
+                if (kp + 2 < 8) { a0v[(kp + 2) % 3] = ap[16 * (kp + 2)]; a1v[(kp + 2) % 3] = ap[16 * (kp + 2) + 8]; }
+                __builtin_amdgcn_sched_barrier(0);
+                fa0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v[kp % 3], wq[(2 * kp) >> 2][(2 * kp) & 3], fa0, 0, 0, 0);
+                fa1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v[kp % 3], wq[(2 * kp + 1) >> 2][(2 * kp + 1) & 3], fa1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             // every lane clears the slot of its own pixel column (the LDS unit executes this wave's accesses in order)
             float* cz = (float*)cbase0 + sl;
@@ -1275,18 +1346,16 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
             wave_sync();
         };
         unsigned short q0[2], q1[2];
-        int qbeta[2];
-        issue_row(0, q0[0], q1[0], qbeta[0]);
-        issue_row(1, q0[1], q1[1], qbeta[1]);
+        issue_row(0, q0[0], q1[0]);
+        issue_row(1, q0[1], q1[1]);
         auto row_step = [&](const int j, const int y, const bool grad) __attribute__((always_inline)) {
             int H0, H1;
             horizontal(q0[j], q1[j], H0, H1);
-            const int cbeta = qbeta[j];
-            issue_row(y + 2, q0[j], q1[j], qbeta[j]);      // (past the last row: v_readlane wraps, a harmless extra load)
+            issue_row(y + 2, q0[j], q1[j]);      // (past the last row: a harmless extra load of the last row)
             f32x2 qv = {0.0f, 0.0f};
-            if (grad) qv = *pend_p;
-            const float r0 = vertical(H0, H1, cbeta);
-            if (grad) {
+            if (grad && HP_ABL != 3) qv = *pend_p;
+            const float r0 = vertical(H0, H1, y);
+            if (grad && HP_ABL != 5) {
                 const int yy = y - 1;                      // gradient of row y - 1 (hog.c:616-672)
                 const float gx = from_right(rm1) - from_left(rm1);
                 const float gy = r0 - rm2;
@@ -1294,7 +1363,9 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
                 const float gm = sqrt_int_up(g2);
                 bool b0, b1, b2;
                 bin_sector4_bits(gx, gy, lv, b0, b1, b2);
-                *pend_p = qv + pend_v;
+                if (HP_ABL == 3) { f32x2 dz = __builtin_elementwise_fma(pend_v, (f32x2){pend_g, pend_g}, qv); asm volatile("" :: "v"(dz), "v"(pend_p)); }
+                else if (HP_PKFMA) *pend_p = __builtin_elementwise_fma(pend_v, (f32x2){pend_g, pend_g}, qv);
+                else *pend_p = qv + pend_v;
                 const float* rt = lv.row_tab[yy];
                 const float ws0 = rt[0], ws1 = rt[1];
                 const int cby = __builtin_bit_cast(int, rt[2]);
@@ -1303,7 +1374,8 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
                     prev_by = cby;
                 }
                 pend_p = (f32x2*)((b0 ? cbase1 : cbase0) + ((b1 ? 2u * bin_stride : 0u) + (b2 ? 4u * bin_stride : 0u)));
-                pend_v = (f32x2){ws0, ws1} * gm;
+                if (HP_PKFMA) { pend_v = (f32x2){ws0, ws1}; pend_g = gm; }
+                else pend_v = (f32x2){ws0, ws1} * gm;
             }
             rm2 = rm1; rm1 = r0;
         };
@@ -1315,7 +1387,8 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
             row_step(1, yrow + 1, true);
         }
         if (yrow < S) row_step(0, yrow, true);
-        *pend_p += pend_v;
+        if (HP_PKFMA) *pend_p = __builtin_elementwise_fma(pend_v, (f32x2){pend_g, pend_g}, *pend_p);
+        else *pend_p += pend_v;
         if (prev_by >= 0) fold_band(prev_by);
         if (prev_by + 1 <= C - 1) fold_band(prev_by + 1);
         wave_sync();
@@ -1324,9 +1397,11 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
         const int dfirst = done & 0xff, dcount = done >> 8;
         for (int j = 0; j < dcount; ++j) {
             const int ps = dfirst + j, lmp = lm0 + ps;
-            float* hp = hist + (ps % HP_HIST_SLOTS) * HSTR;
-            hog_finish_direct<TO, TC>(hp, scratch, out_row + (long long)lmp * lv.P, lv, lane);
+            float* hp = hist + hist_slot(ps) * HSTR;
+            if (HP_ABL != 2) hog_finish_direct<TO, TC>(hp, scratch, out_row + (long long)lmp * lv.P, lv, lane);
             for (int i = lane; i < HSTR / 4; i += 64) ((f32x4*)hp)[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            if (HP_OVERLAY)      // the scratch sat on the column rows, which the next pass expects to be zero
+                for (int i = lane; i < (int)(packed_scratch_bytes(C) / 16); i += 64) ((f32x4*)scratch)[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
             if (idx_row && lane == 0) {
                 if (lmp == 0) idx_row[0] = h;
                 idx_row[1 + lmp] = __float2int_rn(xr[lmp]);
@@ -1423,7 +1498,7 @@ bool sdm_hog_plan_build(const HogLevelDev& lv, int L, HogPlanHost& out)
         const int P = plan_pack(S, G, tmp);
         const int nm = L / G, Gt = L - nm * G;
         const long long cost = (long long)nm * P + (Gt ? plan_pack(S, Gt, tmp) : 0);
-        const bool multi = P >= 2;
+        const bool multi = P >= 2 && HP_PREF_MULTI;
         if (bestCost < 0 || cost < bestCost || (cost == bestCost && multi && !bestMulti)) { bestG = G; bestCost = cost; bestMulti = multi; }
     }
     out.G = bestG; out.n_main = L / bestG; out.Gt = L - out.n_main * bestG;
@@ -1431,6 +1506,7 @@ bool sdm_hog_plan_build(const HogLevelDev& lv, int L, HogPlanHost& out)
     out.P = plan_pack(S, out.G, main_p);
     out.Pt = out.Gt ? plan_pack(S, out.Gt, tail_p) : 0;
     const int NP = out.P + out.Pt;
+    out.hist_slots = 2;
     out.lane_tab.assign((size_t)NP * 64, 0u);
     out.wb.assign((size_t)NP * 64 * 16, 0.0f);
     out.pass_info.assign((size_t)NP * 4, -1);
@@ -1455,6 +1531,9 @@ bool sdm_hog_plan_build(const HogLevelDev& lv, int L, HogPlanHost& out)
             }
         }
         out.pass_info[(size_t)pt * 4 + 3] = dfirst | (dcount << 8);
+        int nseg = 0;
+        for (int k = 0; k < 3; ++k) nseg += out.pass_info[(size_t)pt * 4 + k] >= 0 ? 1 : 0;
+        if (nseg > out.hist_slots) out.hist_slots = nseg;
         for (int l = 0; l < 64; ++l)
             for (int ks = 0; ks < 16; ++ks) out.wb[((size_t)pt * 64 + l) * 16 + ks] = W[4 * ks + (l >> 4)][l & 15];
     }
@@ -1469,7 +1548,7 @@ void sdm_launch_hog_packed(const ImageSetDev& imgs, const int* img_idx, const fl
     const long long total = (long long)N * gpf;
     if (total <= 0) return;
     const unsigned grid = (unsigned)((total + HP_WAVES - 1) / HP_WAVES);
-    const size_t lds = packed_lds_bytes(5, 4) * HP_WAVES;
+    const size_t lds = packed_lds_bytes(5, 4, lv.S, plan.hist_slots) * HP_WAVES;
     hipLaunchKernelGGL((hog_packed_kernel<4, 5>), dim3(grid), dim3(HP_WAVES * 64), lds, stream, imgs, img_idx, x, N, L, eyes, lv, plan,
                        feat, ldf, idx_out, status);
 }

@@ -91,6 +91,7 @@ void sdm_launch_hog_fast(const ImageSetDev& imgs, const int* img_idx, const floa
 #define SDM_PLAN_MAX_SEG 3
 struct HogPlanDev {
     int G, P, n_main, Gt, Pt;
+    int hist_slots;            // patches a pass can touch = histograms a wave keeps in LDS (2; 3 for ROIs under 22 columns)
     const unsigned* lane_tab;
     const float* wb;
     const int* pass_info;
@@ -98,7 +99,7 @@ struct HogPlanDev {
 #ifdef __cplusplus
 #include <vector>
 struct HogPlanHost {
-    int G = 0, P = 0, n_main = 0, Gt = 0, Pt = 0;
+    int G = 0, P = 0, n_main = 0, Gt = 0, Pt = 0, hist_slots = 2;
     std::vector<unsigned> lane_tab;
     std::vector<float> wb;
     std::vector<int> pass_info;

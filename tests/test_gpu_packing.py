@@ -122,3 +122,31 @@ def test_packed_is_deterministic_and_matches_fast_mode(gpu_ctx):
         f = gpu_ctx.hog_features(level, fetch=True)
         gpu_ctx.set_hog_mode(SDM_HOG_COLUMNS)
         assert np.abs(a - f).max() <= 2e-7
+
+
+def test_packed_giant_patches(gpu_ctx):
+    """patch_width_half > 1000 (an 80-fold reduction, far beyond the host's table of resize scales): same results as the
+    one-patch-per-wave launch and the oracle."""
+    rng = np.random.default_rng(11)
+    images = rng.integers(0, 256, (3, 300, 280), dtype=np.uint8)
+    L = 5
+    x0 = np.zeros((3, 2 * L), np.float32)
+    x0[:, :L] = rng.uniform(60, 220, (3, L))
+    x0[:, L:] = rng.uniform(60, 240, (3, L))
+    x0[:, 0], x0[:, 1] = 100.0, 180.0            # IED = 80 px
+    x0[:, L], x0[:, L + 1] = 150.0, 150.0
+    re, le = [0], [1]
+    hp = [HoGParam(1, 5, 6, 4, 27.0), HoGParam(1, 5, 10, 4, 30.5)]      # h = 1080, 1220
+    gpu_ctx.set_model_geometry(L, re, le, hp)
+    gpu_ctx.upload_images(images)
+    gpu_ctx.set_sample_image_index(None)
+    gpu_ctx.set_x(x0)
+    for level in range(2):
+        packed, pidx, plain, qidx = both_launches(gpu_ctx, level)
+        assert pidx[0, 0] >= 1024
+        ofeat, oidx = orc.hog_features_batch(images, None, x0, re, le,
+                                             orc.HoGParam(1, 5, hp[level].cell_size, 4, hp[level].relative_patch_size),
+                                             n_threads=4, want_idx=True)
+        assert np.array_equal(pidx, oidx) and np.array_equal(qidx, oidx)
+        assert np.abs(packed - ofeat).max() <= 1e-6
+        assert np.abs(packed - plain).max() <= 2e-7
