@@ -112,6 +112,13 @@ int sdm_get_hog_info(sdm_ctx* ctx, int level, int* fast_kernel, int* fast_bins);
  * generic HOG kernel instead of the fused one: same results, slower.) */
 int sdm_upload_images_u8(sdm_ctx* ctx, const uint8_t* const* images, const int* width, const int* height,
                          const int* stride_bytes, int n_images);
+/* The same for 3-channel images in cv::imread's BGR byte order (stride_bytes >= 3 * width): converted to gray ONCE per image
+ * on the device, gray = (B*1868 + G*9617 + R*4899 + 8192) >> 14 -- cv::cvtColor(COLOR_BGR2GRAY) of OpenCV 2.4 ... 3.x, which
+ * the reference applies to the whole image at every level for every sample (adaptive_vlhog.hpp:114-120).  gray_shift = 15
+ * selects the 15-bit weights (3735, 19235, 9798) of later OpenCV releases.  (OpenCV is not in the reference tree: parity
+ * unpinned for this step, like cv::resize.) */
+int sdm_upload_images_bgr_u8(sdm_ctx* ctx, const uint8_t* const* images, const int* width, const int* height,
+                             const int* stride_bytes, int n_images, int gray_shift);
 /* Device-resident stack of equally sized images (image i at base + i*height*stride_bytes); not copied. */
 int sdm_set_images_device(sdm_ctx* ctx, const uint8_t* dev_base, int n_images, int width, int height,
                           int stride_bytes);
@@ -169,6 +176,12 @@ int sdm_gram_rhs(sdm_ctx* ctx, int level);
 /* Sum {G, B} over data-parallel ranks through the installed callback (no-op when none is installed). */
 typedef int (*sdm_allreduce_fn)(void* dev_ptr, size_t count_f32, void* hip_stream, void* user);
 int sdm_set_allreduce(sdm_ctx* ctx, sdm_allreduce_fn fn, void* user, int world_size);
+/* The same exchange through RCCL, called by the library itself: ncclAllReduce(sum, float32, in place) on the handle's stream,
+ * so the collective is ordered behind the Gram kernels and before the solve without host synchronisation.  nccl_comm is the
+ * caller's ncclComm_t (one rank per process / GPU); nccl_allreduce_fn is the address of ncclAllReduce in the RCCL the caller
+ * links (recommended: exactly one RCCL per process), or NULL to let the library find the symbol in the process / load librccl.
+ * NULL comm uninstalls.  The reference has no collective (superviseddescent.hpp:170-218 is single-process). */
+int sdm_set_allreduce_rccl(sdm_ctx* ctx, void* nccl_comm, void* nccl_allreduce_fn, int world_size);
 int sdm_allreduce_gram_rhs(sdm_ctx* ctx);
 /* Regulariser::get_matrix (regressors.hpp:126-148) with n_train = the GLOBAL sample count, add to the
  * diagonal (regressors.hpp:215-221), factor and solve (regressors.hpp:224-225; Cholesky instead of
@@ -203,6 +216,8 @@ int sdm_debug_patch(sdm_ctx* ctx, int level, int sample, int landmark, uint8_t* 
  * [0] geometry/tables [1] histogram clear [2] row loop [3] barrier [4] normalisation [5] output stores, [7] waves. */
 int sdm_debug_hog_profile(sdm_ctx* ctx, int level, unsigned long long* out8);
 int sdm_debug_gradient_table(sdm_ctx* ctx, int level, float* g_511x511, int* bin_511x511);
+/* The first n images (all width x height) of the context-owned single-channel image set, back to the host. */
+int sdm_debug_download_images(sdm_ctx* ctx, uint8_t* out, int n, int width, int height);
 /* Lane packing of the HOG launch (default on; also SDM_HOG_NO_PACK=1 in the environment at sdm_create): in SDM_HOG_COLUMNS
  * mode a wave walks a GROUP of patches of one sample in passes of 64 pixel columns instead of one patch per wave (a 50-column
  * ROI then fills the wave).  Same integer decisions; a patch cut by a pass boundary sums its cells from two partial folds.

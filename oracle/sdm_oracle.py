@@ -141,6 +141,20 @@ def get_ied(x: np.ndarray, right_eye: Sequence[int], left_eye: Sequence[int]) ->
                                    le.size))
 
 
+def bgr2gray(bgr: np.ndarray, shift: int = 14) -> np.ndarray:
+    """cv::cvtColor(img, COLOR_BGR2GRAY) on CV_8UC3 as rcr::HogTransform applies it (include/rcr/adaptive_vlhog.hpp:114-120).
+    OpenCV is not in the reference tree (CMakeLists.txt:36, >= 2.4.3, unpinned): restated from its published fixed-point
+    implementation -- imgproc/color.cpp RGB2Gray<uchar>: coefficients B2Y = 1868, G2Y = 9617, R2Y = 4899 with yuv_shift = 14 and
+    CV_DESCALE(x, n) = (x + (1 << (n - 1))) >> n (OpenCV 2.4 ... 3.x); releases from 3.4.2 on use the 15-bit coefficients
+    3735, 19235, 9798.  PARITY UNPINNED for this step (no reference-produced vector exists)."""
+    a = np.asarray(bgr)
+    assert a.dtype == np.uint8 and a.ndim == 3 and a.shape[2] == 3
+    cb, cg, cr = (1868, 9617, 4899) if shift == 14 else (3735, 19235, 9798)
+    assert shift in (14, 15)
+    v = a[..., 0].astype(np.int64) * cb + a[..., 1].astype(np.int64) * cg + a[..., 2].astype(np.int64) * cr
+    return ((v + (1 << (shift - 1))) >> shift).astype(np.uint8)
+
+
 def cv_round(v: float) -> int:
     return int(lib().orc_cv_round(float(v)))
 

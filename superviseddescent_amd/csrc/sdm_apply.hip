@@ -361,6 +361,40 @@ void sdm_launch_subtract_templates(float* feat, long long ldf, const float* tmpl
     hipLaunchKernelGGL(subtract_templates_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, feat, ldf, tmpl, N, F);
 }
 
+// cv::cvtColor(COLOR_BGR2GRAY) on 8-bit pixels (adaptive_vlhog.hpp:114-120): OpenCV's fixed-point weights,
+// gray = (B * cb + G * cg + R * cr + (1 << (shift - 1))) >> shift with (cb, cg, cr) = (1868, 9617, 4899) for shift 14 (OpenCV
+// 2.4 ... 3.x, the reference's era) or (3735, 19235, 9798) for shift 15 (later releases).  Both image sets are dense, so pixel
+// p of the gray set is pixel p of the colour set: no per-image bookkeeping.  Four pixels per thread: 12 bytes in, one dword out.
+__global__ void bgr2gray_kernel(const uint8_t* __restrict__ bgr, uint8_t* __restrict__ gray, long long n_pixels, int cb, int cg, int cr, int shift)
+{
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long p0 = q * 4;
+    if (p0 >= n_pixels) return;
+    const int half = 1 << (shift - 1);
+    if (p0 + 4 <= n_pixels) {
+        const unsigned* src = (const unsigned*)(bgr + p0 * 3);      // (the staging buffer is 4-byte aligned, p0 * 3 is a multiple of 12)
+        const unsigned w0 = src[0], w1 = src[1], w2 = src[2];
+        const unsigned b[12] = {w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u, w0 >> 24, w1 & 255u, (w1 >> 8) & 255u,
+                                (w1 >> 16) & 255u, w1 >> 24, w2 & 255u, (w2 >> 8) & 255u, (w2 >> 16) & 255u, w2 >> 24};
+        unsigned out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            out |= (unsigned)((int)(b[3 * k] * cb + b[3 * k + 1] * cg + b[3 * k + 2] * cr + half) >> shift) << (8 * k);
+        *(unsigned*)(gray + p0) = out;
+    } else {
+        for (long long p = p0; p < n_pixels; ++p)
+            gray[p] = (uint8_t)((bgr[3 * p] * cb + bgr[3 * p + 1] * cg + bgr[3 * p + 2] * cr + half) >> shift);
+    }
+}
+
+void sdm_launch_bgr2gray(const uint8_t* bgr, uint8_t* gray, long long n_pixels, int shift, hipStream_t stream)
+{
+    if (n_pixels <= 0) return;
+    const long long quads = (n_pixels + 3) / 4;
+    const int cb = shift == 15 ? 3735 : 1868, cg = shift == 15 ? 19235 : 9617, cr = shift == 15 ? 9798 : 4899;
+    hipLaunchKernelGGL(bgr2gray_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, bgr, gray, n_pixels, cb, cg, cr, shift);
+}
+
 void sdm_launch_init_boxes(const float* mean, const int* boxes, const float* pert, int N, int L, float* x, hipStream_t stream)
 {
     const long long total = (long long)N * 2 * L;

@@ -5,6 +5,7 @@
 #include "../../include/sdm.h"
 #include "sdm_kernels.h"
 
+#include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -132,6 +133,9 @@ struct sdm_ctx {
     sdm_allreduce_fn allreduce = nullptr;
     void* allreduce_user = nullptr;
     int world_size = 1;
+    // native exchange: ncclAllReduce of the RCCL the process already uses (or librccl loaded on demand)
+    void* rccl_comm = nullptr;
+    int (*rccl_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
 
     // timing
     bool timing = false;
@@ -579,6 +583,60 @@ int sdm_upload_images_u8(sdm_ctx* c, const uint8_t* const* images, const int* w,
     return SDM_OK;
 }
 
+int sdm_upload_images_bgr_u8(sdm_ctx* c, const uint8_t* const* images, const int* w, const int* h, const int* stride, int n,
+                             int gray_shift)
+{
+    if (!c || !images || n <= 0) return fail(SDM_ERR_INVALID, "bad image list");
+    if (gray_shift != 14 && gray_shift != 15) return fail(SDM_ERR_INVALID, "gray_shift must be 14 (OpenCV 2.4 - 3.x) or 15");
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<long long> off(n);
+    long long total = 0;
+    for (int i = 0; i < n; ++i) {
+        if (w[i] <= 0 || h[i] <= 0 || stride[i] < 3 * w[i]) return fail(SDM_ERR_INVALID, "bad image size");
+        off[i] = total;
+        total += (long long)w[i] * h[i];
+    }
+    int rc;
+    ScopedBuf<uint8_t> staging;      // the colour pixels, dense; freed when the gray set is complete
+    if ((rc = staging.ensure((size_t)total * 3 + 16))) return rc;
+    if ((rc = c->img_owned.ensure((size_t)total + 16))) return rc;
+    if ((rc = c->img_off.ensure(n)) || (rc = c->img_w.ensure(n)) || (rc = c->img_h.ensure(n)) || (rc = c->img_stride.ensure(n)))
+        return rc;
+    bool contiguous = true;
+    for (int i = 0; i < n && contiguous; ++i)
+        contiguous = stride[i] == 3 * w[i] && images[i] == images[0] + 3 * off[i];
+    if (contiguous) {
+        HIP_TRY(hipMemcpyAsync(staging.p, images[0], (size_t)total * 3, hipMemcpyHostToDevice, c->stream));
+    } else {
+        for (int i = 0; i < n; ++i)
+            HIP_TRY(hipMemcpy2DAsync(staging.p + 3 * off[i], (size_t)3 * w[i], images[i], stride[i], (size_t)3 * w[i], h[i],
+                                     hipMemcpyHostToDevice, c->stream));
+    }
+    sdm_launch_bgr2gray(staging.p, c->img_owned.p, total, gray_shift, c->stream);
+    HIP_TRY(hipGetLastError());
+    std::vector<int> dense(w, w + n);
+    HIP_TRY(hipMemcpyAsync(c->img_off.p, off.data(), n * sizeof(long long), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->img_w.p, w, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->img_h.p, h, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->img_stride.p, dense.data(), n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    staging.release();
+    c->img_base = c->img_owned.p;
+    c->n_images = n;
+    c->narrow_images = false;
+    for (int i = 0; i < n; ++i) c->narrow_images = c->narrow_images || w[i] < 2 || h[i] > 65535;
+    return SDM_OK;
+}
+
+int sdm_debug_download_images(sdm_ctx* c, uint8_t* out, int n, int w, int h)
+{
+    if (!c || !out || n <= 0 || n > c->n_images || w <= 0 || h <= 0) return fail(SDM_ERR_INVALID, "bad arguments");
+    if (c->img_base != c->img_owned.p) return fail(SDM_ERR_INVALID, "the image set is not owned by the context");
+    HIP_TRY(hipMemcpyAsync(out, c->img_owned.p, (size_t)n * w * h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SDM_OK;
+}
+
 int sdm_set_images_device(sdm_ctx* c, const uint8_t* dev_base, int n, int w, int h, int stride)
 {
     if (!c || !dev_base || n <= 0 || w <= 0 || h <= 0 || stride < w) return fail(SDM_ERR_INVALID, "bad device image stack");
@@ -824,13 +882,35 @@ int sdm_set_allreduce(sdm_ctx* c, sdm_allreduce_fn fn, void* user, int world_siz
 {
     if (!c || world_size < 1) return fail(SDM_ERR_INVALID, "bad all-reduce registration");
     c->allreduce = fn; c->allreduce_user = user; c->world_size = world_size;
+    c->rccl_comm = nullptr; c->rccl_allreduce = nullptr;
+    return SDM_OK;
+}
+
+int sdm_set_allreduce_rccl(sdm_ctx* c, void* nccl_comm, void* nccl_allreduce_fn, int world_size)
+{
+    if (!c || world_size < 1) return fail(SDM_ERR_INVALID, "bad all-reduce registration");
+    if (!nccl_comm) { c->rccl_comm = nullptr; c->rccl_allreduce = nullptr; c->world_size = 1; return SDM_OK; }
+    typedef int (*fn_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    fn_t fn = (fn_t)nccl_allreduce_fn;
+    if (!fn) {
+        // the RCCL already mapped into the process (torch's, the application's) wins; otherwise ROCm's
+        fn = (fn_t)dlsym(RTLD_DEFAULT, "ncclAllReduce");
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (int i = 0; !fn && i < 3; ++i) {
+            void* hnd = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+            if (hnd) fn = (fn_t)dlsym(hnd, "ncclAllReduce");
+        }
+        if (!fn) return fail(SDM_ERR_COMM, "ncclAllReduce not found: pass its address, or make librccl.so loadable");
+    }
+    c->rccl_comm = nccl_comm; c->rccl_allreduce = fn; c->world_size = world_size;
+    c->allreduce = nullptr; c->allreduce_user = nullptr;
     return SDM_OK;
 }
 
 int sdm_allreduce_gram_rhs(sdm_ctx* c)
 {
     if (!c || c->g_level < 0) return fail(SDM_ERR_INVALID, "no Gram matrix to reduce");
-    if (!c->allreduce) return SDM_OK;
+    if (!c->allreduce && !c->rccl_comm) return SDM_OK;
     Timer t(c, SDM_T_ALLREDUCE);
     // only the tiles the solve reads travel: upper Gram tiles + RHS tile columns, packed back to back
     HIP_TRY(hipSetDevice(c->device));
@@ -840,7 +920,12 @@ int sdm_allreduce_gram_rhs(sdm_ctx* c)
     if (rc) return rc;
     sdm_launch_tiles_pack(c->G.p, c->g_ncols, F, c->rhs_tiles, c->gpack.p, 0, c->stream);
     HIP_TRY(hipGetLastError());
-    if (c->allreduce(c->gpack.p, count, (void*)c->stream, c->allreduce_user) != 0)
+    if (c->rccl_comm) {
+        // ncclAllReduce(sendbuff, recvbuff, count, ncclFloat32 = 7, ncclSum = 0, comm, stream): in place, on the engine's stream,
+        // i.e. ordered behind the pack kernel and before the unpack without any host synchronisation
+        const int rcn = c->rccl_allreduce(c->gpack.p, c->gpack.p, count, 7, 0, c->rccl_comm, c->stream);
+        if (rcn != 0) return fail(SDM_ERR_COMM, "ncclAllReduce failed with status " + std::to_string(rcn));
+    } else if (c->allreduce(c->gpack.p, count, (void*)c->stream, c->allreduce_user) != 0)
         return fail(SDM_ERR_COMM, "all-reduce callback reported failure");
     sdm_launch_tiles_pack(c->G.p, c->g_ncols, F, c->rhs_tiles, c->gpack.p, 1, c->stream);
     HIP_TRY(hipGetLastError());

@@ -136,6 +136,9 @@ void sdm_launch_pack_regressor(const float* Rsol, int F, int M, int Mp, float* R
 // feat[n][0:F] -= tmpl[n][0:F]  (known-template mode, superviseddescent.hpp:195-197)
 void sdm_launch_subtract_templates(float* feat, long long ldf, const float* tmpl, int N, int F, hipStream_t stream);
 
+// BGR (3 bytes per pixel, dense) -> gray (dense) with cv::cvtColor's fixed-point weights; shift = 14 | 15
+void sdm_launch_bgr2gray(const uint8_t* bgr, uint8_t* gray, long long n_pixels, int shift, hipStream_t stream);
+
 // ---- before / after the path ----------------------------------------------------
 // x[n] = align_mean(mean, perturb(box[n], pert[n]))   (model.hpp:64-76, rcr-train.cpp:130-146); pert may be null
 void sdm_launch_init_boxes(const float* mean, const int* boxes, const float* pert, int N, int L, float* x, hipStream_t stream);

@@ -107,18 +107,32 @@ class Context:
     def feature_dim(self, level: int) -> int:
         return check(self._lib.sdm_feature_dim(self._h, level))
 
-    def upload_images(self, images):
-        """``images``: list of 2-D uint8 arrays (or one [n,H,W] stack)."""
+    def upload_images(self, images, gray_shift: int = 14):
+        """``images``: list of uint8 arrays (or one stack): H x W single-channel, or H x W x 3 BGR as ``cv::imread`` yields
+        them.  Colour images are converted to gray ONCE per image on the device with OpenCV's fixed-point weights
+        (``cvtColor(COLOR_BGR2GRAY)``, adaptive_vlhog.hpp:114-120 -- the reference converts per sample and per level)."""
         imgs = [np.ascontiguousarray(im, np.uint8) for im in images]
-        for im in imgs:
-            if im.ndim != 2:
-                raise ValueError("images must be single-channel (H x W) uint8")
         n = len(imgs)
+        colour = [im.ndim == 3 for im in imgs]
+        for im in imgs:
+            if not (im.ndim == 2 or (im.ndim == 3 and im.shape[2] == 3)):
+                raise ValueError("images must be H x W (gray) or H x W x 3 (BGR) uint8")
+        if any(colour) and not all(colour):
+            raise ValueError("gray and colour images cannot be mixed in one upload")
         ptrs = (ctypes.c_void_p * n)(*[im.ctypes.data for im in imgs])
         w = np.array([im.shape[1] for im in imgs], np.int32)
         h = np.array([im.shape[0] for im in imgs], np.int32)
         s = np.array([im.strides[0] for im in imgs], np.int32)
-        check(self._lib.sdm_upload_images_u8(self._h, ptrs, _ip(w), _ip(h), _ip(s), n))
+        if n and colour[0]:
+            check(self._lib.sdm_upload_images_bgr_u8(self._h, ptrs, _ip(w), _ip(h), _ip(s), n, int(gray_shift)))
+        else:
+            check(self._lib.sdm_upload_images_u8(self._h, ptrs, _ip(w), _ip(h), _ip(s), n))
+
+    def download_images(self, n: int, width: int, height: int) -> np.ndarray:
+        """The first ``n`` equally sized images of the context's single-channel image set (tests of the gray conversion)."""
+        out = np.empty((n, height, width), np.uint8)
+        check(self._lib.sdm_debug_download_images(self._h, out.ctypes.data, n, width, height))
+        return out
 
     def set_images_device(self, dev_ptr: int, n_images: int, width: int, height: int, stride: int):
         check(self._lib.sdm_set_images_device(self._h, ctypes.c_void_p(dev_ptr), n_images, width, height, stride))
@@ -391,8 +405,9 @@ class HogTransform:
 
     def __init__(self, images, hog_params: Sequence[HoGParam], model_landmarks: Sequence[str],
                  right_eye_ids: Sequence[str], left_eye_ids: Sequence[str],
-                 img_index: Optional[np.ndarray] = None):
+                 img_index: Optional[np.ndarray] = None, images_resident: bool = False):
         self.images = images
+        self.images_resident = bool(images_resident)   # opt-in: the pixels do not change between calls with THIS object
         self.hog_params = list(hog_params)
         self.model_landmarks = list(model_landmarks)
         self.norm = InterEyeDistanceNormalisation(model_landmarks, right_eye_ids, left_eye_ids)
@@ -416,28 +431,34 @@ class SupervisedDescentOptimiser:
         self.ctx = ctx if ctx is not None else Context(device, stream)
         self._bound = None
 
-    def _bind(self, projection: HogTransform):
+    def _bind(self, projection: HogTransform, n_rows: int):
         if not isinstance(projection, HogTransform):
             raise TypeError("the HIP engine accelerates HogTransform projections; generic projection "
                             "functors are served by the C++ header layer (superviseddescent.hpp)")
         if len(projection.hog_params) != len(self.regressors):
             raise ValueError("one HoGParam per regressor level expected")  # rcr-train.cpp:448
+        if projection.img_index is not None and len(projection.img_index) != n_rows:
+            raise ValueError("HogTransform.img_index must hold one image number per sample row")
         norm = self.normalisation or projection.norm
-        key = (id(projection.images), tuple(projection.model_landmarks))
+        # (a no-op on the device when the geometry has not changed: regressors and buffers stay resident)
         self.ctx.set_model_geometry(len(projection.model_landmarks), norm.right_eye, norm.left_eye,
                                     projection.hog_params)
-        if self._bound != key:
+        # The reference's HogTransform reads the CURRENT pixels of its images at every call, so the images are uploaded at
+        # every bind -- unless the caller declares them resident (HogTransform(..., images_resident=True)) and passes the
+        # very same projection object again, which this optimiser then holds a strong reference to.
+        if not (projection.images_resident and self._bound is projection):
             self.ctx.upload_images(projection.images)
-            self._bound = key
+        self._bound = projection
         self.ctx.set_sample_image_index(projection.img_index)
 
     def train(self, parameters, initialisations, templates, projection: HogTransform,
               on_training_epoch_callback: Optional[Callable[[np.ndarray], None]] = None,
               allreduce=None, world_size: int = 1, n_train_global: int = 0):
-        self._bind(projection)
+        x0 = np.asarray(initialisations, np.float32)
+        self._bind(projection, x0.shape[0])
         c = self.ctx
         c.set_templates(templates)                                           # superviseddescent.hpp:195-197
-        c.set_x(np.asarray(initialisations, np.float32))
+        c.set_x(x0)
         c.set_targets(np.asarray(parameters, np.float32))
         c.set_allreduce(allreduce, world_size)
         n_glob = n_train_global or c.N
@@ -461,11 +482,12 @@ class SupervisedDescentOptimiser:
 
     def test(self, initialisations, templates, projection: HogTransform,
              on_regressor_iteration_callback: Optional[Callable[[np.ndarray], None]] = None) -> np.ndarray:
-        self._bind(projection)
+        x0 = np.atleast_2d(np.asarray(initialisations, np.float32))
+        self._bind(projection, x0.shape[0])
         self._load_regressors()
         c = self.ctx
         c.set_templates(templates)                                           # superviseddescent.hpp:287-289
-        c.set_x(np.atleast_2d(np.asarray(initialisations, np.float32)))
+        c.set_x(x0)
         if on_regressor_iteration_callback is None:
             return c.detect_batch()                                           # :262-306
         for level in range(len(self.regressors)):
@@ -489,11 +511,25 @@ class detection_model:
         self.hog_params = list(hog_params)
         self.right_eye_ids, self.left_eye_ids = list(right_eye_ids), list(left_eye_ids)
 
-    def detect(self, image: np.ndarray, facebox_or_init) -> np.ndarray:
-        """model.hpp:132-157: one image, from a face box (x, y, w, h) or from an initial landmark row."""
+    def detect(self, image: np.ndarray, facebox=None, initialisation=None) -> np.ndarray:
+        """model.hpp:132-157, both overloads: ``detect(image, facebox)`` with a face box (x, y, w, h) -- four numbers, 1-D --
+        or ``detect(image, initialisation=row)`` with an initial landmark row (1 x 2L).  A 2-D second positional argument is
+        taken as an initialisation, so a 2-landmark model (2L = 4) is not mistaken for a box."""
         from .synth import align_mean
-        a = np.asarray(facebox_or_init)
-        init = align_mean(self.mean, tuple(int(v) for v in a)) if a.size == 4 else a.astype(np.float32).reshape(1, -1)
+        if (facebox is None) == (initialisation is None):
+            raise ValueError("give either a face box or an initialisation")
+        if facebox is not None:
+            a = np.asarray(facebox)
+            if a.ndim == 2:
+                initialisation, facebox = a, None
+            elif a.shape != (4,):
+                raise ValueError("a face box is (x, y, width, height)")
+        if facebox is not None:
+            init = align_mean(self.mean, tuple(int(v) for v in np.asarray(facebox)))
+        else:
+            init = np.asarray(initialisation, np.float32).reshape(1, -1)
+            if init.shape[1] != self.mean.size:
+                raise ValueError("the initialisation must hold 2L coordinates")
         hog = HogTransform([image], self.hog_params, self.landmark_ids, self.right_eye_ids, self.left_eye_ids)
         return self.optimised_model.predict(np.atleast_2d(init), None, hog)[0]
 

@@ -43,9 +43,9 @@ struct HoGParam {
 
 namespace detail {
 
-// single-channel u8 view of an image; BGR images are converted ONCE per image with OpenCV's fixed-point
-// weights (B*1868 + G*9617 + R*4899 + 8192) >> 14 (the reference converts per sample and per level,
-// adaptive_vlhog.hpp:114-120)
+// single-channel u8 view of an image on the HOST (used only for lists that mix gray and colour images; all-colour lists are
+// converted by the device kernel behind sdm_upload_images_bgr_u8): OpenCV's fixed-point weights
+// (B*1868 + G*9617 + R*4899 + 8192) >> 14 (the reference converts per sample and per level, adaptive_vlhog.hpp:114-120)
 inline cv::Mat to_gray(const cv::Mat& img)
 {
     if (img.channels() == 1) return img;
@@ -81,17 +81,24 @@ inline void configure(superviseddescent::hip::Handle& h, const std::vector<cv::M
                                  (int)lv.size(), lv.data()),
           "sdm_set_model_geometry");
     if (upload_images) {
+        // colour images (cv::imread's BGR) are converted to gray once per image ON THE DEVICE (sdm_upload_images_bgr_u8);
+        // only a list that mixes gray and colour images converts its colour members on the host first
+        bool all_colour = !images.empty(), any_colour = false;
+        for (const auto& im : images) { all_colour = all_colour && im.channels() == 3; any_colour = any_colour || im.channels() == 3; }
         std::vector<cv::Mat> gray;
         std::vector<const uint8_t*> ptrs;
         std::vector<int> w, hh, st;
         for (const auto& im : images) {
-            gray.push_back(to_gray(im));
+            gray.push_back((any_colour && !all_colour) ? to_gray(im) : im);
             ptrs.push_back(gray.back().ptr<uint8_t>(0));
             w.push_back(gray.back().cols);
             hh.push_back(gray.back().rows);
             st.push_back((int)gray.back().step());
         }
-        check(sdm_upload_images_u8(h.get(), ptrs.data(), w.data(), hh.data(), st.data(), (int)ptrs.size()), "sdm_upload_images_u8");
+        if (all_colour)
+            check(sdm_upload_images_bgr_u8(h.get(), ptrs.data(), w.data(), hh.data(), st.data(), (int)ptrs.size(), 14), "sdm_upload_images_bgr_u8");
+        else
+            check(sdm_upload_images_u8(h.get(), ptrs.data(), w.data(), hh.data(), st.data(), (int)ptrs.size()), "sdm_upload_images_u8");
     }
 }
 

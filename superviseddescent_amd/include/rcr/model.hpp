@@ -119,14 +119,19 @@ struct BatchedBackend<rcr::HogTransform, LinearRegressor<Solver>, rcr::InterEyeD
         set_templates(c, templates, x0.rows);
         hip::check(sdm_set_x(c, x0.ptr<float>(0), x0.rows), "sdm_set_x");
         hip::check(sdm_set_targets(c, xs.ptr<float>(0), xs.rows), "sdm_set_targets");
+        // data-parallel training (hip_backend.hpp: set_data_parallel / set_data_parallel_rccl): this process holds a shard of
+        // the rows, {A^T A, A^T b} are summed over the ranks once per level and every rank solves the same system
+        hip::install_data_parallel(c);
+        const long long n_global = hip::data_parallel().n_train_global > 0 ? hip::data_parallel().n_train_global : x0.rows;
         for (size_t level = 0; level < regressors.size(); ++level) {
             const Regulariser& r = regressors[level].get_regulariser();
             hip::check(sdm_hog_features(c, (int)level, nullptr), "sdm_hog_features");
             hip::check(sdm_gram_rhs(c, (int)level), "sdm_gram_rhs");
+            hip::check(sdm_allreduce_gram_rhs(c), "sdm_allreduce_gram_rhs");      // (a no-op when nothing is installed)
             const int F = sdm_feature_dim(c, (int)level);
             cv::Mat R(F, x0.cols, CV_32FC1);
             hip::check(sdm_solve(c, (int)level, r.type() == Regulariser::RegularisationType::MatrixNorm ? SDM_REG_MATRIX_NORM : SDM_REG_MANUAL,
-                                 r.param(), r.regularises_last_row() ? 1 : 0, x0.rows, R.ptr<float>(0), nullptr),
+                                 r.param(), r.regularises_last_row() ? 1 : 0, n_global, R.ptr<float>(0), nullptr),
                        "sdm_solve");
             regressors[level].x = R;
             hip::check(sdm_apply(c, (int)level), "sdm_apply");

@@ -38,6 +38,45 @@ private:
     sdm_ctx* ctx_;
 };
 
+// Data-parallel training of the batched backend (one process per GPU, every process holds a shard of the rows): the
+// per-level exchange of {A^T A, A^T b} is installed here, per thread, before SupervisedDescentOptimiser::train is called
+// -- either a callback (any transport) or an RCCL communicator the library calls itself.  n_train_global = the row count
+// over all ranks (the N of Regulariser's MatrixNorm, regressors.hpp:133-136).  The reference is single-process; with the
+// default (nothing installed) the backend behaves exactly like it.
+struct DataParallel {
+    sdm_allreduce_fn fn = nullptr;
+    void* user = nullptr;
+    void* rccl_comm = nullptr;          // ncclComm_t
+    void* rccl_allreduce = nullptr;     // &ncclAllReduce of the RCCL the application links, or nullptr: the library loads librccl
+    int world_size = 1;
+    long long n_train_global = 0;
+};
+inline DataParallel& data_parallel()
+{
+    static thread_local DataParallel dp;
+    return dp;
+}
+inline void set_data_parallel(sdm_allreduce_fn fn, void* user, int world_size, long long n_train_global)
+{
+    DataParallel& dp = data_parallel();
+    dp = DataParallel();
+    dp.fn = fn; dp.user = user; dp.world_size = world_size; dp.n_train_global = n_train_global;
+}
+inline void set_data_parallel_rccl(void* nccl_comm, void* nccl_allreduce_fn, int world_size, long long n_train_global)
+{
+    DataParallel& dp = data_parallel();
+    dp = DataParallel();
+    dp.rccl_comm = nccl_comm; dp.rccl_allreduce = nccl_allreduce_fn; dp.world_size = world_size; dp.n_train_global = n_train_global;
+}
+inline void clear_data_parallel() { data_parallel() = DataParallel(); }
+// applied by the batched backend to the context it trains on
+inline void install_data_parallel(sdm_ctx* c)
+{
+    const DataParallel& dp = data_parallel();
+    if (dp.rccl_comm) check(sdm_set_allreduce_rccl(c, dp.rccl_comm, dp.rccl_allreduce, dp.world_size), "sdm_set_allreduce_rccl");
+    else if (dp.fn) check(sdm_set_allreduce(c, dp.fn, dp.user, dp.world_size), "sdm_set_allreduce");
+}
+
 // one lazily created handle per thread for the stand-alone solver calls
 inline Handle& default_handle()
 {

@@ -38,14 +38,21 @@ class _DeviceSpan:
 def make_torch_allreduce(device_index: int) -> Callable[[int, int, int], int]:
     """Callback for ``Context.set_allreduce``: sums ``count`` floats at ``ptr`` over all ranks in place.
 
-    The engine context must run on torch's current stream of that device (``Context(device, stream=
-    torch.cuda.current_stream().cuda_stream)``) so that the collective is ordered after the Gram kernel."""
+    The engine hands over the HIP stream its tile-pack kernel was launched on (``stream``); the collective is issued
+    with that stream as torch's current one, so it is ordered after the pack and before the unpack / Cholesky on ANY
+    context stream -- the context's own non-blocking stream as well as one shared with torch."""
     import torch
     import torch.distributed as dist
 
-    def allreduce(ptr: int, count: int, _stream: int) -> int:
-        t = torch.as_tensor(_DeviceSpan(ptr, count), device=torch.device("cuda", device_index))
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    dev = torch.device("cuda", device_index)
+
+    def allreduce(ptr: int, count: int, stream: int) -> int:
+        t = torch.as_tensor(_DeviceSpan(ptr, count), device=dev)
+        if stream:
+            with torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=dev)):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        else:   # the legacy default stream
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return 0
 
     return allreduce
