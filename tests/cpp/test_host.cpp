@@ -8,6 +8,10 @@
 #include "superviseddescent/regressors.hpp"
 #include "superviseddescent/superviseddescent.hpp"
 
+#include <cstdlib>
+#include <cstdio>
+#include <fstream>
+#include <iterator>
 #include <sstream>
 
 using cv::Mat;
@@ -289,6 +293,45 @@ TEST(ModelFile, RoundTripAndByteLayout)
     threw = false;
     try { rcr::load_detection_model("/nonexistent/model.bin"); } catch (const std::runtime_error&) { threw = true; }
     EXPECT_TRUE(threw);
+}
+
+// ---- the same file, pinned: tests/golden/cereal_ref_model.bin was written by the REFERENCE's vendored cereal-1.1.1
+//      (oracle/ref_cereal_writer.cpp; member lists of model.hpp:181, superviseddescent.hpp:359, regressors.hpp:167,398,
+//      adaptive_vlhog.hpp:58, mat_cerealisation.hpp:42-58).  sdm_io must emit exactly those bytes and read them back. ----
+TEST(ModelFile, BytesEqualRealCereal)
+{
+    const char* dir = std::getenv("SDM_GOLDEN_DIR");
+    if (!dir) { std::printf("  (SDM_GOLDEN_DIR not set: skipped)\n"); return; }
+    std::ifstream gf(std::string(dir) + "/cereal_ref_model.bin", std::ios::binary);
+    EXPECT_TRUE((bool)gf);
+    const std::string golden((std::istreambuf_iterator<char>(gf)), std::istreambuf_iterator<char>());
+    using LR = LinearRegressor<VerbosePartialPivLUSolver>;
+    vector<LR> regs;
+    for (int l = 0; l < 2; ++l) {
+        LR r(l == 0 ? Regulariser(Regulariser::RegularisationType::MatrixNorm, 1.5f, false)
+                    : Regulariser(Regulariser::RegularisationType::Manual, 0.125f, true));
+        r.x = Mat(3, 4, CV_32FC1);
+        for (int i = 0; i < 12; ++i) r.x.at<float>(i / 4, i % 4) = 0.25f * i + l;
+        regs.push_back(r);
+    }
+    vector<std::string> ids{"37", "40", "9"}, re{"37"}, le{"40"};
+    rcr::detection_model::model_type opt(regs, rcr::InterEyeDistanceNormalisation(ids, re, le));
+    Mat mean = (cv::Mat_<float>(1, 6) << 0.1f, 0.2f, 0.3f, 0.4f, 0.5f, 0.6f);
+    vector<rcr::HoGParam> hp{{VlHogVariantUoctti, 5, 11, 4, 1.0f}, {VlHogVariantDalalTriggs, 3, 10, 9, 0.7f}};
+    rcr::detection_model m(opt, mean, ids, hp, re, le);
+    std::stringstream ss;
+    { sdm_io::BinaryOutputArchive out(ss); out(m); }
+    EXPECT_EQ(ss.str().size(), golden.size());
+    EXPECT_TRUE(ss.str() == golden);
+    // and the reference-written file loads
+    std::stringstream in_s(golden);
+    rcr::detection_model m2;
+    { sdm_io::BinaryInputArchive in(in_s); in(m2); }
+    EXPECT_EQ(m2.get_hog_params()[1].num_bins, 9);
+    EXPECT_TRUE(m2.get_hog_params()[1].vlhog_variant == VlHogVariantDalalTriggs);
+    EXPECT_EQ(m2.get_optimised_model().get_regressors()[1].get_regulariser().param(), 0.125f);
+    EXPECT_TRUE(m2.get_optimised_model().get_regressors()[1].get_regulariser().regularises_last_row());
+    EXPECT_NEAR(0.0, cv::norm(m2.get_optimised_model().get_regressors()[1].x, regs[1].x), 0.0);
 }
 
 int main() { return run_all_tests(); }
