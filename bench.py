@@ -7,14 +7,16 @@ of 4096 synthetic 256x256 faces per GPU.  Images, the initial landmark rows and 
 in HBM before the timed region.  With N GPUs every rank detects its own 4096 faces (independent shards,
 no collective on the data path -> weak scaling); `value` = faces of all ranks / max-over-ranks time.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 200 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-        --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3
+        --master-port 29500 bench.py --gpus 8 --steps 200 --warmup 5
 
 Rank 0 prints ONE JSON line (contract in the task description) including
   "roofline"     -- HOG kernel: algorithmic HBM bytes / HIP-event-timed kernel duration vs 8 TB/s
-  "cpu_baseline" -- the CPU oracle (the reference's algorithm restated, oracle/) timed on this box's cores
-                    on a bounded sample of the same workload, and the GPU-vs-oracle parity on that sample
+  "cpu_baseline" -- the CPU oracle (the reference's algorithm restated, oracle/; its HOG back-end is the reference's own
+                    hog.c when oracle/_ref is present) timed on this box's cores on a bounded sample of the same workload
+  "parity"       -- GPU vs oracle on that sample: landmarks (relative L2), faces whose integer patch decisions differ at any
+                    level, the largest per-face error, and the same in SDM_HOG_EXACT_ORDER mode
 """
 from __future__ import annotations
 
@@ -36,8 +38,8 @@ MFMA_F32_PEAK_TF = 157.3   # f32-input MFMA dense peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4096, help="faces per GPU")
     ap.add_argument("--train-rows", type=int, default=100000,
                     help="training rows = faces of the train-metric leg (images x 10 initialisations), sharded over the GPUs")
@@ -191,21 +193,25 @@ def main():
     achieved_gbs = bytes_per_launch / (hog_avg_ms * 1e-3) / 1e9 if hog_avg_ms > 0 else 0.0
     apply_tf = apply_flops / n_levels / (app_ms / max(app_n, 1) * 1e-3) / 1e12 if app_ms > 0 else 0.0
 
-    # HBM bytes per launch from the PMC passes (rocprofv3 --pmc cannot run inside this process): the committed
-    # measurement of this same command, valid for the launch geometry it was taken at
+    # HBM bytes and instruction counts per launch from the PMC passes (rocprofv3 --pmc cannot run inside this process): the
+    # committed measurement of this same command (scripts/profile_bench.sh), valid for the batch it was taken at
     traffic, traffic_src, valu_issue = None, None, None
+    hog_kernel = "hog_packed_kernel"
     try:
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")) as fh:
             tj = json.load(fh)
-        ent = tj["kernels"]["hog_fast_kernel"]
-        if int(str(ent["launch_geometry"]).split("+")[0]) == args.batch * L * 64:
+        ent = tj["kernels"][hog_kernel]
+        if int(tj.get("batch", 0)) == args.batch:
             traffic, traffic_src = float(ent["bytes_per_launch"]), "profiles/hbm_traffic.json (" + tj["source"] + ")"
-            # the bound that actually limits this kernel: VALU issue, one wave instruction per 4 cycles per SIMD
-            peak_ginst = 256 * 4 * 2.4 / 4.0
-            ach = float(ent["SQ_INSTS_VALU"]) / (hog_avg_ms * 1e-3) / 1e9
-            valu_issue = {"insts_per_launch": float(ent["SQ_INSTS_VALU"]), "achieved": ach, "peak": peak_ginst,
-                          "unit": "G wave-instructions/s", "frac": ach / peak_ginst}
-    except (OSError, KeyError, ValueError):
+            # what actually limits this kernel is instruction issue: SIMD-cycles per wave-instruction over the launch
+            simd_cycles = 256 * 4 * 2.4e9 * hog_avg_ms * 1e-3
+            valu_issue = {"valu_insts_per_launch": float(ent["SQ_INSTS_VALU"]), "salu_insts_per_launch": float(ent.get("SQ_INSTS_SALU", 0.0)),
+                          "simd_cycles_per_valu_inst": simd_cycles / float(ent["SQ_INSTS_VALU"]),
+                          "valu_insts_per_patch": float(ent["SQ_INSTS_VALU"]) / (args.batch * L),
+                          "note": "measured issue cost per wave-instruction on gfx950 (profiles/r02_ubench_valu_rates.txt): ~2.7 cycles "
+                                  "for 2-operand add/mul/logic, ~4.4 for VOP3 / compares / conversions / DPP / 24-bit multiplies, 8.3 for "
+                                  "v_sqrt_f32, 16.4 for f64 transcendentals; a scalar instruction beside each vector one costs ~2 more"}
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
         pass
 
     out = {
@@ -231,7 +237,7 @@ def main():
             "sharding": "faces sharded by rank, no collective on the detect path",
         },
         "roofline": {
-            "kernel": "hog_fast_kernel",
+            "kernel": hog_kernel,
             "bound": "hbm",
             "achieved": achieved_gbs,
             "peak": HBM_PEAK_GBS,
@@ -241,9 +247,8 @@ def main():
             "traffic_source": traffic_src,
             "valu_issue": valu_issue,
             "algorithmic_bytes_per_launch": bytes_per_launch,
-            "note": "the kernel is VALU-issue bound, not HBM bound: see valu_issue (SQ_INSTS_VALU of the committed PMC pass over "
-                    "this launch's duration; %s VALU instructions per patch); HBM traffic is below the algorithmic bytes"
-                    % (int(valu_issue["insts_per_launch"] / (args.batch * L)) if valu_issue else "n/a"),
+            "note": "the kernel is instruction-issue bound, not HBM bound (bit-exact integer resize + IEEE sqrt + reference binning "
+                    "cost ~37 vector instructions per pixel row): see valu_issue; HBM traffic is at or below the algorithmic bytes",
             "avg_launch_ms": hog_avg_ms,
             "launches": hog_n,
         },
@@ -273,7 +278,9 @@ def main():
     # ---- CPU baseline: the oracle on this box's host cores, bounded sample of the same batch -----------
     if not args.no_cpu:
         from oracle import sdm_oracle as orc
+        from superviseddescent_amd import _lib
         cores = os.cpu_count() or 1
+        ref_hog = orc.use_reference_hog(True)      # the reference's own include/rcr/hog.c (oracle/_ref), when present
         # bounded sample: ~5 ms of CPU work per face and level-set => about 20 core-seconds in total
         ns = min(args.cpu_sample or max(256, min(4096, 16 * cores)), args.batch)
         oparams = [orc.HoGParam(*p) for p in ibug.SHIPPED_HOG_PARAMS]
@@ -284,6 +291,7 @@ def main():
             oregs.append(r)
         osdo = orc.SupervisedDescentOptimiser(oregs, orc.InterEyeDistanceNormalisation(re, le))
         ohog = orc.HogTransform(images[:ns], oparams, re, le, None, n_threads=cores)
+        ohog.keep_idx = True
         t0 = time.perf_counter()
         ox = osdo.test(x0[:ns], None, ohog)
         cpu_dt = time.perf_counter() - t0
@@ -292,18 +300,53 @@ def main():
         t0 = time.perf_counter()
         osdo.test(x0[:n1], None, ohog1)
         cpu1_dt = time.perf_counter() - t0
-        rel = float(np.linalg.norm((x_final[:ns] - ox).astype(np.float64)) / np.linalg.norm(ox.astype(np.float64)))
         out["cpu_baseline"] = {
             "value": ns / cpu_dt,
             "unit": "faces/s",
             "cores": cores,
-            "kind": "port",
-            "sample": "first %d faces of the batch, full 4-level cascade, task-per-sample on %d threads "
-                      "(superviseddescent.hpp:173-177); single thread: %.1f faces/s on %d faces"
-                      % (ns, cores, n1 / cpu1_dt, n1),
+            "kind": "reference-hog" if ref_hog else "port",
+            "sample": "first %d faces of the batch, full 4-level cascade: the reference's HogTransform restated (crop, cv::resize 8U, "
+                      "reorder) around %s, task-per-sample on %d threads with a pool per level as in superviseddescent.hpp:173-177; "
+                      "single thread: %.1f faces/s on %d faces"
+                      % (ns, "the reference's own hog.c (oracle/_ref/libref_hog.so)" if ref_hog else "the restated hog.c", cores,
+                         n1 / cpu1_dt, n1),
             "single_thread_value": n1 / cpu1_dt,
         }
-        out["parity"] = {"rel_l2_landmarks_vs_oracle": rel, "faces_checked": ns, "tolerance": 1e-4}
+
+        # parity on the sample, free-running: landmarks, integer decisions per level, per-face errors -- in the default
+        # accumulation mode and in SDM_HOG_EXACT_ORDER (features bit-identical to the reference's raster-order sums)
+        def gpu_cascade(mode):
+            ctx.set_hog_mode(mode)
+            ctx.set_images_device(d_images.data_ptr(), ns, 256, 256, 256)
+            ctx.set_x(x0[:ns])
+            idxs = []
+            for l in range(n_levels):
+                ctx.hog_features(l)
+                idxs.append(ctx.patch_indices())
+                ctx.apply(l)
+            return ctx.get_x(), idxs
+
+        def compare(xg, idxs):
+            diverged = np.zeros(ns, bool)
+            for l in range(n_levels):
+                diverged |= (idxs[l] != ohog.idx_per_level[l]).any(axis=1)
+            d = (xg - ox).astype(np.float64)
+            per_face = np.linalg.norm(d, axis=1) / np.linalg.norm(ox.astype(np.float64), axis=1)
+            same = ~diverged
+            return {"rel_l2_landmarks_vs_oracle": float(np.linalg.norm(d) / np.linalg.norm(ox.astype(np.float64))),
+                    "faces_with_different_integer_decisions": int(diverged.sum()),
+                    "max_per_face_rel_error": float(per_face.max()),
+                    "max_per_face_rel_error_same_decisions": float(per_face[same].max()) if same.any() else None,
+                    "rel_l2_same_decisions": float(np.linalg.norm(d[same]) / np.linalg.norm(ox[same].astype(np.float64))) if same.any() else None}
+
+        par = compare(*gpu_cascade(_lib.SDM_HOG_COLUMNS))
+        par_exact = compare(*gpu_cascade(_lib.SDM_HOG_EXACT_ORDER))
+        ctx.set_hog_mode(_lib.SDM_HOG_COLUMNS)
+        out["parity"] = dict(par, faces_checked=ns, tolerance=1e-4, levels=n_levels,
+                             exact_order_mode=par_exact,
+                             note="free-running 4-level cascade; a face 'differs in integer decisions' when a cvRound'ed patch centre or the "
+                                  "patch half-width at any level differs from the oracle's (a landmark within float rounding of x.5): from "
+                                  "there on it is a different, equally valid trajectory")
     print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

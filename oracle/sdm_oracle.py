@@ -408,14 +408,20 @@ class HogTransform:
         self.right_eye, self.left_eye = list(right_eye), list(left_eye)
         self.img_index, self.n_threads = img_index, n_threads
         self._buf = None   # feature matrix reused across levels (avoids re-faulting 100+ MB per level)
+        self.keep_idx = False       # True: the integer patch decisions of every call are kept in idx_per_level[level]
+        self.idx_per_level = {}
 
     def __call__(self, x: np.ndarray, level: int) -> np.ndarray:
         x = np.atleast_2d(np.asarray(x, np.float32))
         F = feature_dim(x.shape[1] // 2, self.hog_params[level])
         if self._buf is None or self._buf.shape != (x.shape[0], F):
             self._buf = np.empty((x.shape[0], F), np.float32)
-        return hog_features_batch(self.images, self.img_index, x, self.right_eye, self.left_eye,
-                                  self.hog_params[level], self.n_threads, out=self._buf)
+        res = hog_features_batch(self.images, self.img_index, x, self.right_eye, self.left_eye,
+                                 self.hog_params[level], self.n_threads, want_idx=self.keep_idx, out=self._buf)
+        if self.keep_idx:
+            self.idx_per_level[level] = res[1]
+            return res[0]
+        return res
 
 
 def align_mean(mean: np.ndarray, box, scaling_x=1.0, scaling_y=1.0, translation_x=0.0,

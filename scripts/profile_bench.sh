@@ -7,7 +7,7 @@ REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/profile_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 10 --warmup 2 --no-cpu --train-rows 20000"
+CMD="python $REPO/bench.py --steps 20 --warmup 2 --no-cpu --train-rows 20000"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $CMD > $OUT/bench_under_trace.json 2> $OUT/trace_stderr.log
 cp $OUT/trace/t_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 i=0
@@ -22,7 +22,7 @@ out="$OUT"
 def short(n):
     m=re.search(r'(\w+_kernel)', n); return m.group(1) if m else n.split("(")[0][:40]
 with open(out+"/summary.txt","w") as fh:
-    fh.write("== rocprofv3 --kernel-trace --stats : python bench.py --steps 10 --warmup 2 --no-cpu --train-rows 20000 ==\n")
+    fh.write("== rocprofv3 --kernel-trace --stats : python bench.py --steps 20 --warmup 2 --no-cpu --train-rows 20000 ==\n")
     fh.write("%-28s %7s %13s %11s %7s\n" % ("kernel","calls","total_us","avg_us","%"))
     for r in list(csv.DictReader(open(out+"/kernel_stats.csv")))[:14]:
         fh.write("%-28s %7s %13.1f %11.2f %7.2f\n" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"])/1e3, float(r["AverageNs"])/1e3, float(r["Percentage"])))
@@ -31,7 +31,7 @@ with open(out+"/summary.txt","w") as fh:
     for f in glob.glob(out+"/trace/*kernel_trace.csv"):
         for r in csv.DictReader(open(f)):
             k=short(r["Kernel_Name"])
-            if k in ("hog_fast_kernel","apply_partial_kernel","apply_tiled_kernel","apply_reduce_kernel","syrk_tn_kernel"):
+            if k in ("hog_packed_kernel","hog_fast_kernel","apply_partial_kernel","apply_tiled_kernel","apply_reduce_kernel","syrk_tn_kernel","syrk_tn_glds_kernel"):
                 geo[(k,"x".join(r.get(c,"?") for c in ("Grid_Size_X","Grid_Size_Y","Grid_Size_Z")))].append((float(r["End_Timestamp"])-float(r["Start_Timestamp"]))/1e3)
     fh.write("\n== kernel trace by launch geometry (avg over dispatches; the detect steps of bench.py are the rows with the most calls) ==\n")
     fh.write("%-28s %12s %7s %11s\n" % ("kernel","grid","calls","avg_us"))
@@ -41,7 +41,7 @@ with open(out+"/summary.txt","w") as fh:
     for f in glob.glob(out+"/p*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             k=short(r["Kernel_Name"])
-            if k not in ("hog_fast_kernel","apply_partial_kernel","apply_tiled_kernel","syrk_tn_kernel"): continue
+            if k not in ("hog_packed_kernel","hog_fast_kernel","apply_partial_kernel","apply_tiled_kernel","syrk_tn_kernel","syrk_tn_glds_kernel"): continue
             k="%s grid=%s" % (k, r.get("Grid_Size","?"))
             rows[k][r["Counter_Name"]]+=float(r["Counter_Value"]); cnt[(k,r["Counter_Name"])]+=1
     # one kernel is launched with several problem sizes (training rows, detect batch): keep, per kernel, the launch
@@ -74,8 +74,8 @@ for k,v in rows.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         hbm[k.split(" grid=")[0]]={"bytes_per_launch": (2*v["FETCH_SIZE"]/cnt[(k,"FETCH_SIZE")]+v["WRITE_SIZE"]/cnt[(k,"WRITE_SIZE")])*1024.0,
                                    "launch_geometry": k.split(" grid=")[1], "dispatches": cnt[(k,"FETCH_SIZE")]}
-        for c in ("SQ_INSTS_VALU","SQ_INSTS_SALU","SQ_INSTS_LDS","SQ_WAVES"):
+        for c in ("SQ_INSTS_VALU","SQ_INSTS_SALU","SQ_INSTS_LDS","SQ_WAVES","SQ_ACTIVE_INST_VALU","SQ_LDS_BANK_CONFLICT","SQ_LDS_IDX_ACTIVE","SQ_VALU_MFMA_BUSY_CYCLES","SQ_BUSY_CYCLES","GRBM_GUI_ACTIVE"):
             if c in v: hbm[k.split(" grid=")[0]][c]=v[c]/cnt[(k,c)]
-json.dump({"source": "scripts/profile_bench.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of python bench.py --steps 10 --warmup 2 --no-cpu --train-rows 20000; FETCH_SIZE x2 (gfx950), KB units", "kernels": hbm}, open(out+"/hbm_traffic.json","w"), indent=1)
+json.dump({"batch": 4096, "source": "scripts/profile_bench.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of python bench.py --steps 20 --warmup 2 --no-cpu --train-rows 20000; FETCH_SIZE x2 (gfx950), KB units", "kernels": hbm}, open(out+"/hbm_traffic.json","w"), indent=1)
 print(open(out+"/summary.txt").read())
 PY
