@@ -1049,13 +1049,23 @@ hog_fast_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float* 
 #endif
 #define HP_ROWS_BYTES(O) ((size_t)2 * (O) * HP_ST * 8)
 #define HP_HIST_BYTES(O, CC) ((size_t)2 * (O) * (CC) * 4)
-__host__ __device__ inline size_t packed_scratch_bytes(int C) { return al16((size_t)C * C * 4) + al16((size_t)(C + 1) * (C + 1) * 8); }
+#ifndef HP_PREFETCH_TAB
+#define HP_PREFETCH_TAB 0           /* row-table offsets read one row step ahead of their use */
+#endif
+#ifndef HP_STAGE_TEX
+#define HP_STAGE_TEX 1              /* the clamped hc values of the descriptor pass are staged in LDS for the texture sums (instead of recomputed) */
+#endif
+// finish scratch: cell norms, block factors and (HP_STAGE_TEX) the clamped undirected values [4][O][CC] in double
+__host__ __device__ inline size_t packed_scratch_bytes(int C, int O = 4)
+{
+    return al16((size_t)C * C * 4) + al16((size_t)(C + 1) * (C + 1) * 8) + (HP_STAGE_TEX ? al16((size_t)4 * O * C * C * 8) : 0);
+}
 // per wave: [ column rows | per-row table of the vertical taps, S + 2 entries of 16 bytes | hist_slots histograms ]
 // (the finish scratch overlays the column rows, which are all zero between two passes)
 __host__ __device__ inline size_t packed_rowtab_bytes(int S) { return (size_t)(S + 2) * 16; }
 __host__ __device__ inline size_t packed_lds_bytes(int C, int O, int S, int hist_slots)
 {
-    return al16(HP_ROWS_BYTES(O)) + packed_rowtab_bytes(S) + hist_slots * al16(HP_HIST_BYTES(O, C * C)) + (HP_OVERLAY ? 0 : packed_scratch_bytes(C));
+    return al16(HP_ROWS_BYTES(O)) + packed_rowtab_bytes(S) + hist_slots * al16(HP_HIST_BYTES(O, C * C)) + (HP_OVERLAY ? 0 : packed_scratch_bytes(C, O));
 }
 
 // hog_finish_lean with the descriptor written straight to the feature row (no staging copy: 2 KB less LDS per wave)
@@ -1067,6 +1077,9 @@ __device__ void hog_finish_direct(const float* hist, unsigned char* scratch, flo
     constexpr int O = TO, C = TC, CC = C * C, CB = C + 1;
     float* nrm = (float*)scratch;
     FT* fac = (FT*)(scratch + al16((size_t)CC * 4));
+    FT* hcc = (FT*)(scratch + al16((size_t)CC * 4) + al16((size_t)CB * CB * 8));      // [4][O][CC] clamped hc_j (HP_STAGE_TEX)
+    static_assert(((TC * TC * 4 + 15) / 16 * 16) + (((TC + 1) * (TC + 1) * 8 + 15) / 16 * 16) + 4 * TO * TC * TC * 8 <= 2 * TO * HP_ST * 8 || !HP_OVERLAY,
+                  "the finish scratch overlays the column rows");
     for (int c = lane; c < CC; c += 64) {                       // cell norms (hog.c:875-890)
         float n = 0.0f;
         for (int k = 0; k < O; ++k) {
@@ -1102,6 +1115,9 @@ __device__ void hog_finish_direct(const float* hist, unsigned char* scratch, flo
             out_desc[ct + k * CC] = (float)((FT)0.5 * (ha1 + ha2 + ha3 + ha4));
             out_desc[ct + (k + O) * CC] = (float)((FT)0.5 * (hb1 + hb2 + hb3 + hb4));
             out_desc[ct + (k + 2 * O) * CC] = (float)((FT)0.5 * (hc1 + hc2 + hc3 + hc4));
+            if (HP_STAGE_TEX) {      // t = k * CC + c: consecutive lanes, consecutive doubles
+                hcc[t] = hc1; hcc[O * CC + t] = hc2; hcc[2 * O * CC + t] = hc3; hcc[3 * O * CC + t] = hc4;
+            }
         } else {
             out_desc[ct + k * CC] = (float)hc1;
             out_desc[ct + (k + O) * CC] = (float)hc2;
@@ -1109,17 +1125,23 @@ __device__ void hog_finish_direct(const float* hist, unsigned char* scratch, flo
             out_desc[ct + (k + 3 * O) * CC] = (float)hc4;
         }
     }
-    if (lv.variant == 1) {                                      // texture sums (hog.c:1020-1023, 1047-1052)
+    if (lv.variant == 1) {                                      // texture sums (hog.c:1020-1023, 1047-1052): t_j = sum over k, in order, of the clamped hc_j
         const float tex = 1.0f / sqrtf(18.0f);
+        if (HP_STAGE_TEX) wave_sync();
         for (int t = lane; t < 4 * CC; t += 64) {
             const int j = t / CC, c = t - j * CC;
             const int y = c / C, x = c - y * C, ct = x * C + y;
-            const FT fj = fac[x + (j & 1) + (y + (j >> 1)) * CB];
             FT acc = 0;
-            for (int k = 0; k < O; ++k) {
-                const FT ha = hist[c + k * CC], hb = hist[c + (k + O) * CC];
-                const FT haj = fj * ha, hbj = fj * hb;
-                acc += CL02(haj + hbj);
+            if (HP_STAGE_TEX) {
+#pragma unroll
+                for (int k = 0; k < O; ++k) acc += hcc[(j * O + k) * CC + c];
+            } else {
+                const FT fj = fac[x + (j & 1) + (y + (j >> 1)) * CB];
+                for (int k = 0; k < O; ++k) {
+                    const FT ha = hist[c + k * CC], hb = hist[c + (k + O) * CC];
+                    const FT haj = fj * ha, hbj = fj * hb;
+                    acc += CL02(haj + hbj);
+                }
             }
             out_desc[ct + (3 * O + j) * CC] = (float)(tex * acc);
         }
@@ -1288,8 +1310,10 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
 
         // ---- row loop ----------------------------------------------------------------------------------------------------------
         // the image loads of row y: the two source rows' byte offsets come from the row table (one broadcast 8-byte LDS read)
+        i32x2 rr_next = {0, 0};      // HP_PREFETCH_TAB: the source-row offsets of the next row to issue, read one step ahead
         auto issue_row = [&](int y, unsigned short& q0, unsigned short& q1) {
-            const i32x2 rr = *(const i32x2*)&rowtab[y];
+            const i32x2 rr = (HP_PREFETCH_TAB && y >= 2) ? rr_next : *(const i32x2*)&rowtab[y];
+            if (HP_PREFETCH_TAB && y >= 1) rr_next = *(const i32x2*)&rowtab[y + 1 < S + 2 ? y + 1 : S + 1];
             if (HP_ABL == 4) { q0 = (unsigned short)(vb + rr.x); q1 = (unsigned short)(vb + rr.y); return; }
             q0 = __builtin_amdgcn_raw_buffer_load_b16(img_rsrc, vb + rr.x, 0, 0);
             q1 = __builtin_amdgcn_raw_buffer_load_b16(img_rsrc, vb + rr.y, 0, 0);
@@ -1401,7 +1425,7 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
             if (HP_ABL != 2) hog_finish_direct<TO, TC>(hp, scratch, out_row + (long long)lmp * lv.P, lv, lane);
             for (int i = lane; i < HSTR / 4; i += 64) ((f32x4*)hp)[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
             if (HP_OVERLAY)      // the scratch sat on the column rows, which the next pass expects to be zero
-                for (int i = lane; i < (int)(packed_scratch_bytes(C) / 16); i += 64) ((f32x4*)scratch)[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+                for (int i = lane; i < (int)(packed_scratch_bytes(C, O) / 16); i += 64) ((f32x4*)scratch)[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
             if (idx_row && lane == 0) {
                 if (lmp == 0) idx_row[0] = h;
                 idx_row[1 + lmp] = __float2int_rn(xr[lmp]);
