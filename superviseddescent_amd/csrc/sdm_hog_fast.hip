@@ -1049,9 +1049,6 @@ hog_fast_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float* 
 #endif
 #define HP_ROWS_BYTES(O) ((size_t)2 * (O) * HP_ST * 8)
 #define HP_HIST_BYTES(O, CC) ((size_t)2 * (O) * (CC) * 4)
-#ifndef HP_PREFETCH_TAB
-#define HP_PREFETCH_TAB 0           /* row-table offsets read one row step ahead of their use */
-#endif
 #ifndef HP_STAGE_TEX
 #define HP_STAGE_TEX 1              /* the clamped hc values of the descriptor pass are staged in LDS for the texture sums (instead of recomputed) */
 #endif
@@ -1242,7 +1239,7 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
     // ---- clear the column rows and the histogram slots --------------------------------------------------------------------
     {
         const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (int i = lane; i < (int)((al16(HP_ROWS_BYTES(O)) + packed_rowtab_bytes(S)) / 16) + nslots * (HSTR / 4); i += 64) ((f32x4*)lds)[i] = z4;
+        for (int i = lane; i < (int)(al16(HP_ROWS_BYTES(O)) / 16); i += 64) ((f32x4*)lds)[i] = z4;      // (the histograms are stored before they are added to)
     }
     wave_sync();
     // the per-row table: every lane reads entry y with ONE broadcast LDS read per row (no v_readlane, no scalar decoding);
@@ -1307,13 +1304,15 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
         const bool recv = seg_slot >= 0 && lq < (2 * O + 3) / 4;           // rows 4 lq + e < 2O exist
         float* hrecv = hist + (seg_slot >= 0 ? hist_slot(seg_slot) : 0) * HSTR + (4 * lq) * CC + (li - sg * C);
         const int done = pinfo[3];
+        const int nkp = (done >> 16) & 0xff;          // k-step pairs (8 lanes each) that hold columns in this pass
+        // the first pass that touches a patch STORES its cells, a later one (the patch was cut) adds to them: the histogram
+        // slots need no clearing, and the uncut patches no read-modify-write
+        const bool first_seen = sg < 3 && ((done >> (24 + sg)) & 1);
 
         // ---- row loop ----------------------------------------------------------------------------------------------------------
         // the image loads of row y: the two source rows' byte offsets come from the row table (one broadcast 8-byte LDS read)
-        i32x2 rr_next = {0, 0};      // HP_PREFETCH_TAB: the source-row offsets of the next row to issue, read one step ahead
         auto issue_row = [&](int y, unsigned short& q0, unsigned short& q1) {
-            const i32x2 rr = (HP_PREFETCH_TAB && y >= 2) ? rr_next : *(const i32x2*)&rowtab[y];
-            if (HP_PREFETCH_TAB && y >= 1) rr_next = *(const i32x2*)&rowtab[y + 1 < S + 2 ? y + 1 : S + 1];
+            const i32x2 rr = *(const i32x2*)&rowtab[y];
             if (HP_ABL == 4) { q0 = (unsigned short)(vb + rr.x); q1 = (unsigned short)(vb + rr.y); return; }
             q0 = __builtin_amdgcn_raw_buffer_load_b16(img_rsrc, vb + rr.x, 0, 0);
             q1 = __builtin_amdgcn_raw_buffer_load_b16(img_rsrc, vb + rr.y, 0, 0);
@@ -1353,8 +1352,10 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
             for (int kp = 0; kp < 8; ++kp) {
                 if (kp + 2 < 8) { a0v[(kp + 2) % 3] = ap[16 * (kp + 2)]; a1v[(kp + 2) % 3] = ap[16 * (kp + 2) + 8]; }
                 __builtin_amdgcn_sched_barrier(0);
-                fa0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v[kp % 3], wq[(2 * kp) >> 2][(2 * kp) & 3], fa0, 0, 0, 0);
-                fa1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v[kp % 3], wq[(2 * kp + 1) >> 2][(2 * kp + 1) & 3], fa1, 0, 0, 0);
+                if (kp < 6 || kp < nkp) {      // (a 55-column pass leaves the last 8 lanes without a column: 14 products instead of 16)
+                    fa0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v[kp % 3], wq[(2 * kp) >> 2][(2 * kp) & 3], fa0, 0, 0, 0);
+                    fa1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v[kp % 3], wq[(2 * kp + 1) >> 2][(2 * kp + 1) & 3], fa1, 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             // every lane clears the slot of its own pixel column (the LDS unit executes this wave's accesses in order)
@@ -1363,9 +1364,15 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
             for (int k = 0; k < 2 * O; ++k) cz[k * ST * 2] = 0.0f;
             if (recv) {
                 float* hf = hrecv + b * C;
+                if (first_seen) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (4 * lq + e < 2 * O) hf[e * CC] += fa0[e] + fa1[e];
+                    for (int e = 0; e < 4; ++e)
+                        if (4 * lq + e < 2 * O) hf[e * CC] = fa0[e] + fa1[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (4 * lq + e < 2 * O) hf[e * CC] += fa0[e] + fa1[e];
+                }
             }
             wave_sync();
         };
@@ -1418,12 +1425,11 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
         wave_sync();
 
         // ---- patches whose last column was in this pass: normalise, store, free the histogram slot -----------------------------
-        const int dfirst = done & 0xff, dcount = done >> 8;
+        const int dfirst = done & 0xff, dcount = (done >> 8) & 0xff;
         for (int j = 0; j < dcount; ++j) {
             const int ps = dfirst + j, lmp = lm0 + ps;
             float* hp = hist + hist_slot(ps) * HSTR;
             if (HP_ABL != 2) hog_finish_direct<TO, TC>(hp, scratch, out_row + (long long)lmp * lv.P, lv, lane);
-            for (int i = lane; i < HSTR / 4; i += 64) ((f32x4*)hp)[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
             if (HP_OVERLAY)      // the scratch sat on the column rows, which the next pass expects to be zero
                 for (int i = lane; i < (int)(packed_scratch_bytes(C, O) / 16); i += 64) ((f32x4*)scratch)[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
             if (idx_row && lane == 0) {
@@ -1554,7 +1560,12 @@ bool sdm_hog_plan_build(const HogLevelDev& lv, int L, HogPlanHost& out)
                 if (b + 1 <= lv.C - 1) W[x][a.seg * lv.C + b + 1] = w2;
             }
         }
-        out.pass_info[(size_t)pt * 4 + 3] = dfirst | (dcount << 8);
+        // k-step pairs in use, and which segments see their patch for the first time (its column 0 is in this pass)
+        int first_bits = 0;
+        for (int x = 0; x < (int)pl.size(); ++x)
+            if (pl[x].col == 0) first_bits |= 1 << pl[x].seg;
+        const int nkp = ((int)pl.size() + 7) / 8;
+        out.pass_info[(size_t)pt * 4 + 3] = dfirst | (dcount << 8) | (nkp << 16) | (first_bits << 24);
         int nseg = 0;
         for (int k = 0; k < 3; ++k) nseg += out.pass_info[(size_t)pt * 4 + k] >= 0 ? 1 : 0;
         if (nseg > out.hist_slots) out.hist_slots = nseg;

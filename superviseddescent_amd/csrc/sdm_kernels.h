@@ -86,7 +86,8 @@ void sdm_launch_hog_fast(const ImageSetDev& imgs, const int* img_idx, const floa
 //   lane_tab[pass][lane]  patch slot in the group | column << 8 | contributes << 16 | lane in use << 17 | segment << 20
 //   wb[pass][lane][16]    the fold weights W[x][n] (hog.c:697-704; n = segment * C + cell column) in the order the
 //                         matrix-core B operand wants them: entry ks of lane l is W[4 ks + (l >> 4)][l & 15]
-//   pass_info[pass][4]    patch slot of segment 0, 1, 2 (-1 = none), first completed patch slot | count << 8
+//   pass_info[pass][4]    patch slot of segment 0, 1, 2 (-1 = none); first completed patch slot | count << 8 | k-step pairs in
+//                         use << 16 | (bit s: segment s starts its patch in this pass) << 24
 // Passes of the main groups come first (P of them), then the tail group's Pt.
 #define SDM_PLAN_MAX_SEG 3
 struct HogPlanDev {

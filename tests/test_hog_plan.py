@@ -60,7 +60,13 @@ def test_plan_covers_every_column_once(built, C, cell, O, L):
             assert slots == list(range(slots[0], slots[0] + len(slots)))
             for k in range(3):
                 assert info[k] == seg_slots.get(k, -1)
-            dfirst, dcount = int(info[3]) & 0xff, int(info[3]) >> 8
+            dfirst, dcount = int(info[3]) & 0xff, (int(info[3]) >> 8) & 0xff
+            nkp, first_bits = (int(info[3]) >> 16) & 0xff, (int(info[3]) >> 24) & 7
+            in_use = sum(a["in_use"] for a in lanes)
+            assert nkp == -(-in_use // 8) and all(a["in_use"] == (x < in_use) for x, a in enumerate(lanes))
+            for k in sorted(seg_slots):      # a segment stores (instead of adds) exactly when its patch's column 0 is in this pass
+                starts = any(a["in_use"] and a["seg"] == k and a["col"] == 0 for a in lanes)
+                assert bool((first_bits >> k) & 1) == starts
             done_here = [a["slot"] for a in lanes if a["in_use"] and a["col"] == S - 1]
             assert done_here == list(range(dfirst, dfirst + dcount))
             done_all += done_here
