@@ -85,6 +85,41 @@ int main(int argc, char** argv)
             if (cv::norm(a, b, cv::NORM_L2) != 0.0) throw std::runtime_error("zero templates changed the result");
         }
 
+        // ---- data-parallel hook of the header layer (hip_backend.hpp): a world of ONE rank whose exchange callback leaves the
+        //      packed Gram / RHS buffer as it is must reproduce the regressors bit for bit, and be called once per level ----
+        {
+            static int exchanges = 0;
+            static size_t floats = 0;
+            auto fn = [](void*, size_t count, void*, void*) -> int { ++exchanges; floats = count; return 0; };
+            hip::set_data_parallel(fn, nullptr, 1, N);
+            std::vector<LR> regs2;
+            for (int l = 0; l < n_levels; ++l)
+                regs2.emplace_back(LR(Regulariser(reg_type ? Regulariser::RegularisationType::MatrixNorm : Regulariser::RegularisationType::Manual,
+                                                  reg_param, reg_last != 0)));
+            SupervisedDescentOptimiser<LR, rcr::InterEyeDistanceNormalisation> m2(regs2, rcr::InterEyeDistanceNormalisation(ids, re, le));
+            m2.train(xstar, x0, Mat(), hog);
+            hip::clear_data_parallel();
+            if (exchanges != n_levels || floats == 0) throw std::runtime_error("data-parallel hook: exchange not called once per level");
+            for (int l = 0; l < n_levels; ++l)
+                if (cv::norm(m2.get_regressors()[l].x, model.get_regressors()[l].x, cv::NORM_L2) != 0.0)
+                    throw std::runtime_error("data-parallel hook changed the regressors");
+        }
+        // ---- colour input (adaptive_vlhog.hpp:114-120): BGR images whose three channels are equal convert to exactly that
+        //      gray image (the fixed-point weights sum to 1 << 14), so the cascade must not move ----
+        {
+            std::vector<std::vector<uint8_t>> store;
+            std::vector<Mat> colour;
+            for (int i = 0; i < n_img; ++i) {
+                store.emplace_back((size_t)H * W * 3);
+                for (size_t p2 = 0; p2 < (size_t)H * W; ++p2) store.back()[3 * p2] = store.back()[3 * p2 + 1] = store.back()[3 * p2 + 2] = images[i].ptr<uint8_t>(0)[p2];
+                colour.push_back(Mat(H, W, CV_8UC3, store.back().data()));
+            }
+            rcr::HogTransform hogc(colour, hog_params, ids, re, le);
+            hogc.sample_image_index = idx;
+            if (cv::norm(model.test(x0, Mat(), hogc), model.test(x0, Mat(), hog), cv::NORM_L2) != 0.0)
+                throw std::runtime_error("colour images: result differs from the gray images");
+        }
+
         // ---- save / load / detect (reference model.hpp:132-157, 192-219) ----
         auto meanv = read_all<float>(dir + "/mean.f32");
         Mat mean(1, 2 * L, CV_32FC1, meanv.data());
