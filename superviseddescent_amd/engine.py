@@ -92,6 +92,12 @@ class Context:
         check(self._lib.sdm_set_model_geometry(self._h, num_landmarks, _ip(re), re.size, _ip(le), le.size,
                                                len(hog_params), arr))
         self.L, self.n_levels = num_landmarks, len(hog_params)
+        # a changed geometry drops the device-side regressors (the same geometry again is a no-op in the library)
+        key = (num_landmarks, tuple(re.tolist()), tuple(le.tolist()),
+               tuple((p.vlhog_variant, p.num_cells, p.cell_size, p.num_bins, float(np.float32(p.relative_patch_size))) for p in hog_params))
+        if key != getattr(self, "_geometry_key", None):
+            self._geometry_key = key
+            self.geometry_epoch = getattr(self, "geometry_epoch", 0) + 1
 
     def set_hog_mode(self, mode: int):
         """``_lib.SDM_HOG_COLUMNS`` (default: per-pixel-column f32 sums folded into cells on the matrix cores),
@@ -376,12 +382,27 @@ class Regulariser:
 
 
 class LinearRegressor:
-    """regressors.hpp:318-400.  ``x`` is the learned F x M matrix (public, as in the reference)."""
+    """regressors.hpp:318-400.  ``x`` is the learned F x M matrix (public, as in the reference).  Assigning ``x`` bumps a
+    version number, which lets the optimiser keep an unchanged regressor resident on the device between calls (modify the
+    array IN PLACE and call ``touch()`` to have it uploaded again)."""
 
     def __init__(self, regulariser: Optional[Regulariser] = None):
-        self.x: Optional[np.ndarray] = None
+        self._x: Optional[np.ndarray] = None
+        self._version = 0
         self.regulariser = regulariser or Regulariser()
         self.last_lambda: Optional[float] = None
+
+    @property
+    def x(self) -> Optional[np.ndarray]:
+        return self._x
+
+    @x.setter
+    def x(self, value):
+        self._x = value
+        self._version += 1
+
+    def touch(self):
+        self._version += 1
 
 
 class InterEyeDistanceNormalisation:
@@ -430,6 +451,7 @@ class SupervisedDescentOptimiser:
         # the oracle, the product path always builds the HIP context here
         self.ctx = ctx if ctx is not None else Context(device, stream)
         self._bound = None
+        self._resident, self._resident_geom = {}, None      # level -> (id(regressor), version) of what the device holds
 
     def _bind(self, projection: HogTransform, n_rows: int):
         if not isinstance(projection, HogTransform):
@@ -461,6 +483,7 @@ class SupervisedDescentOptimiser:
         c.set_x(x0)
         c.set_targets(np.asarray(parameters, np.float32))
         c.set_allreduce(allreduce, world_size)
+        self._resident, self._resident_geom = {}, getattr(c, "geometry_epoch", None)
         n_glob = n_train_global or c.N
         for level, reg in enumerate(self.regressors):
             c.hog_features(level)                                            # superviseddescent.hpp:173-189
@@ -469,16 +492,26 @@ class SupervisedDescentOptimiser:
             r = reg.regulariser
             reg.x, reg.last_lambda = c.solve(level, r.regularisation_type, r.param, r.regularise_last_row,
                                              n_glob)                         # :207
+            self._resident[level] = (id(reg), reg._version)                  # (sdm_solve left it on the device)
             c.apply(level)                                                   # :209-216
             if on_training_epoch_callback is not None:
                 on_training_epoch_callback(c.get_x())                        # :217
         return c.get_x()
 
     def _load_regressors(self):
+        """Regressors the device already holds (same object, same version, same geometry since) are not uploaded again: a
+        per-frame ``detect()`` then costs the image upload and the kernels, not 4 x 1.5 MB of regressor traffic."""
+        geom = getattr(self.ctx, "geometry_epoch", None)
+        if self._resident_geom != geom:
+            self._resident = {}
+            self._resident_geom = geom
         for level, reg in enumerate(self.regressors):
             if reg.x is None:
                 raise RuntimeError("regressor level %d has not been learned" % level)
-            self.ctx.set_regressor(level, reg.x)
+            key = (id(reg), reg._version)
+            if self._resident.get(level) != key:
+                self.ctx.set_regressor(level, reg.x)
+                self._resident[level] = key
 
     def test(self, initialisations, templates, projection: HogTransform,
              on_regressor_iteration_callback: Optional[Callable[[np.ndarray], None]] = None) -> np.ndarray:
