@@ -183,6 +183,23 @@ int sdm_set_allreduce(sdm_ctx* ctx, sdm_allreduce_fn fn, void* user, int world_s
  * NULL comm uninstalls.  The reference has no collective (superviseddescent.hpp:170-218 is single-process). */
 int sdm_set_allreduce_rccl(sdm_ctx* ctx, void* nccl_comm, void* nccl_allreduce_fn, int world_size);
 int sdm_allreduce_gram_rhs(sdm_ctx* ctx);
+/* Sharded factorisation of the (already summed and identical) system inside sdm_solve.  The reference solves on one core
+ * (regressors.hpp:224-225); replicated on every rank the solve is the serial fraction of data-parallel training.  With sharding
+ * installed rank r performs the tile operations of the 128-column tile columns j with j % world_size == r: per 128-column step
+ * the owner of the step's column broadcasts <= 4 tiles (its factored diagonal tile + the column's tiles of the open group of 4
+ * panel rows), per group of 4 steps the ranks all-gather the group's panel rows; the back substitution stays replicated.
+ * The regressor is bit-identical to the replicated solve's for any world_size.  Collectives run on `hip_stream` (the
+ * handle's stream) and must be stream-ordered like ncclBroadcast / ncclAllGather; they return 0 on success.
+ *   bcast:     `count_f32` floats at dev_ptr, from rank `root` to all
+ *   allgather: every rank contributes `count_f32` floats at send_ptr; recv_ptr receives world_size * count_f32, rank-major
+ * Passing NULL for both callbacks (or a NULL communicator) restores the replicated solve. */
+typedef int (*sdm_bcast_fn)(void* dev_ptr, size_t count_f32, int root, void* hip_stream, void* user);
+typedef int (*sdm_allgather_fn)(const void* send_ptr, void* recv_ptr, size_t count_f32, void* hip_stream, void* user);
+int sdm_set_solve_sharding(sdm_ctx* ctx, int rank, int world_size, sdm_bcast_fn bcast, sdm_allgather_fn allgather, void* user);
+/* The same through RCCL, called by the library itself on the handle's stream; the function addresses may be NULL (looked up as
+ * ncclBroadcast / ncclAllGather in the process, then in librccl.so). */
+int sdm_set_solve_sharding_rccl(sdm_ctx* ctx, void* nccl_comm, int rank, int world_size, void* nccl_broadcast_fn,
+                                void* nccl_allgather_fn);
 /* Regulariser::get_matrix (regressors.hpp:126-148) with n_train = the GLOBAL sample count, add to the
  * diagonal (regressors.hpp:215-221), factor and solve (regressors.hpp:224-225; Cholesky instead of
  * PartialPivLU: the regularised Gram matrix is SPD).  Stores R as the level's regressor; R_host may be NULL. */

@@ -26,6 +26,7 @@ EXPORTED = [
     "sdm_set_sample_image_index", "sdm_set_x", "sdm_get_x", "sdm_set_x_device", "sdm_get_x_device",
     "sdm_hog_features", "sdm_get_patch_indices", "sdm_set_regressor", "sdm_get_regressor", "sdm_apply",
     "sdm_detect_batch", "sdm_set_targets", "sdm_gram_rhs", "sdm_set_allreduce", "sdm_set_allreduce_rccl", "sdm_allreduce_gram_rhs",
+    "sdm_set_solve_sharding", "sdm_set_solve_sharding_rccl",
     "sdm_set_templates", "sdm_init_from_boxes", "sdm_normalised_errors", "sdm_solve", "sdm_solve_normal_equations", "sdm_train_level", "sdm_gram_device_ptr", "sdm_x_device_ptr", "sdm_features_device_ptr",
     "sdm_enable_timing", "sdm_get_timing", "sdm_debug_patch", "sdm_debug_hog_profile", "sdm_debug_gradient_table",
     "sdm_debug_set_hog_packing", "sdm_debug_hog_plan", "sdm_upload_images_bgr_u8", "sdm_debug_download_images",
@@ -41,6 +42,9 @@ class SdmHogParam(ctypes.Structure):
 
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
                                 ctypes.c_void_p)
+# sdm_bcast_fn(dev_ptr, count_f32, root, hip_stream, user), sdm_allgather_fn(send_ptr, recv_ptr, count_f32, hip_stream, user)
+BCAST_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)
+ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p)
 
 _LIB = None
 
@@ -120,6 +124,8 @@ def lib() -> ctypes.CDLL:
             "sdm_set_allreduce": [c_void_p, ALLREDUCE_FN, c_void_p, c_int],
             "sdm_allreduce_gram_rhs": [c_void_p],
             "sdm_set_allreduce_rccl": [c_void_p, c_void_p, c_void_p, c_int],
+            "sdm_set_solve_sharding": [c_void_p, c_int, c_int, BCAST_FN, ALLGATHER_FN, c_void_p],
+            "sdm_set_solve_sharding_rccl": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
             "sdm_solve": [c_void_p, c_int, c_int, ctypes.c_float, c_int, ctypes.c_longlong, c_float_p, c_float_p],
             "sdm_train_level": [c_void_p, c_int, c_int, ctypes.c_float, c_int, ctypes.c_longlong],
             "sdm_solve_normal_equations": [c_void_p, c_float_p, c_int, c_int, c_float_p, c_int, c_int, ctypes.c_float, c_int,

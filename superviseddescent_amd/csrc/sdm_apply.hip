@@ -458,9 +458,9 @@ void sdm_launch_apply(const float* feat, long long ldf, int N, int F, const floa
         const dim3 grid((N + AT_BM - 1) / AT_BM, splits);
         static unsigned long long attr_seen = 0;
         if (sdm_first_use_on_device(attr_seen)) {
-            (void)hipFuncSetAttribute((const void*)apply_tiled_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)apply_tiled_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)apply_tiled_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            SDM_SET_ATTR((const void*)apply_tiled_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            SDM_SET_ATTR((const void*)apply_tiled_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            SDM_SET_ATTR((const void*)apply_tiled_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         }
         const size_t lds = (size_t)2 * (AT_BM + NT * 16) * AT_BK * sizeof(float);
         if (NT == 1) hipLaunchKernelGGL(apply_tiled_kernel<1>, grid, dim3(256), lds, stream, feat, ldf, N, kslabs, Rt, ldr, partial, splits);

@@ -136,6 +136,15 @@ struct sdm_ctx {
     // native exchange: ncclAllReduce of the RCCL the process already uses (or librccl loaded on demand)
     void* rccl_comm = nullptr;
     int (*rccl_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    // sharded factorisation (sdm_set_solve_sharding*): rank / world of the SOLVE, its two collectives, staging tiles
+    int shard_rank = 0, shard_world = 0;          // world 0 = replicated solve
+    sdm_bcast_fn shard_bcast = nullptr;
+    sdm_allgather_fn shard_allgather = nullptr;
+    void* shard_user = nullptr;
+    void* shard_comm = nullptr;                   // ncclComm_t of the native path
+    int (*rccl_bcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*rccl_allgather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    DevBuf<float> shard_stage;
 
     // timing
     bool timing = false;
@@ -359,7 +368,7 @@ void sdm_destroy(sdm_ctx* c)
     c->img_owned.release(); c->img_off.release(); c->img_w.release(); c->img_h.release();
     c->img_stride.release(); c->img_idx.release(); c->x[0].release(); c->x[1].release();
     c->xstar.release(); c->tmpl.release(); c->feat.release(); c->patch_idx.release(); c->status.release();
-    c->partial.release(); c->G.release(); c->gpack.release(); c->fro.release(); c->Rsol.release(); c->winv.release(); c->lambda_dev.release();
+    c->partial.release(); c->shard_stage.release(); c->G.release(); c->gpack.release(); c->fro.release(); c->Rsol.release(); c->winv.release(); c->lambda_dev.release();
     for (auto& r : c->Rt) r.release();
     for (auto& q : c->plans) { q.lane_tab.release(); q.wb.release(); q.pass_info.release(); }
     if (c->own_stream) e = hipStreamDestroy(c->stream);
@@ -878,6 +887,20 @@ int sdm_gram_rhs(sdm_ctx* c, int level)
     return SDM_OK;
 }
 
+namespace {
+void* find_rccl_symbol(const char* name)
+{
+    // the RCCL already mapped into the process (torch's, the application's) wins; otherwise ROCm's
+    void* fn = dlsym(RTLD_DEFAULT, name);
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (int i = 0; !fn && i < 3; ++i) {
+        void* hnd = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+        if (hnd) fn = dlsym(hnd, name);
+    }
+    return fn;
+}
+}  // namespace
+
 int sdm_set_allreduce(sdm_ctx* c, sdm_allreduce_fn fn, void* user, int world_size)
 {
     if (!c || world_size < 1) return fail(SDM_ERR_INVALID, "bad all-reduce registration");
@@ -892,18 +915,54 @@ int sdm_set_allreduce_rccl(sdm_ctx* c, void* nccl_comm, void* nccl_allreduce_fn,
     if (!nccl_comm) { c->rccl_comm = nullptr; c->rccl_allreduce = nullptr; c->world_size = 1; return SDM_OK; }
     typedef int (*fn_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
     fn_t fn = (fn_t)nccl_allreduce_fn;
-    if (!fn) {
-        // the RCCL already mapped into the process (torch's, the application's) wins; otherwise ROCm's
-        fn = (fn_t)dlsym(RTLD_DEFAULT, "ncclAllReduce");
-        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (int i = 0; !fn && i < 3; ++i) {
-            void* hnd = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
-            if (hnd) fn = (fn_t)dlsym(hnd, "ncclAllReduce");
-        }
-        if (!fn) return fail(SDM_ERR_COMM, "ncclAllReduce not found: pass its address, or make librccl.so loadable");
-    }
+    if (!fn) fn = (fn_t)find_rccl_symbol("ncclAllReduce");
+    if (!fn) return fail(SDM_ERR_COMM, "ncclAllReduce not found: pass its address, or make librccl.so loadable");
     c->rccl_comm = nccl_comm; c->rccl_allreduce = fn; c->world_size = world_size;
     c->allreduce = nullptr; c->allreduce_user = nullptr;
+    return SDM_OK;
+}
+
+namespace {
+int shard_bcast_thunk(void* self, float* buf, size_t count, int root, hipStream_t stream)
+{
+    sdm_ctx* c = (sdm_ctx*)self;
+    if (c->shard_comm)   // ncclBroadcast(sendbuff, recvbuff, count, ncclFloat32 = 7, root, comm, stream), in place
+        return c->rccl_bcast(buf, buf, count, 7, root, c->shard_comm, stream);
+    return c->shard_bcast(buf, count, root, (void*)stream, c->shard_user);
+}
+int shard_allgather_thunk(void* self, const float* send, float* recv, size_t count, hipStream_t stream)
+{
+    sdm_ctx* c = (sdm_ctx*)self;
+    if (c->shard_comm)   // ncclAllGather(sendbuff, recvbuff, sendcount, ncclFloat32 = 7, comm, stream)
+        return c->rccl_allgather(send, recv, count, 7, c->shard_comm, stream);
+    return c->shard_allgather(send, recv, count, (void*)stream, c->shard_user);
+}
+}  // namespace
+
+int sdm_set_solve_sharding(sdm_ctx* c, int rank, int world_size, sdm_bcast_fn bcast, sdm_allgather_fn allgather, void* user)
+{
+    if (!c) return fail(SDM_ERR_INVALID, "null handle");
+    c->shard_comm = nullptr; c->rccl_bcast = nullptr; c->rccl_allgather = nullptr;
+    if (!bcast && !allgather) { c->shard_world = 0; c->shard_bcast = nullptr; c->shard_allgather = nullptr; return SDM_OK; }
+    if (!bcast || !allgather || world_size < 1 || rank < 0 || rank >= world_size)
+        return fail(SDM_ERR_INVALID, "sdm_set_solve_sharding: both collectives and 0 <= rank < world_size are required");
+    c->shard_rank = rank; c->shard_world = world_size; c->shard_bcast = bcast; c->shard_allgather = allgather; c->shard_user = user;
+    return SDM_OK;
+}
+
+int sdm_set_solve_sharding_rccl(sdm_ctx* c, void* nccl_comm, int rank, int world_size, void* nccl_broadcast_fn, void* nccl_allgather_fn)
+{
+    if (!c) return fail(SDM_ERR_INVALID, "null handle");
+    c->shard_bcast = nullptr; c->shard_allgather = nullptr; c->shard_user = nullptr;
+    if (!nccl_comm) { c->shard_world = 0; c->shard_comm = nullptr; return SDM_OK; }
+    if (world_size < 1 || rank < 0 || rank >= world_size) return fail(SDM_ERR_INVALID, "sdm_set_solve_sharding_rccl: 0 <= rank < world_size required");
+    if (!nccl_broadcast_fn) nccl_broadcast_fn = find_rccl_symbol("ncclBroadcast");
+    if (!nccl_allgather_fn) nccl_allgather_fn = find_rccl_symbol("ncclAllGather");
+    if (!nccl_broadcast_fn || !nccl_allgather_fn)
+        return fail(SDM_ERR_COMM, "ncclBroadcast / ncclAllGather not found: pass their addresses, or make librccl.so loadable");
+    c->rccl_bcast = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))nccl_broadcast_fn;
+    c->rccl_allgather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))nccl_allgather_fn;
+    c->shard_comm = nccl_comm; c->shard_rank = rank; c->shard_world = world_size;
     return SDM_OK;
 }
 
@@ -956,7 +1015,16 @@ int sdm_solve(sdm_ctx* c, int level, int reg_type, float reg_param, int regulari
     {
         Timer t(c, SDM_T_FACTOR);
         // factor + forward substitution (the back substitution is part of the same launcher)
-        sdm_launch_cholesky_solve(c->G.p, ncols, F, Fp, Mp, c->Rsol.p, Mp, c->winv.p, c->status.p, c->stream, &c->solve_aux);
+        SolveShard shard{};
+        const bool sharded = c->shard_world >= 1 && (c->shard_comm || c->shard_bcast);
+        if (sharded) {
+            if ((rc = c->shard_stage.ensure(sdm_solve_shard_stage_tiles(ncols, c->shard_world) * 128 * 128))) return rc;
+            shard.rank = c->shard_rank; shard.world = c->shard_world; shard.stage = c->shard_stage.p; shard.self = c;
+            shard.bcast = shard_bcast_thunk; shard.allgather = shard_allgather_thunk;
+        }
+        const int crc = sdm_launch_cholesky_solve(c->G.p, ncols, F, Fp, Mp, c->Rsol.p, Mp, c->winv.p, c->status.p, c->stream,
+                                                  &c->solve_aux, sharded ? &shard : nullptr);
+        if (crc) return fail(SDM_ERR_COMM, "sharded factorisation: a collective failed with status " + std::to_string(crc));
     }
     HIP_TRY(hipGetLastError());
     // R (Fp x Mp) -> Rt (Mp x ldf, zero padded: the apply GEMM's operand) on the device; the host copy only on request
@@ -996,7 +1064,7 @@ int sdm_solve_normal_equations(sdm_ctx* c, const float* A, int N, int F, const f
         if (reg_type == SDM_REG_MATRIX_NORM) sdm_launch_fro2_upper(dG.p, ncols, F, dfro.p, c->stream);
         sdm_launch_add_diag(dG.p, ncols, F, dfro.p + F, reg_type, reg_param, N, regularise_last_row, c->lambda_dev.p, c->stream);
     }
-    { Timer t(c, SDM_T_FACTOR); sdm_launch_cholesky_solve(dG.p, ncols, F, Fp, Mp, dR.p, Mp, dW.p, c->status.p, c->stream, &c->solve_aux); }
+    { Timer t(c, SDM_T_FACTOR); (void)sdm_launch_cholesky_solve(dG.p, ncols, F, Fp, Mp, dR.p, Mp, dW.p, c->status.p, c->stream, &c->solve_aux); }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy2DAsync(R_host, (size_t)M * sizeof(float), dR.p, (size_t)Mp * sizeof(float), (size_t)M * sizeof(float), F,
                              hipMemcpyDeviceToHost, c->stream));

@@ -1627,7 +1627,7 @@ static void launch_fast_oc(const ImageSetDev& imgs, const int* img_idx, const fl
     const size_t lds = fast_wg_lds_bytes(lv.cell, lv.C, lv.O, lv.D, pair, columns);
     static unsigned long long attr_seen = 0;
     if (sdm_first_use_on_device(attr_seen)) {
-#define HATTR(A, B, P) (void)hipFuncSetAttribute((const void*)hog_fast_kernel<A, B, TO, TC, P>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+#define HATTR(A, B, P) SDM_SET_ATTR((const void*)hog_fast_kernel<A, B, TO, TC, P>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
         HATTR(ACC_EXACT_ORDER, 0, false); HATTR(ACC_EXACT_ORDER, 1, false); HATTR(ACC_EXACT_ORDER, 2, false);
         HATTR(ACC_FIXED64, 0, false); HATTR(ACC_FIXED64, 1, false); HATTR(ACC_FIXED64, 2, false);
         HATTR(ACC_EXACT_ORDER, 2, true); HATTR(ACC_FIXED64, 2, true);
@@ -1662,7 +1662,7 @@ void sdm_launch_hog_fast_profile(const ImageSetDev& imgs, const int* img_idx, co
     const unsigned grid = (unsigned)((total + HF_WAVES - 1) / HF_WAVES);
     static unsigned long long attr_seen = 0;
     if (sdm_first_use_on_device(attr_seen))
-        (void)hipFuncSetAttribute((const void*)hog_fast_kernel<ACC_COLUMNS, 2, 4, 5, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        SDM_SET_ATTR((const void*)hog_fast_kernel<ACC_COLUMNS, 2, 4, 5, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((hog_fast_kernel<ACC_COLUMNS, 2, 4, 5, false, true>), dim3(grid), dim3(HF_WAVES * 64), per * HF_WAVES + HF_WT_BYTES,
                        stream, imgs, img_idx, x, N, L, eyes, lv, feat, ldf, (int*)nullptr, status, per, prof_dev);
 }

@@ -2,6 +2,7 @@
 // Not part of the public boundary (that is include/sdm.h).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdio>
 #include <stdint.h>
 
 #define SDM_SCALE_TAB 128
@@ -157,7 +158,8 @@ void sdm_launch_targets(const float* x, const float* xstar, int N, int L, const 
 // ncols x ncols matrix (i-tile <= j-tile); A is [rows][lda], C is [ncols][ldc]. ncols % 128 == 0.
 // tile_i0 / tile_j0 restrict the update to tiles with i-tile >= tile_i0 (used by the Cholesky).
 void sdm_launch_syrk_tn(const float* A, long long lda, int rows, int ncols, float* C, long long ldc,
-                        float alpha, int accumulate, int tile_i0, hipStream_t stream, int tile_rows = 0);
+                        float alpha, int accumulate, int tile_i0, hipStream_t stream, int tile_rows = 0, int own_rank = 0,
+                        int own_world = 1);
 
 // Frobenius norm^2 (double) of the symmetric matrix whose upper triangle (incl. diagonal) of the
 // leading F x F block is stored in G; result accumulated into *out (must be zeroed).
@@ -182,7 +184,29 @@ inline bool sdm_first_use_on_device(unsigned long long& seen)
     return true;
 }
 
+// a refused attribute (dynamic LDS above 64 KB) is reported once, with the call site; the launch that follows fails and the
+// C-ABI returns that error (the results used to be discarded)
+inline void sdm_check_launch_attr(hipError_t e, const char* what)
+{
+    if (e != hipSuccess) fprintf(stderr, "libsdm_hip: hipFuncSetAttribute(%s) failed: %s\n", what, hipGetErrorString(e));
+}
+#define SDM_SET_ATTR(...) sdm_check_launch_attr(hipFuncSetAttribute(__VA_ARGS__), #__VA_ARGS__)
+
 // second queue + two events for the look-ahead of the blocked Cholesky (optional)
 struct SolveAux { hipStream_t stream; hipEvent_t chain_done, tail_done; };
-void sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs, float* R_out,
-                               long long ldr, float* work, int* status, hipStream_t stream, const SolveAux* aux = nullptr);
+// Sharded factorisation: every rank holds the same regularised system; rank r performs the tile operations of
+// the tile columns j with j % world == r.  Per 128-column step the owner of the step's column broadcasts its factored
+// diagonal tile and the column's tiles of the open panel group (<= 4 tiles); per group of 4 steps the ranks all-gather the
+// group's panel rows.  `stage` holds (world + 1) * 4 * (T / world + 1) tiles.  The callbacks return 0 on success.
+struct SolveShard {
+    int rank, world;
+    float* stage;
+    void* self;
+    int (*bcast)(void* self, float* buf, size_t count_f32, int root, hipStream_t stream);
+    int (*allgather)(void* self, const float* send, float* recv, size_t count_f32_per_rank, hipStream_t stream);
+};
+inline size_t sdm_solve_shard_stage_tiles(int ncols, int world) { return (size_t)(world + 1) * 4 * (size_t)(ncols / 128 / world + 1); }
+// returns 0, or the non-zero result of a failed collective
+int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs, float* R_out,
+                              long long ldr, float* work, int* status, hipStream_t stream, const SolveAux* aux = nullptr,
+                              const SolveShard* shard = nullptr);

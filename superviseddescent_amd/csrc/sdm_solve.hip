@@ -35,9 +35,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <bool CHUNKED>
 __global__ void __launch_bounds__(256)
 syrk_tn_kernel(const float* __restrict__ A, long long lda, int rows, float* __restrict__ C, long long ldc,
-               float alpha, int accumulate, int tile_i0)
+               float alpha, int accumulate, int tile_i0, int own_first, int own_stride)
 {
-    const int ti = blockIdx.y + tile_i0, tj = blockIdx.x + tile_i0;
+    // (own_first, own_stride): the tile columns this launch covers, counted from tile_i0 -- (0, 1) = all of them; a rank of a
+    // sharded factorisation passes the columns it owns
+    const int ti = blockIdx.y + tile_i0, tj = tile_i0 + own_first + blockIdx.x * own_stride;
     if (tj < ti) return;
     __shared__ __attribute__((aligned(16))) float As[SYRK_BK][TILE];
     __shared__ __attribute__((aligned(16))) float Bs[SYRK_BK][TILE];
@@ -150,9 +152,9 @@ __device__ inline void glds16_solve(const float* g, float* lds_dst)
 template <bool CHUNKED>
 __global__ void __launch_bounds__(256)
 syrk_tn_glds_kernel(const float* __restrict__ A, long long lda, int rows, float* __restrict__ C, long long ldc,
-                    float alpha, int accumulate, int tile_i0)
+                    float alpha, int accumulate, int tile_i0, int own_first, int own_stride)
 {
-    const int ti = blockIdx.y + tile_i0, tj = blockIdx.x + tile_i0;
+    const int ti = blockIdx.y + tile_i0, tj = tile_i0 + own_first + blockIdx.x * own_stride;
     if (tj < ti) return;
     extern __shared__ __attribute__((aligned(16))) float glds[];      // [2 buffers][A | B][SYRK_GBK][TILE]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -243,12 +245,14 @@ syrk_tn_glds_kernel(const float* __restrict__ A, long long lda, int rows, float*
 #define THIN_N 64
 __global__ void __launch_bounds__(256)
 syrk_tn_thin_kernel(const float* __restrict__ A, long long lda, int rows, float* __restrict__ C, long long ldc,
-                    float alpha, int tile_i0)
+                    float alpha, int tile_i0, int own_first, int own_stride)
 {
-    // blockIdx.y: 64-row sub-tile row counted from tile row tile_i0; blockIdx.x: 64-column sub-tile column counted from
-    // tile column tile_i0.  Everything below is relative to the first tile of this sub-tile row.
+    // blockIdx.y: 64-row sub-tile row counted from tile row tile_i0; blockIdx.x: 64-column half of the covered tile column
+    // number blockIdx.x / 2 (tile column tile_i0 + own_first + (blockIdx.x / 2) * own_stride).  Everything below is relative
+    // to the first tile of this sub-tile row.
     const int ti = tile_i0 + (int)(blockIdx.y >> 1), si = blockIdx.y & 1;
-    const int sj = (int)blockIdx.x - 2 * (ti - tile_i0);    // sub-tile column counted from the start of tile ti
+    const int tjc = tile_i0 + own_first + (int)(blockIdx.x >> 1) * own_stride;
+    const int sj = 2 * (tjc - ti) + (int)(blockIdx.x & 1);  // sub-tile column counted from the start of tile ti
     if (sj < si) return;                                   // left of / below the diagonal
     extern __shared__ __attribute__((aligned(16))) float tl[];   // [A | B][THIN_BK][THIN_N]
     float* As = tl;
@@ -424,7 +428,8 @@ potrf_tile_kernel(float* __restrict__ G, long long ldg, int k0, int* __restrict_
         }
         __syncthreads();
         if (*badf != 0.0f) {
-            if (t == 0) atomicOr(status, 2);
+            // (the NaN travels with the tile: the other ranks of a sharded factorisation see the failure in trsm_tile_kernel)
+            if (t == 0) { atomicOr(status, 2); Gk[0] = __builtin_nanf(""); }
             return;
         }
         // (b) panel: column c right of the block: U[j0+m][c] = (T[j0+m][c] - sum_{p<m} U[j0+p][j0+m] U[j0+p][c]) / U[j0+m][j0+m]
@@ -476,15 +481,18 @@ potrf_tile_kernel(float* __restrict__ G, long long ldg, int k0, int* __restrict_
 //      The extra last workgroup solves for the identity instead and stores U_kk^-T (= the transposed inverse of the
 //      diagonal factor) into winv_t: the back substitution then needs only products, no serial solves ----------------
 __global__ void __launch_bounds__(TILE * PQ)
-trsm_tile_kernel(float* __restrict__ G, long long ldg, int k0, int tile_j0, int n_tiles, float* __restrict__ winv_t)
+trsm_tile_kernel(float* __restrict__ G, long long ldg, int k0, int tile_j0, int n_tiles, float* __restrict__ winv_t, int own_stride,
+                 int* __restrict__ status)
 {
+    // workgroup b < n_tiles: tile column tile_j0 + b * own_stride (the caller's columns: all of them, or the owned ones)
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* UT = sm;                    // [128][128] U_kk transposed: UT[r][m] = U[m][r]
     float* Y = sm + TILE * TILE;       // [128][128] the tile, solved in place; only the threads of column c touch column c
     const int t = threadIdx.x, c = t & (TILE - 1), q = t >> 7;
     const bool inverse = (int)blockIdx.x == n_tiles;
-    const long long j0g = (long long)(tile_j0 + blockIdx.x) * TILE;
+    const long long j0g = (long long)(tile_j0 + (int)blockIdx.x * own_stride) * TILE;
     const float* Gk = G + (long long)k0 * ldg + k0;
+    if (inverse && t == 0 && !(Gk[0] == Gk[0])) atomicOr(status, 2);      // the owner's potrf reported "not positive definite"
     float* B = inverse ? winv_t : G + (long long)k0 * ldg + j0g;
     const long long ldb = inverse ? TILE : ldg;
     // 16-byte loads: thread t takes 4 columns of row (t/32 + 16*pass)
@@ -637,39 +645,46 @@ backsolve_step_kernel(float* __restrict__ G, long long ldg, int k0, int rhs0, co
 }  // namespace
 
 void sdm_launch_syrk_tn(const float* A, long long lda, int rows, int ncols, float* C, long long ldc,
-                        float alpha, int accumulate, int tile_i0, hipStream_t stream, int tile_rows)
+                        float alpha, int accumulate, int tile_i0, hipStream_t stream, int tile_rows, int own_rank, int own_world)
 {
-    // tiles (ti, tj) with tile_i0 <= ti < tile_i0 + tile_rows (all remaining tile rows when tile_rows <= 0), tj >= ti
+    // tiles (ti, tj) with tile_i0 <= ti < tile_i0 + tile_rows (all remaining tile rows when tile_rows <= 0), tj >= ti;
+    // with own_world > 1 only the tile columns tj with tj % own_world == own_rank (a rank's share of a sharded factorisation).
+    // The kernel is chosen from the GLOBAL shape (T, Ty, rows), never from the share: a tile is computed by the same
+    // instructions whoever owns it, so the factor does not depend on the number of ranks.
     const int T = ncols / TILE - tile_i0;
     if (T <= 0 || rows <= 0) return;
     const int Ty = (tile_rows > 0 && tile_rows < T) ? tile_rows : T;
+    const int W = own_world > 1 ? own_world : 1;
+    const int first = W > 1 ? (((own_rank - tile_i0) % W) + W) % W : 0;      // first covered column, counted from tile_i0
+    const int Tx = first < T ? (T - first + W - 1) / W : 0;                   // covered tile columns
+    if (Tx <= 0) return;
     const bool chunked = rows > SYRK_CHUNK * SYRK_BK * 4;
     // thin updates (a panel group's row update / a head with fewer tiles than the chip has CUs)
     if (Ty <= 4 && T * Ty <= 320 && accumulate && rows % THIN_BK == 0 && rows <= 1024) {
         const size_t lds = (size_t)2 * THIN_BK * THIN_N * sizeof(float);      // 64 KB
         static unsigned long long thin_seen = 0;
         if (sdm_first_use_on_device(thin_seen))
-            (void)hipFuncSetAttribute((const void*)syrk_tn_thin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(syrk_tn_thin_kernel, dim3(2 * T, 2 * Ty), dim3(256), lds, stream, A, lda, rows, C, ldc, alpha, tile_i0);
+            sdm_check_launch_attr(hipFuncSetAttribute((const void*)syrk_tn_thin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "syrk_tn_thin_kernel");
+        hipLaunchKernelGGL(syrk_tn_thin_kernel, dim3(2 * Tx, 2 * Ty), dim3(256), lds, stream, A, lda, rows, C, ldc, alpha, tile_i0, first, W);
         return;
     }
     if (rows % SYRK_GBK == 0) {      // LDS-direct staging
         const size_t lds = (size_t)2 * 2 * SYRK_GBK * TILE * sizeof(float);      // 64 KB
         static unsigned long long attr_seen = 0;
         if (sdm_first_use_on_device(attr_seen)) {
-            (void)hipFuncSetAttribute((const void*)syrk_tn_glds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)syrk_tn_glds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            sdm_check_launch_attr(hipFuncSetAttribute((const void*)syrk_tn_glds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "syrk_tn_glds_kernel");
+            sdm_check_launch_attr(hipFuncSetAttribute((const void*)syrk_tn_glds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "syrk_tn_glds_kernel");
         }
         if (chunked)
-            hipLaunchKernelGGL(syrk_tn_glds_kernel<true>, dim3(T, Ty), dim3(256), lds, stream, A, lda, rows, C, ldc, alpha, accumulate, tile_i0);
+            hipLaunchKernelGGL(syrk_tn_glds_kernel<true>, dim3(Tx, Ty), dim3(256), lds, stream, A, lda, rows, C, ldc, alpha, accumulate, tile_i0, first, W);
         else
-            hipLaunchKernelGGL(syrk_tn_glds_kernel<false>, dim3(T, Ty), dim3(256), lds, stream, A, lda, rows, C, ldc, alpha, accumulate, tile_i0);
+            hipLaunchKernelGGL(syrk_tn_glds_kernel<false>, dim3(Tx, Ty), dim3(256), lds, stream, A, lda, rows, C, ldc, alpha, accumulate, tile_i0, first, W);
     } else if (chunked)
-        hipLaunchKernelGGL(syrk_tn_kernel<true>, dim3(T, Ty), dim3(256), 0, stream, A, lda, rows, C, ldc, alpha,
-                           accumulate, tile_i0);
+        hipLaunchKernelGGL(syrk_tn_kernel<true>, dim3(Tx, Ty), dim3(256), 0, stream, A, lda, rows, C, ldc, alpha,
+                           accumulate, tile_i0, first, W);
     else
-        hipLaunchKernelGGL(syrk_tn_kernel<false>, dim3(T, Ty), dim3(256), 0, stream, A, lda, rows, C, ldc, alpha,
-                           accumulate, tile_i0);
+        hipLaunchKernelGGL(syrk_tn_kernel<false>, dim3(Tx, Ty), dim3(256), 0, stream, A, lda, rows, C, ldc, alpha,
+                           accumulate, tile_i0, first, W);
 }
 
 // ---- packed exchange buffer ----------------------------------------------------------------------------------------
@@ -685,6 +700,26 @@ __global__ __launch_bounds__(256) void tiles_pack_kernel(float* G, long long ldg
     for (int e = threadIdx.x; e < TILE * TILE / 4; e += 256) {
         const int r = e / (TILE / 4), c4 = e % (TILE / 4);
         float4* g = (float4*)(G + (long long)(ti * TILE + r) * ldg + (long long)tj * TILE) + c4;
+        if (unpack) *g = p[e]; else p[e] = *g;
+    }
+}
+
+// ---- exchange buffers of the sharded factorisation --------------------------------------------------------------
+// stage[(z * nr + y) * nc + x] <-> tile (r0 + y, first_z + x * W) of G, first_z = the first tile column >= c0 owned by rank
+// rank0 + z (column j belongs to rank j % W); columns beyond tile column c_end - 1 are skipped (the ranks own different
+// numbers of columns, the buffers are sized for the largest share).  W = 1, nc = 1, c0 = the column: one column of tiles.
+__global__ __launch_bounds__(256) void tiles_gather_kernel(float* G, long long ldg, float* stage, int r0, int nr, int c0, int c_end,
+                                                            int W, int rank0, int nc, int unpack, int skip_rank)
+{
+    const int x = blockIdx.x, y = blockIdx.y, r = rank0 + (int)blockIdx.z;
+    if (unpack && r == skip_rank) return;                 // a rank's own tiles are already in place
+    const int first = c0 + ((((r - c0) % W) + W) % W);
+    const int col = first + x * W;
+    if (col >= c_end) return;
+    float4* p = (float4*)(stage + ((size_t)((size_t)blockIdx.z * nr + y) * nc + x) * TILE * TILE);
+    for (int e = threadIdx.x; e < TILE * TILE / 4; e += 256) {
+        const int rr = e / (TILE / 4), c4 = e % (TILE / 4);
+        float4* g = (float4*)(G + (long long)((r0 + y) * TILE + rr) * ldg + (long long)col * TILE) + c4;
         if (unpack) *g = p[e]; else p[e] = *g;
     }
 }
@@ -716,8 +751,8 @@ void sdm_launch_add_diag(float* G, long long ldg, int F, const double* fro2, int
                        reg_type, param, (float)n_train, regularise_last_row, lambda_out);
 }
 
-void sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs, float* R_out,
-                               long long ldr, float* work, int* status, hipStream_t stream, const SolveAux* aux)
+int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs, float* R_out,
+                              long long ldr, float* work, int* status, hipStream_t stream, const SolveAux* aux, const SolveShard* shard)
 {
     // work: Tf * 128 * 128 floats, receives the transposed inverses U_kk^-T of the diagonal factor tiles
     const int Tf = (F + TILE - 1) / TILE;          // factor tiles
@@ -727,9 +762,9 @@ void sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrh
     const size_t lds_trsm = ((size_t)2 * TILE * TILE) * sizeof(float);
     static unsigned long long attr_seen = 0;
     if (sdm_first_use_on_device(attr_seen)) {
-        (void)hipFuncSetAttribute((const void*)potrf_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)trsm_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-#define BSATTR(NJv) (void)hipFuncSetAttribute((const void*)backsolve_step_kernel<NJv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+        SDM_SET_ATTR((const void*)potrf_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        SDM_SET_ATTR((const void*)trsm_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define BSATTR(NJv) SDM_SET_ATTR((const void*)backsolve_step_kernel<NJv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
         BSATTR(1); BSATTR(2); BSATTR(3); BSATTR(4); BSATTR(5);
 #undef BSATTR
     }
@@ -740,32 +775,67 @@ void sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrh
     // `stream`, the critical path) and everything below them (tail, on aux->stream).  The next group's potrf / trsm /
     // row updates -- single-workgroup latency chains -- are then issued while the tail, which carries almost all the
     // flops, is still in flight; the two only meet again at the next head (same tile rows), which waits for the tail.
+    //
+    // Sharded (shard != null): the same sequence of launches, each restricted to the tile columns this rank owns (column j
+    // belongs to rank j % world), so every tile is computed by the same instructions as in the replicated solve and the factor
+    // is bit-identical for any number of ranks.  What a rank reads but does not own arrives by two exchanges: at step k the
+    // owner of column k broadcasts U_kk and the column-k tiles of the open group's panel rows (the row update and the panel
+    // solve of the others need them); at a group end the ranks all-gather the group's panel rows, which the trailing update
+    // reads across ALL columns.  After the last group every rank holds all of U and of the forward-substituted right-hand
+    // sides; the back substitution is replicated.
     const int LAZY = 4;
     const bool overlap = aux && aux->stream && Tf > 2 * LAZY;
+    const int W = shard ? shard->world : 1, me = shard ? shard->rank : 0;
     bool tail_pending = false;
     for (int k = 0; k < Tf; ++k) {
         const int k0 = k * TILE;
         const int g0 = (k / LAZY) * LAZY;                 // first panel of this group
-        if (k > g0)   // bring tile row k up to date with the panels g0 .. k-1 of its group
-            sdm_launch_syrk_tn(G + (long long)g0 * TILE * ldg, ldg, (k - g0) * TILE, ncols, G, ldg, -1.0f, 1, k, stream, 1);
-        hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(TILE * PQ), lds_potrf, stream, G, ldg, k0, status);
+        const int nb = k - g0;                            // panels of the group before this one
+        const bool mine = !shard || k % W == me;
+        // bring tile row k up to date with the panels g0 .. k-1 of its group (owned columns; the owner of column k first:
+        // its tile (k, k) is what the chain waits for)
+        if (nb && mine) sdm_launch_syrk_tn(G + (long long)g0 * TILE * ldg, ldg, nb * TILE, ncols, G, ldg, -1.0f, 1, k, stream, 1, me, W);
+        if (mine) hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(TILE * PQ), lds_potrf, stream, G, ldg, k0, status);
+        if (shard) {
+            // tiles (g0 .. k, k): the group's panel rows in column k, then the factored diagonal tile
+            if (mine) hipLaunchKernelGGL(tiles_gather_kernel, dim3(1, nb + 1, 1), dim3(256), 0, stream, G, ldg, shard->stage, g0, nb + 1, k, k + 1, 1, 0, 1, 0, -1);
+            const int rc = shard->bcast(shard->self, shard->stage, (size_t)(nb + 1) * TILE * TILE, k % W, stream);
+            if (rc) return rc;
+            if (!mine) {
+                hipLaunchKernelGGL(tiles_gather_kernel, dim3(1, nb + 1, 1), dim3(256), 0, stream, G, ldg, shard->stage, g0, nb + 1, k, k + 1, 1, 0, 1, 1, -1);
+                if (nb) sdm_launch_syrk_tn(G + (long long)g0 * TILE * ldg, ldg, nb * TILE, ncols, G, ldg, -1.0f, 1, k, stream, 1, me, W);
+            }
+        }
         const int ntr = T - (k + 1);
-        // ntr panel tiles + one workgroup that produces U_kk^-T for the back substitution
-        hipLaunchKernelGGL(trsm_tile_kernel, dim3(ntr + 1), dim3(TILE * PQ), lds_trsm, stream, G, ldg, k0, k + 1, ntr,
-                           work + (size_t)k * TILE * TILE);
+        // the panel tiles of the owned columns + one workgroup that produces U_kk^-T for the back substitution
+        const int first = k + 1 + ((((me - (k + 1)) % W) + W) % W);             // first owned column right of k
+        const int nown = first < T ? (T - first + W - 1) / W : 0;
+        hipLaunchKernelGGL(trsm_tile_kernel, dim3(nown + 1), dim3(TILE * PQ), lds_trsm, stream, G, ldg, k0, first, nown,
+                           work + (size_t)k * TILE * TILE, W, status);
         const bool group_end = (k + 1) % LAZY == 0 || k == Tf - 1;
         if (group_end && ntr > 0) {   // trailing update of all tiles (ti >= k+1, tj >= ti) from the group's panel rows
             const float* panels = G + (long long)g0 * TILE * ldg;
             const int prow = (k + 1 - g0) * TILE;
+            if (shard) {
+                // all-gather of the panel rows g0 .. k right of column k: every rank contributes the tiles of its columns
+                const int nr = k + 1 - g0, ncmax = (ntr + W - 1) / W;
+                const size_t per_rank = (size_t)nr * ncmax * TILE * TILE;
+                float* send = shard->stage;
+                float* recv = shard->stage + per_rank;
+                hipLaunchKernelGGL(tiles_gather_kernel, dim3(ncmax, nr, 1), dim3(256), 0, stream, G, ldg, send, g0, nr, k + 1, T, W, me, ncmax, 0, -1);
+                const int rc = shard->allgather(shard->self, send, recv, per_rank, stream);
+                if (rc) return rc;
+                hipLaunchKernelGGL(tiles_gather_kernel, dim3(ncmax, nr, W), dim3(256), 0, stream, G, ldg, recv, g0, nr, k + 1, T, W, 0, ncmax, 1, me);
+            }
             if (!overlap) {
-                sdm_launch_syrk_tn(panels, ldg, prow, ncols, G, ldg, -1.0f, 1, k + 1, stream, 0);
+                sdm_launch_syrk_tn(panels, ldg, prow, ncols, G, ldg, -1.0f, 1, k + 1, stream, 0, me, W);
             } else {
                 (void)hipEventRecord(aux->chain_done, stream);
                 if (tail_pending) (void)hipStreamWaitEvent(stream, aux->tail_done, 0);   // head rows were tail rows of the last group
-                sdm_launch_syrk_tn(panels, ldg, prow, ncols, G, ldg, -1.0f, 1, k + 1, stream, LAZY);
+                sdm_launch_syrk_tn(panels, ldg, prow, ncols, G, ldg, -1.0f, 1, k + 1, stream, LAZY, me, W);
                 if (k + 1 + LAZY < T) {
                     (void)hipStreamWaitEvent(aux->stream, aux->chain_done, 0);
-                    sdm_launch_syrk_tn(panels, ldg, prow, ncols, G, ldg, -1.0f, 1, k + 1 + LAZY, aux->stream, 0);
+                    sdm_launch_syrk_tn(panels, ldg, prow, ncols, G, ldg, -1.0f, 1, k + 1 + LAZY, aux->stream, 0, me, W);
                     (void)hipEventRecord(aux->tail_done, aux->stream);
                     tail_pending = true;
                 }
@@ -789,4 +859,5 @@ void sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrh
         }
 #undef BS
     }
+    return 0;
 }

@@ -265,6 +265,34 @@ class Context:
     def allreduce_gram_rhs(self):
         check(self._lib.sdm_allreduce_gram_rhs(self._h))
 
+    def set_solve_sharding(self, rank: int, world_size: int, bcast: Optional[Callable[[int, int, int, int], int]],
+                           allgather: Optional[Callable[[int, int, int, int], int]]):
+        """Sharded factorisation inside ``solve`` (include/sdm.h: sdm_set_solve_sharding): rank ``rank`` of ``world_size``
+        works on the tile columns ``j % world_size == rank``.  ``bcast(dev_ptr, count_f32, root, hip_stream) -> 0`` and
+        ``allgather(send_ptr, recv_ptr, count_f32_per_rank, hip_stream) -> 0`` must be stream-ordered.  ``None`` for both
+        restores the replicated solve."""
+        if bcast is None and allgather is None:
+            check(self._lib.sdm_set_solve_sharding(self._h, 0, 0, _lib.BCAST_FN(), _lib.ALLGATHER_FN(), None))
+            return
+
+        def guard(fn):
+            def tramp(*args):
+                try:
+                    return int(fn(*args[:-1]) or 0)
+                except Exception:  # never let an exception cross the C boundary
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            return tramp
+        b, g = _lib.BCAST_FN(guard(bcast)), _lib.ALLGATHER_FN(guard(allgather))
+        self._keep += [b, g]
+        check(self._lib.sdm_set_solve_sharding(self._h, rank, world_size, b, g, None))
+
+    def set_solve_sharding_rccl(self, comm: Optional[int], rank: int = 0, world_size: int = 1, bcast_fn: Optional[int] = None,
+                                allgather_fn: Optional[int] = None):
+        """The same through RCCL called by the library on its own stream; ``comm`` = ncclComm_t (None uninstalls)."""
+        check(self._lib.sdm_set_solve_sharding_rccl(self._h, comm, rank, world_size, bcast_fn, allgather_fn))
+
     def solve(self, level: int, reg_type: int, reg_param: float, regularise_last_row: bool,
               n_train_global: int = 0, fetch: bool = True):
         lam = ctypes.c_float(0.0)

@@ -1,0 +1,167 @@
+"""Sharded factorisation (include/sdm.h: sdm_set_solve_sharding, csrc/sdm_solve.hip: sdm_launch_cholesky_solve with a
+SolveShard): W contexts on ONE GPU play the W ranks of a training run AFTER the all-reduce -- each holds the same regularised
+system -- and factor it together: rank r works on the tile columns j % W == r, the owner of a step's column broadcasts its
+diagonal tile, the ranks all-gather each group of panel rows.  The collectives of this test are device-to-device copies
+between the contexts' buffers, synchronised by a thread barrier (one thread drives one context, as one process would drive
+one GPU).  Every tile is computed by the same instructions whoever owns it, so the regressor must be BIT-identical to the
+replicated solve for every W -- including the look-ahead over two queues (more than 8 factor tiles) and the two-tile
+right-hand side of the 68-landmark layout.
+
+The reference solves on one core (include/superviseddescent/regressors.hpp:224-225); north_star: data-parallel training
+whose replicated solve is the serial fraction (missing item 3)."""
+import threading
+
+import numpy as np
+import pytest
+
+from superviseddescent_amd import Context, HoGParam, SdmError, ibug, synth
+
+pytestmark = pytest.mark.gpu
+
+
+class _Span:
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f4", "data": (int(ptr), False), "version": 3,
+                                         "strides": None}
+
+
+def prepared_context(images, idx, x_star, x0, ids, params):
+    re, le = ibug.eye_indices(ids)
+    ctx = Context(0)
+    ctx.set_model_geometry(len(ids), re, le, [HoGParam(*p) for p in params])
+    ctx.upload_images(images)
+    ctx.set_sample_image_index(idx)
+    ctx.set_x(x0)
+    ctx.set_targets(x_star)
+    ctx.hog_features(0)
+    ctx.gram_rhs(0)
+    return ctx
+
+
+class LocalGroup:
+    """bcast / all-gather between W contexts of one process: stream sync + barrier + device-to-device copies."""
+
+    def __init__(self, world):
+        import torch
+        self.torch = torch
+        self.world = world
+        self.barrier = threading.Barrier(world, timeout=120)
+        self.slots = [None] * world
+        self.calls = [dict(bcast=0, allgather=0, bcast_floats=0, allgather_floats=0) for _ in range(world)]
+        self.dev = torch.device("cuda", 0)
+
+    def _stream(self, stream):
+        return self.torch.cuda.ExternalStream(int(stream), device=self.dev)
+
+    def _view(self, ptr, count):
+        return self.torch.as_tensor(_Span(ptr, count), device=self.dev)
+
+    def bcast(self, rank):
+        def fn(ptr, count, root, stream):
+            st = self._stream(stream)
+            if rank == root:
+                st.synchronize()
+                self.slots[0] = ptr
+            self.barrier.wait()
+            if rank != root:
+                with self.torch.cuda.stream(st):
+                    self._view(ptr, count).copy_(self._view(self.slots[0], count))
+                st.synchronize()
+            self.barrier.wait()
+            self.calls[rank]["bcast"] += 1
+            self.calls[rank]["bcast_floats"] += count
+            return 0
+        return fn
+
+    def allgather(self, rank):
+        def fn(send, recv, count, stream):
+            st = self._stream(stream)
+            st.synchronize()
+            self.slots[rank] = send
+            self.barrier.wait()
+            out = self._view(recv, count * self.world)
+            with self.torch.cuda.stream(st):
+                for r in range(self.world):
+                    out[r * count:(r + 1) * count].copy_(self._view(self.slots[r], count))
+            st.synchronize()
+            self.barrier.wait()
+            self.calls[rank]["allgather"] += 1
+            self.calls[rank]["allgather_floats"] += count
+            return 0
+        return fn
+
+
+def solve_sharded(world, make_ctx, reg):
+    group = LocalGroup(world)
+    ctxs = [make_ctx() for _ in range(world)]
+    out, errors = [None] * world, [None] * world
+
+    def work(rank):
+        try:
+            ctxs[rank].set_solve_sharding(rank, world, group.bcast(rank), group.allgather(rank))
+            out[rank] = ctxs[rank].solve(0, reg[0], reg[1], reg[2], n_train_global=0)
+        except Exception as e:  # noqa: BLE001 -- reported by the caller
+            errors[rank] = e
+            group.barrier.abort()
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for c in ctxs:
+        c.close()
+    return out, errors, group.calls
+
+
+CASES = {
+    # name: (landmark ids, one HoG level, regulariser)           F, factor tiles, RHS tiles
+    "rcr22_25_tiles": (ibug.RCR22_IDS, (1, 3, 12, 4, 0.9), (1, 1.5, False)),        # 3169, 25, 1: look-ahead path (> 8 tiles)
+    "rcr68_two_rhs_tiles": (ibug.IBUG68_IDS, (1, 2, 14, 4, 0.8), (0, 25.0, True)),  # 4353, 35, 2
+    "rcr22_7_tiles": (ibug.RCR22_IDS, (1, 1, 24, 6, 0.8), (0, 1.0, True)),          # 22*22+1 = 485 ... 4 tiles: no look-ahead
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_sharded_factorisation_is_bit_identical(built, case):
+    ids, hp, reg = CASES[case]
+    images, boxes, gt = synth.make_faces(96, seed=515)
+    x_star, x0, idx = synth.make_samples(boxes, gt, ids, n_perturb=4, seed=516)           # 480 rows
+
+    def make_ctx():
+        return prepared_context(images, idx, x_star, x0, ids, [hp])
+    ref = make_ctx()
+    R1, lam1 = ref.solve(0, reg[0], reg[1], reg[2], n_train_global=0)
+    ref.close()
+    F = R1.shape[0]
+    Tf = -(-F // 128)
+    T = Tf + (-(-(2 * len(ids)) // 16) * 16 + 127) // 128
+    for world in (1, 2, 3, 4):
+        out, errors, calls = solve_sharded(world, make_ctx, reg)
+        assert errors == [None] * world, errors
+        for rank in range(world):
+            R, lam = out[rank]
+            assert lam == lam1
+            assert np.array_equal(R.view(np.uint32), R1.view(np.uint32)), (case, world, rank)
+            # one broadcast per 128-column step, one all-gather per group of 4 steps that has columns to its right
+            assert calls[rank]["bcast"] == Tf
+            assert calls[rank]["allgather"] == -(-Tf // 4)
+            # a step ships at most 4 tiles, the gathers ship each rank's share of the panel rows (padded to the largest share)
+            assert calls[rank]["bcast_floats"] <= 4 * Tf * 128 * 128
+            assert calls[rank]["allgather_floats"] <= (T * (T + 1) // 2 // world + 4 * T) * 128 * 128
+
+
+def test_sharded_failure_is_seen_by_every_rank(built):
+    """A matrix that is not positive definite: the owner of the failing diagonal tile reports it, and so must the others."""
+    ids, hp, _ = CASES["rcr22_25_tiles"]
+    images, boxes, gt = synth.make_faces(16, seed=517)
+    x_star, x0, idx = synth.make_samples(boxes, gt, ids, n_perturb=1, seed=518)           # 32 rows, 3169 features
+    reg = (0, -50.0, True)                                                                # lambda < 0: G - 50 I is indefinite
+
+    def make_ctx():
+        return prepared_context(images, idx, x_star, x0, ids, [hp])
+    ref = make_ctx()
+    with pytest.raises(SdmError):
+        ref.solve(0, reg[0], reg[1], reg[2], n_train_global=0)
+    ref.close()
+    out, errors, _ = solve_sharded(3, make_ctx, reg)
+    assert all(isinstance(e, SdmError) for e in errors), errors
