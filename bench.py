@@ -102,6 +102,9 @@ def main():
     sdo = SupervisedDescentOptimiser([LinearRegressor(reg()) for _ in params], device=local_rank, stream=stream)
     hog = HogTransform(timg, params, ids, ibug.RIGHT_EYE_IDS, ibug.LEFT_EYE_IDS, tidx)
     allreduce = parallel.make_torch_allreduce(local_rank) if use_dist else None
+    # the summed system is factored by all ranks together (tile-column ownership) unless SDM_BENCH_REPLICATED_SOLVE=1
+    shard_solve = use_dist and os.environ.get("SDM_BENCH_REPLICATED_SOLVE", "0") != "1"
+    solve_collectives = parallel.make_torch_solve_collectives(local_rank) if shard_solve else None
     nlsr = []
     train_wall = []
     for rep in range(2):    # the second pass is the measured one (buffers allocated, code loaded)
@@ -112,6 +115,7 @@ def main():
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         sdo.train(txs, tx0, None, hog, allreduce=allreduce, world_size=world, n_train_global=n_train_global,
+                  rank=rank if shard_solve else None, solve_collectives=solve_collectives,
                   on_training_epoch_callback=(lambda cur: nlsr.append(float(np.linalg.norm(cur - txs) / np.linalg.norm(txs))))
                   if rep == 0 else None)
         if use_dist:
@@ -128,6 +132,7 @@ def main():
     regressors = [r.x for r in sdo.regressors]
     ctx = sdo.ctx
     ctx.set_allreduce(None, 1)
+    ctx.set_solve_sharding(0, 0, None, None)
 
     # ---- workload: this rank's shard of synthetic faces, resident in HBM --------------------------------
     images, boxes, gt = synth.make_faces(args.batch, seed=synth.SEED + 17 * rank)
@@ -268,6 +273,8 @@ def main():
             "sec_per_cascade": train_wall[-1] / n_levels,
             "scaling": "strong",
             "collective": "one all-reduce of {A^T A, A^T b} per level (torch.distributed nccl = RCCL)" if use_dist else "none (1 GPU)",
+            "solve": ("sharded over the ranks by tile column: one <= 4-tile broadcast per 128-column step, one all-gather per 4 steps"
+                      if shard_solve else "replicated on every rank" if use_dist else "single GPU"),
             "stage_ms_per_level_rank0": {k: v[0] / n_levels for k, v in train_timing.items()},
             "nlsr_per_level_rank0": nlsr,
             "seconds_total_two_passes": train_s,

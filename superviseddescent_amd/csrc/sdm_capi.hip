@@ -1021,6 +1021,8 @@ int sdm_solve(sdm_ctx* c, int level, int reg_type, float reg_param, int regulari
             if ((rc = c->shard_stage.ensure(sdm_solve_shard_stage_tiles(ncols, c->shard_world) * 128 * 128))) return rc;
             shard.rank = c->shard_rank; shard.world = c->shard_world; shard.stage = c->shard_stage.p; shard.self = c;
             shard.bcast = shard_bcast_thunk; shard.allgather = shard_allgather_thunk;
+            static const int emulate = getenv("SDM_SOLVE_SHARD_EMULATE") ? atoi(getenv("SDM_SOLVE_SHARD_EMULATE")) : 0;
+            shard.emulate_chain = emulate;
         }
         const int crc = sdm_launch_cholesky_solve(c->G.p, ncols, F, Fp, Mp, c->Rsol.p, Mp, c->winv.p, c->status.p, c->stream,
                                                   &c->solve_aux, sharded ? &shard : nullptr);

@@ -204,6 +204,9 @@ struct SolveShard {
     void* self;
     int (*bcast)(void* self, float* buf, size_t count_f32, int root, hipStream_t stream);
     int (*allgather)(void* self, const float* send, float* recv, size_t count_f32_per_rank, hipStream_t stream);
+    // measurement only (scripts/sharded_solve_timing.py): also run the potrf of the diagonal tiles this rank does NOT own, so
+    // that one context on one GPU spends the time a rank of a real run spends waiting for the owner's potrf
+    int emulate_chain;
 };
 inline size_t sdm_solve_shard_stage_tiles(int ncols, int world) { return (size_t)(world + 1) * 4 * (size_t)(ncols / 128 / world + 1); }
 // returns 0, or the non-zero result of a failed collective

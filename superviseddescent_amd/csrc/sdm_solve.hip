@@ -795,7 +795,7 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
         // bring tile row k up to date with the panels g0 .. k-1 of its group (owned columns; the owner of column k first:
         // its tile (k, k) is what the chain waits for)
         if (nb && mine) sdm_launch_syrk_tn(G + (long long)g0 * TILE * ldg, ldg, nb * TILE, ncols, G, ldg, -1.0f, 1, k, stream, 1, me, W);
-        if (mine) hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(TILE * PQ), lds_potrf, stream, G, ldg, k0, status);
+        if (mine || shard->emulate_chain) hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(TILE * PQ), lds_potrf, stream, G, ldg, k0, status);
         if (shard) {
             // tiles (g0 .. k, k): the group's panel rows in column k, then the factored diagonal tile
             if (mine) hipLaunchKernelGGL(tiles_gather_kernel, dim3(1, nb + 1, 1), dim3(256), 0, stream, G, ldg, shard->stage, g0, nb + 1, k, k + 1, 1, 0, 1, 0, -1);

@@ -503,7 +503,10 @@ class SupervisedDescentOptimiser:
 
     def train(self, parameters, initialisations, templates, projection: HogTransform,
               on_training_epoch_callback: Optional[Callable[[np.ndarray], None]] = None,
-              allreduce=None, world_size: int = 1, n_train_global: int = 0):
+              allreduce=None, world_size: int = 1, n_train_global: int = 0, rank: Optional[int] = None,
+              solve_collectives=None):
+        """``rank`` + ``solve_collectives = (bcast, allgather)`` (parallel.make_torch_solve_collectives) additionally shard the
+        factorisation of the summed system over the ranks (Context.set_solve_sharding); without them every rank solves it."""
         x0 = np.asarray(initialisations, np.float32)
         self._bind(projection, x0.shape[0])
         c = self.ctx
@@ -511,6 +514,11 @@ class SupervisedDescentOptimiser:
         c.set_x(x0)
         c.set_targets(np.asarray(parameters, np.float32))
         c.set_allreduce(allreduce, world_size)
+        if hasattr(c, "set_solve_sharding"):
+            if solve_collectives is not None and rank is not None:
+                c.set_solve_sharding(rank, world_size, *solve_collectives)
+            else:
+                c.set_solve_sharding(0, 0, None, None)
         self._resident, self._resident_geom = {}, getattr(c, "geometry_epoch", None)
         n_glob = n_train_global or c.N
         for level, reg in enumerate(self.regressors):

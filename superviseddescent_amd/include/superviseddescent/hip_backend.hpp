@@ -50,6 +50,13 @@ struct DataParallel {
     void* rccl_allreduce = nullptr;     // &ncclAllReduce of the RCCL the application links, or nullptr: the library loads librccl
     int world_size = 1;
     long long n_train_global = 0;
+    // sharded factorisation of the summed system (sdm.h: sdm_set_solve_sharding*): this rank's number, and either two
+    // callbacks or -- with rccl_comm -- ncclBroadcast / ncclAllGather (addresses may be nullptr: looked up by name)
+    int rank = -1;                      // < 0: replicated solve
+    sdm_bcast_fn bcast = nullptr;
+    sdm_allgather_fn allgather = nullptr;
+    void* rccl_broadcast = nullptr;
+    void* rccl_allgather = nullptr;
 };
 inline DataParallel& data_parallel()
 {
@@ -68,6 +75,17 @@ inline void set_data_parallel_rccl(void* nccl_comm, void* nccl_allreduce_fn, int
     dp = DataParallel();
     dp.rccl_comm = nccl_comm; dp.rccl_allreduce = nccl_allreduce_fn; dp.world_size = world_size; dp.n_train_global = n_train_global;
 }
+// opt in to the sharded factorisation on top of either exchange (call after set_data_parallel / set_data_parallel_rccl)
+inline void set_solve_sharding(int rank, sdm_bcast_fn bcast, sdm_allgather_fn allgather)
+{
+    DataParallel& dp = data_parallel();
+    dp.rank = rank; dp.bcast = bcast; dp.allgather = allgather;
+}
+inline void set_solve_sharding_rccl(int rank, void* nccl_broadcast_fn = nullptr, void* nccl_allgather_fn = nullptr)
+{
+    DataParallel& dp = data_parallel();
+    dp.rank = rank; dp.rccl_broadcast = nccl_broadcast_fn; dp.rccl_allgather = nccl_allgather_fn;
+}
 inline void clear_data_parallel() { data_parallel() = DataParallel(); }
 // applied by the batched backend to the context it trains on
 inline void install_data_parallel(sdm_ctx* c)
@@ -75,6 +93,13 @@ inline void install_data_parallel(sdm_ctx* c)
     const DataParallel& dp = data_parallel();
     if (dp.rccl_comm) check(sdm_set_allreduce_rccl(c, dp.rccl_comm, dp.rccl_allreduce, dp.world_size), "sdm_set_allreduce_rccl");
     else if (dp.fn) check(sdm_set_allreduce(c, dp.fn, dp.user, dp.world_size), "sdm_set_allreduce");
+    if (dp.rank >= 0 && dp.bcast && dp.allgather)
+        check(sdm_set_solve_sharding(c, dp.rank, dp.world_size, dp.bcast, dp.allgather, dp.user), "sdm_set_solve_sharding");
+    else if (dp.rank >= 0 && dp.rccl_comm)
+        check(sdm_set_solve_sharding_rccl(c, dp.rccl_comm, dp.rank, dp.world_size, dp.rccl_broadcast, dp.rccl_allgather),
+              "sdm_set_solve_sharding_rccl");
+    else
+        check(sdm_set_solve_sharding(c, 0, 0, nullptr, nullptr, nullptr), "sdm_set_solve_sharding");
 }
 
 // one lazily created handle per thread for the stand-alone solver calls

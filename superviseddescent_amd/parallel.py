@@ -58,6 +58,31 @@ def make_torch_allreduce(device_index: int) -> Callable[[int, int, int], int]:
     return allreduce
 
 
+def make_torch_solve_collectives(device_index: int):
+    """``(bcast, allgather)`` for ``Context.set_solve_sharding``: the two collectives of the sharded factorisation
+    (include/sdm.h) through ``torch.distributed`` (nccl = RCCL), issued with the engine's stream as torch's current one."""
+    import torch
+    import torch.distributed as dist
+
+    dev = torch.device("cuda", device_index)
+
+    def on_stream(stream):
+        return torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=dev)) if stream else torch.cuda.stream(None)
+
+    def bcast(ptr: int, count: int, root: int, stream: int) -> int:
+        with on_stream(stream):
+            dist.broadcast(torch.as_tensor(_DeviceSpan(ptr, count), device=dev), src=root)
+        return 0
+
+    def allgather(send: int, recv: int, count: int, stream: int) -> int:
+        with on_stream(stream):
+            dist.all_gather_into_tensor(torch.as_tensor(_DeviceSpan(recv, count * dist.get_world_size()), device=dev),
+                                        torch.as_tensor(_DeviceSpan(send, count), device=dev))
+        return 0
+
+    return bcast, allgather
+
+
 def make_host_allreduce() -> Callable[[np.ndarray], None]:
     """All-reduce for host buffers (gloo): used by the CPU tests of the data-parallel logic."""
     import torch

@@ -26,20 +26,32 @@ def main():
     reg = lambda: Regulariser(Regulariser.RegularisationType.MatrixNorm, 1.5, False)
     stream = torch.cuda.current_stream().cuda_stream
 
-    def train(allreduce, rows):
+    def train(allreduce, rows, shard=False):
         sdo = SupervisedDescentOptimiser([LinearRegressor(reg()) for _ in params], device=local, stream=stream)
         hog = HogTransform(images, params, ids, ibug.RIGHT_EYE_IDS, ibug.LEFT_EYE_IDS, idx[rows])
-        calls = []
-        fn = None
+        calls, shard_calls = [], []
+        fn, coll = None, None
         if allreduce is not None:
             def fn(ptr, count, s):
                 calls.append(count)
                 return allreduce(ptr, count, s)
-        x = sdo.train(xs[rows], x0[rows], None, hog, allreduce=fn, world_size=world, n_train_global=xs.shape[0])
-        return [r.x.copy() for r in sdo.regressors], x, calls
+        if shard:
+            b, g = parallel.make_torch_solve_collectives(local)
+            coll = (lambda *a: (shard_calls.append("b"), b(*a))[1], lambda *a: (shard_calls.append("g"), g(*a))[1])
+        x = sdo.train(xs[rows], x0[rows], None, hog, allreduce=fn, world_size=world, n_train_global=xs.shape[0],
+                      rank=rank if shard else None, solve_collectives=coll)
+        return [r.x.copy() for r in sdo.regressors], x, (shard_calls if shard else calls)
 
     R_dist, x_dist, calls = train(parallel.make_torch_allreduce(local), slice(ra, rb))
     assert len(calls) == len(params) and all(c > 0 for c in calls), calls      # one exchange per cascade level
+    # the same with the factorisation sharded over the ranks (dist.broadcast / dist.all_gather_into_tensor on the engine's
+    # stream): bit-identical regressors for any world size
+    R_shard, x_shard, scalls = train(parallel.make_torch_allreduce(local), slice(ra, rb), shard=True)
+    tiles = -(-R_dist[0].shape[0] // 128)
+    assert scalls.count("b") == len(params) * tiles and scalls.count("g") == len(params) * -(-tiles // 4), len(scalls)
+    for a, b in zip(R_shard, R_dist):
+        assert np.array_equal(a, b), float(np.abs(a - b).max())
+    assert np.array_equal(x_shard, x_dist)
     if world == 1:
         R_solo, x_solo, _ = train(None, slice(0, xs.shape[0]))
         for a, b in zip(R_dist, R_solo):

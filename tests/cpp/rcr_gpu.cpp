@@ -92,6 +92,11 @@ int main(int argc, char** argv)
             static size_t floats = 0;
             auto fn = [](void*, size_t count, void*, void*) -> int { ++exchanges; floats = count; return 0; };
             hip::set_data_parallel(fn, nullptr, 1, N);
+            // ... and the factorisation sharded over the (one) rank: the two collectives are identities but must be called --
+            // one broadcast per 128-column step, one all-gather per group of four -- and the regressors must not change
+            static int bcasts = 0, gathers = 0;
+            hip::set_solve_sharding(0, [](void*, size_t, int root, void*, void*) -> int { ++bcasts; return root == 0 ? 0 : 1; },
+                                    [](const void*, void*, size_t, void*, void*) -> int { ++gathers; return 0; });   // (a rank's own tiles are already in place)
             std::vector<LR> regs2;
             for (int l = 0; l < n_levels; ++l)
                 regs2.emplace_back(LR(Regulariser(reg_type ? Regulariser::RegularisationType::MatrixNorm : Regulariser::RegularisationType::Manual,
@@ -100,6 +105,8 @@ int main(int argc, char** argv)
             m2.train(xstar, x0, Mat(), hog);
             hip::clear_data_parallel();
             if (exchanges != n_levels || floats == 0) throw std::runtime_error("data-parallel hook: exchange not called once per level");
+            if (bcasts == 0 || gathers == 0 || bcasts < 4 * gathers - 3 * n_levels || bcasts > 4 * gathers)
+                throw std::runtime_error("data-parallel hook: the sharded factorisation did not run its collectives");
             for (int l = 0; l < n_levels; ++l)
                 if (cv::norm(m2.get_regressors()[l].x, model.get_regressors()[l].x, cv::NORM_L2) != 0.0)
                     throw std::runtime_error("data-parallel hook changed the regressors");

@@ -47,4 +47,4 @@ def test_bench_under_torchrun(built):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == n and out["value"] > 0 and out["scaling"] == "weak"
-    assert "RCCL" in out["train"]["collective"]
+    assert "RCCL" in out["train"]["collective"] and out["train"]["solve"].startswith("sharded")

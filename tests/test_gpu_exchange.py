@@ -186,6 +186,20 @@ def test_native_rccl_allreduce_world_of_one(built):
     _lib.check(_lib.lib().sdm_set_allreduce_rccl(ctx._h, comm, None, 1))
     ctx.hog_features(0); ctx.gram_rhs(0); ctx.allreduce_gram_rhs(); ctx.synchronize()
     _lib.check(_lib.lib().sdm_set_allreduce_rccl(ctx._h, None, None, 1))      # uninstall
+    # the sharded factorisation through RCCL (sdm_set_solve_sharding_rccl): ncclBroadcast per 128-column step and ncclAllGather
+    # per panel group, called by the library on its stream.  One rank owns every tile column, so the collectives are
+    # identities -- but they are really issued (handed over by address, then found by name), and the result must not change
+    for fns in ((ctypes.cast(rccl.ncclBroadcast, ctypes.c_void_p), ctypes.cast(rccl.ncclAllGather, ctypes.c_void_p)), (None, None)):
+        ctx.set_solve_sharding_rccl(comm, 0, 1, *fns)
+        ctx.set_x(x0)
+        for level in range(len(params)):
+            ctx.hog_features(level)
+            ctx.gram_rhs(level)
+            R, lam = ctx.solve(level, reg[0], reg[1], reg[2], n_train_global=0)
+            assert np.array_equal(R.view(np.uint32), ref_regs[level][0].view(np.uint32)) and lam == ref_regs[level][1]
+            ctx.apply(level)
+        assert np.array_equal(ctx.get_x().view(np.uint32), ref_x.view(np.uint32))
+    ctx.set_solve_sharding_rccl(None)
     ctx.close()
     ctx_probe.close()
     assert rccl.ncclCommDestroy(comm) == 0
