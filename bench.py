@@ -102,8 +102,10 @@ def main():
     sdo = SupervisedDescentOptimiser([LinearRegressor(reg()) for _ in params], device=local_rank, stream=stream)
     hog = HogTransform(timg, params, ids, ibug.RIGHT_EYE_IDS, ibug.LEFT_EYE_IDS, tidx)
     allreduce = parallel.make_torch_allreduce(local_rank) if use_dist else None
-    # the summed system is factored by all ranks together (tile-column ownership) unless SDM_BENCH_REPLICATED_SOLVE=1
-    shard_solve = use_dist and os.environ.get("SDM_BENCH_REPLICATED_SOLVE", "0") != "1"
+    # SDM_BENCH_SHARD_SOLVE=1: the summed system is factored by all ranks together (tile-column ownership).  Off by
+    # default: at the bench's F = 8 801 the factorisation is bound by its chain of 69 single-workgroup panel steps, which
+    # sharding does not shorten (profiles/r02_sharded_solve_timing.json); it pays at F = 27 201 (RCR-68)
+    shard_solve = use_dist and os.environ.get("SDM_BENCH_SHARD_SOLVE", "0") == "1"
     solve_collectives = parallel.make_torch_solve_collectives(local_rank) if shard_solve else None
     nlsr = []
     train_wall = []

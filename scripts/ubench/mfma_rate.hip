@@ -40,11 +40,10 @@ __global__ void __launch_bounds__(256) k(float* out, unsigned long long* clk, in
     out[blockIdx.x * 256 + threadIdx.x] = s;
     if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
 }
-template <int NACC, int MODE> static void run(const char* name, int wgs)
+template <int NACC, int MODE> static void run(const char* name, int wgs, int iters = 2000)
 {
     float* out; unsigned long long* clk; hipMalloc(&out, (size_t)wgs * 256 * 4); hipMalloc(&clk, 16);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    const int iters = 2000;
     k<NACC, MODE><<<wgs, 256>>>(out, clk, iters); hipDeviceSynchronize();
     hipEventRecord(a); k<NACC, MODE><<<wgs, 256>>>(out, clk, iters); hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
@@ -64,5 +63,8 @@ int main()
     run<3, 1>("+ 4 ds_read_b128 per 12 MFMAs", 512);
     run<6, 1>("+ reads, 6 accumulators", 512);
     run<3, 2>("+ reads + barrier per 48 MFMAs", 512);
+    // sustained: ~70 ms launches, the length of the Gram launch of training (does the clock hold?)
+    run<3, 0>("MFMA only, 3 accumulators, 55x longer", 512, 110000);
+    run<3, 2>("+ reads + barrier, 55x longer", 512, 110000);
     return 0;
 }

@@ -191,26 +191,34 @@ syrk_tn_glds_kernel(const float* __restrict__ A, long long lda, int rows, float*
     const int nslabs = rows / SYRK_GBK;
     constexpr int chunk = SYRK_CHUNK * SYRK_BK / SYRK_GBK;      // slabs per 256-row chunk
     issue(0, 0);
-    for (int s = 0; s < nslabs; ++s) {
-        __syncthreads();                 // slab s has landed (the barrier drains the LDS-direct loads); buffer (s+1)%2 is free
-        if (s + 1 < nslabs) issue(s + 1, (s + 1) & 1);
-        const float (*As)[TILE] = (const float (*)[TILE])(glds + (size_t)(s & 1) * 2 * SYRK_GBK * TILE);
-        const float (*Bp)[TILE] = diag ? As : (const float (*)[TILE])(glds + (size_t)(s & 1) * 2 * SYRK_GBK * TILE + SYRK_GBK * TILE);
+    // Two nested loops, not one loop with an "every 8th slab" branch: inside the inner loop the accumulators are touched by
+    // MFMAs only and stay in the accumulation registers; with the branch the compiler kept them in VGPRs across the back-edge
+    // and copied all 64 of them to the AGPRs and back around the MFMAs of EVERY slab (128 v_accvgpr moves + a drain of the
+    // matrix pipeline per 64 MFMAs: 9 % of the Gram launch, found with a loads-only / compute-only ablation in round 2).
+    const int step = CHUNKED ? chunk : nslabs;
+    for (int c0 = 0; c0 < nslabs; c0 += step) {
+        const int c1 = c0 + step < nslabs ? c0 + step : nslabs;
+        for (int s = c0; s < c1; ++s) {
+            __syncthreads();                 // slab s has landed (the barrier drains the LDS-direct loads); buffer (s+1)%2 is free
+            if (s + 1 < nslabs) issue(s + 1, (s + 1) & 1);
+            const float (*As)[TILE] = (const float (*)[TILE])(glds + (size_t)(s & 1) * 2 * SYRK_GBK * TILE);
+            const float (*Bp)[TILE] = diag ? As : (const float (*)[TILE])(glds + (size_t)(s & 1) * 2 * SYRK_GBK * TILE + SYRK_GBK * TILE);
 #pragma unroll
-        for (int kk = 0; kk < SYRK_GBK; kk += 2) {
-            const int k = kk + (lane >> 5);
-            float a[2], b[2];
+            for (int kk = 0; kk < SYRK_GBK; kk += 2) {
+                const int k = kk + (lane >> 5);
+                float a[2], b[2];
 #pragma unroll
-            for (int m = 0; m < 2; ++m) a[m] = As[k][wr * 64 + m * 32 + (lane & 31)];
+                for (int m = 0; m < 2; ++m) a[m] = As[k][wr * 64 + m * 32 + (lane & 31)];
 #pragma unroll
-            for (int n = 0; n < 2; ++n) b[n] = Bp[k][wc * 64 + n * 32 + (lane & 31)];
+                for (int n = 0; n < 2; ++n) b[n] = Bp[k][wc * 64 + n * 32 + (lane & 31)];
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
+                    for (int n = 0; n < 2; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
+            }
         }
-        if (CHUNKED && ((s + 1) % chunk == 0 || s + 1 == nslabs)) {
+        if (CHUNKED) {   // fold the chunk
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll

@@ -19,8 +19,8 @@ def _free_port():
     return p
 
 
-def _torchrun(nproc, script, *args, timeout=600):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _torchrun(nproc, script, *args, timeout=600, **extra_env):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), script, *args]
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
@@ -42,7 +42,7 @@ def test_bench_under_torchrun(built):
     import torch
     n = min(torch.cuda.device_count(), 2)
     r = _torchrun(n, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--batch", "256",
-                  "--train-rows", "800", "--no-cpu")
+                  "--train-rows", "800", "--no-cpu", SDM_BENCH_SHARD_SOLVE="1")
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
