@@ -13,6 +13,8 @@ from superviseddescent_amd import Context, HoGParam, ibug, synth  # noqa: E402
 
 def main():
     rows = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+    hp = tuple(float(v) for v in sys.argv[2].split(",")) if len(sys.argv) > 2 else ibug.SHIPPED_HOG_PARAMS[0]
+    hp = (int(hp[0]), int(hp[1]), int(hp[2]), int(hp[3]), float(hp[4]))
     ids = ibug.RCR22_IDS
     re, le = ibug.eye_indices(ids)
     images, boxes, gt = synth.make_faces(256, seed=1)
@@ -20,7 +22,7 @@ def main():
     x_star, x0, idx = synth.make_samples(boxes, gt, ids, n_perturb=per - 1, seed=2)
     x_star, x0, idx = x_star[:rows], x0[:rows], idx[:rows]
     ctx = Context(0)
-    ctx.set_model_geometry(len(ids), re, le, [HoGParam(*ibug.SHIPPED_HOG_PARAMS[0])])
+    ctx.set_model_geometry(len(ids), re, le, [HoGParam(*hp)])
     ctx.upload_images(images)
     ctx.set_sample_image_index(idx)
     ctx.set_x(x0)
@@ -33,7 +35,7 @@ def main():
         ctx.gram_rhs(0)
         ctx.synchronize()
         best = min(best, ctx.get_timing(reset=True)["gram"][0])
-    F = 8801
+    F = len(ids) * hp[1] ** 2 * (3 * hp[3] + 4) + 1
     T = -(-F // 128)
     useful = 2.0 * rows * F * (F + 1) / 2 + 2.0 * rows * F * 44
     executed = 2.0 * rows * 128 * 128 * (T * (T + 1) / 2 + T)
