@@ -384,41 +384,68 @@ __device__ inline void st16(float* p, const float (&v)[IB])
     for (int q = 0; q < IB / 4; ++q) *(f32x4s*)(p + 4 * q) = (f32x4s){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
 }
 
-// ---- Cholesky of one diagonal tile (upper: G_kk = U^T U).  512 threads: thread (q, c) = (t / 128, t % 128) works on
-//      column c; the diagonal-block factor and the panel solve are done by the q == 0 thread of a column, the
-//      rank-16 trailing update of the column is split row-cyclically over its four threads -------------------------
+// Lanes of ONE wave exchanging data through LDS: the hardware executes a wave's LDS instructions in order, but the compiler
+// reasons per thread (it may forward a thread's own earlier store to its later load of the same address, past another lane's
+// store in between): a wavefront-scope release / acquire pair makes the exchange visible to it.  No workgroup barrier.
+__device__ inline void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- Cholesky of one diagonal tile (upper: G_kk = U^T U) ---------------------------------------------------------------
+// One workgroup of 8 waves; the upper triangle is 36 tiles of 16 x 16 and never leaves the registers: wave w owns the tiles
+// (rb, w), rb <= w, of block column w as matrix-core accumulators.  Per 16-wide step j:
+//   (a) wave j factors its diagonal tile -- one lane per column, pivots and the scaled pivot row travel through v_readlane;
+//   (b) every wave w > j solves its tile (j, w) against that factor (one lane per column, coefficients broadcast from LDS)
+//       and publishes it as a panel row block in LDS;
+//   (c) every wave w > j applies the rank-16 update to its tiles (rb, w), j < rb <= w, with v_mfma_f32_16x16x4_f32 (operands
+//       straight from the panel).
+// Two barriers per step, 64 KB less LDS than the version that kept the working tile there, and the trailing update -- the
+// only part with flops -- no longer walks LDS element by element: 50 -> 27 us per tile, on the chain of every 128-column step.
+// An accumulator tile is turned into "one column per lane" (and back) through 1 KB of wave-private LDS.
 #define PQ 4
+#define POTRF_PLD (TILE + 16)     // row stride of the panel in LDS (fragment reads of two 16-column halves: disjoint banks)
 __global__ void __launch_bounds__(TILE * PQ)
 potrf_tile_kernel(float* __restrict__ G, long long ldg, int k0, int* __restrict__ status)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* T = sm;                    // [128][128] working tile, row-major (upper triangle is data)
-    float* P = sm + TILE * TILE;      // [128][16]  current panel, transposed: P[c][m] = U[j0+m][c]
-    float* Dt = P + TILE * IB;        // [16][16]   factor of the current diagonal block, transposed: Dt[i][q] = U[j0+q][j0+i]
-    float* badf = Dt + IB * IB;       // "not positive definite" flag (all LDS of this kernel is dynamic)
-    const int t = threadIdx.x, c = t & (TILE - 1), q = t >> 7;
+    float* P = sm;                               // [16][POTRF_PLD]  current panel: P[m][c] = U[j0 + m][c]
+    float* Dt = P + IB * POTRF_PLD;              // [16][16]         factor of the current diagonal block, transposed: Dt[i][q] = U[j0+q][j0+i]
+    float* badf = Dt + IB * IB;                  // "not positive definite" flag
+    float* scratch = badf + 4;                   // [8 waves][16][17]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 15, lq = lane >> 4;
     float* Gk = G + (long long)k0 * ldg + k0;
+    float* S = scratch + wave * IB * (IB + 1);
     if (t == 0) *badf = 0.0f;
-    const int lr = t >> 5, lc = (t & 31) * 4;   // 16-byte loads: thread t takes 4 columns of rows t/32 + 16*pass
-#pragma unroll 8
-    for (int r = lr; r < TILE; r += 16) *(f32x4s*)(T + r * TILE + lc) = *(const f32x4s*)(Gk + (long long)r * ldg + lc);
+    // this wave's tiles in C/D layout: acc[rb][e] = T[16 rb + 4 lq + e][16 wave + li], rb <= wave
+    f32x4 acc[NIB];
+#pragma unroll
+    for (int rb = 0; rb < NIB; ++rb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            acc[rb][e] = rb <= wave ? Gk[(long long)(IB * rb + 4 * lq + e) * ldg + IB * wave + li] : 0.0f;
     __syncthreads();
-
+#pragma unroll
     for (int jb = 0; jb < NIB; ++jb) {
-        const int j0 = jb * IB;
-        // (a) 16 x 16 diagonal block: lane i of the first wave owns its column i in registers; pivots and the scaled
-        //     pivot row travel through v_readlane (no LDS round trips, no barriers)
-        if (t < 64) {
-            const int i = t & 15;
+        // (a) the diagonal tile: accumulator layout -> lane i holds column i -> factor -> Dt (for the others) and back
+        if (wave == jb) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) S[(4 * lq + e) * (IB + 1) + li] = acc[jb][e];
+            wave_lds_sync();
             float d[IB];
 #pragma unroll
-            for (int r = 0; r < IB; ++r) d[r] = T[(j0 + r) * TILE + j0 + i];
+            for (int r = 0; r < IB; ++r) d[r] = S[r * (IB + 1) + li];
+            wave_lds_sync();
+            bool bad = false;
 #pragma unroll
             for (int s_ = 0; s_ < IB; ++s_) {
                 const float piv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d[s_]), s_));
                 const float sd = sqrtf(piv);
-                if (!(piv > 0.0f)) *badf = 1.0f;
-                const float u = (i == s_) ? sd : d[s_] / sd;          // U[s][i] for i >= s
+                bad = bad || !(piv > 0.0f);
+                const float u = (li == s_) ? sd : d[s_] / sd;          // U[s][i] for i >= s
                 d[s_] = u;
 #pragma unroll
                 for (int r = s_ + 1; r < IB; ++r) {
@@ -426,13 +453,18 @@ potrf_tile_kernel(float* __restrict__ G, long long ldg, int k0, int* __restrict_
                     d[r] -= ur * u;                                   // meaningful for i >= r
                 }
             }
-            if (t < IB) {
+            if (bad && lane == 0) *badf = 1.0f;
+            if (lane < IB) {
 #pragma unroll
                 for (int r = 0; r < IB; ++r) {
-                    T[(j0 + r) * TILE + j0 + i] = (i >= r) ? d[r] : 0.0f;
-                    Dt[i * IB + r] = (i >= r) ? d[r] : 0.0f;
+                    const float v = (li >= r) ? d[r] : 0.0f;
+                    Dt[li * IB + r] = v;
+                    S[r * (IB + 1) + li] = v;
                 }
             }
+            wave_lds_sync();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[jb][e] = S[(4 * lq + e) * (IB + 1) + li];
         }
         __syncthreads();
         if (*badf != 0.0f) {
@@ -440,49 +472,61 @@ potrf_tile_kernel(float* __restrict__ G, long long ldg, int k0, int* __restrict_
             if (t == 0) { atomicOr(status, 2); Gk[0] = __builtin_nanf(""); }
             return;
         }
-        // (b) panel: column c right of the block: U[j0+m][c] = (T[j0+m][c] - sum_{p<m} U[j0+p][j0+m] U[j0+p][c]) / U[j0+m][j0+m]
-        const bool right = c >= j0 + IB;
-        if (right && q == 0) {
+        if (jb + 1 == NIB) break;
+        // (b) panel: tile (jb, wave) for wave > jb: U[j0+m][c] = (T[j0+m][c] - sum_{p<m} U[j0+p][j0+m] U[j0+p][c]) / U[j0+m][j0+m]
+        if (wave > jb) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) S[(4 * lq + e) * (IB + 1) + li] = acc[jb][e];
+            wave_lds_sync();
             float y[IB];
 #pragma unroll
-            for (int m = 0; m < IB; ++m) y[m] = T[(j0 + m) * TILE + c];
+            for (int m = 0; m < IB; ++m) y[m] = S[m * (IB + 1) + li];
+            wave_lds_sync();
 #pragma unroll
             for (int m = 0; m < IB; ++m) {
                 float dcol[IB];
                 ld16(Dt + m * IB, dcol);                              // U[j0+p][j0+m], p = 0..15
-                float acc = y[m];
+                float a_ = y[m];
 #pragma unroll
-                for (int p = 0; p < m; ++p) acc -= dcol[p] * y[p];
-                y[m] = acc / dcol[m];
+                for (int p_ = 0; p_ < m; ++p_) a_ -= dcol[p_] * y[p_];
+                y[m] = a_ / dcol[m];
             }
+            if (lane < IB) {
 #pragma unroll
-            for (int m = 0; m < IB; ++m) T[(j0 + m) * TILE + c] = y[m];
-            st16(P + c * IB, y);
+                for (int m = 0; m < IB; ++m) {
+                    S[m * (IB + 1) + li] = y[m];
+                    P[m * POTRF_PLD + IB * wave + li] = y[m];
+                }
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[jb][e] = S[(4 * lq + e) * (IB + 1) + li];
         }
         __syncthreads();
-        // (c) trailing update of column c: T[r][c] -= sum_m U[j0+m][r] U[j0+m][c],  j0+16 <= r <= c, rows r = q mod 4
-        if (right) {
-            float y[IB];
-            ld16(P + c * IB, y);
-#pragma unroll 2
-            for (int r = j0 + IB + q; r <= c; r += PQ) {
-                float pr[IB];
-                ld16(P + r * IB, pr);
-                float acc0 = T[r * TILE + c], acc1 = 0.0f;
+        // (c) trailing update of this wave's tiles (rb, wave), jb < rb <= wave: T -= P_rb^T P_wave
+        if (wave > jb) {
+            float bop[4];
 #pragma unroll
-                for (int m = 0; m < IB; m += 2) { acc0 -= pr[m] * y[m]; acc1 -= pr[m + 1] * y[m + 1]; }
-                T[r * TILE + c] = acc0 + acc1;
-            }
+            for (int s_ = 0; s_ < 4; ++s_) bop[s_] = -P[(4 * s_ + lq) * POTRF_PLD + IB * wave + li];
+#pragma unroll
+            for (int rb = jb + 1; rb < NIB; ++rb)
+                if (rb <= wave) {
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_)
+                        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(P[(4 * s_ + lq) * POTRF_PLD + IB * rb + li], bop[s_], acc[rb], 0, 0, 0);
+                }
         }
-        __syncthreads();
+        // (the next step's (a) touches only its own wave's registers and scratch; P is rewritten after the next barrier)
     }
-#pragma unroll 8
-    for (int r = lr; r < TILE; r += 16) {
-        f32x4s v = *(const f32x4s*)(T + r * TILE + lc);
-        v[0] = (lc + 0 >= r) ? v[0] : 0.0f; v[1] = (lc + 1 >= r) ? v[1] : 0.0f;
-        v[2] = (lc + 2 >= r) ? v[2] : 0.0f; v[3] = (lc + 3 >= r) ? v[3] : 0.0f;
-        *(f32x4s*)(Gk + (long long)r * ldg + lc) = v;     // strict lower part becomes zero
-    }
+    // store: the upper triangle from the accumulators, zeros below the diagonal (mirror tiles included)
+#pragma unroll
+    for (int rb = 0; rb < NIB; ++rb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = IB * rb + 4 * lq + e, c = IB * wave + li;
+            if (rb <= wave) Gk[(long long)r * ldg + c] = (c >= r) ? acc[rb][e] : 0.0f;
+            else Gk[(long long)r * ldg + c] = 0.0f;
+        }
 }
 
 // ---- panel solve: G[k0:k0+128, tj*128 : +128] <- U_kk^-T * (same), on the matrix cores --------------------------------
@@ -549,6 +593,7 @@ trsm_tile_kernel(float* __restrict__ G, long long ldg, int k0, int tile_j0, int 
         // B_j (accumulator layout) -> B operand: k-step s needs rows 4 s + lq
 #pragma unroll
         for (int e = 0; e < 4; ++e) S[(4 * lq + e) * (IB + 1) + li] = acc[jb][e];
+        wave_lds_sync();
         float bop[4], aop[4];
 #pragma unroll
         for (int s_ = 0; s_ < 4; ++s_) {
@@ -560,10 +605,13 @@ trsm_tile_kernel(float* __restrict__ G, long long ldg, int k0, int tile_j0, int 
         for (int s_ = 0; s_ < 4; ++s_) y = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[s_], bop[s_], y, 0, 0, 0);
         acc[jb] = y;
         if (jb + 1 < NIB) {
+            wave_lds_sync();          // (the reads of B_j above are done before the slot is rewritten)
 #pragma unroll
             for (int e = 0; e < 4; ++e) S[(4 * lq + e) * (IB + 1) + li] = y[e];
+            wave_lds_sync();
 #pragma unroll
             for (int s_ = 0; s_ < 4; ++s_) bop[s_] = -S[(4 * s_ + lq) * (IB + 1) + li];
+            wave_lds_sync();
             // B_r -= L_rj Y_j:  A[row li][k] = L[16 rb + li][j0 + k] = U[j0 + k][16 rb + li]
 #pragma unroll
             for (int rb = jb + 1; rb < NIB; ++rb)
@@ -791,7 +839,7 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
     const int Tf = (F + TILE - 1) / TILE;          // factor tiles
     const int ncols = rhs0 + TILE * ((nrhs + TILE - 1) / TILE);   // factor tiles + one or two RHS tile columns
     const int T = ncols / TILE;
-    const size_t lds_potrf = ((size_t)TILE * TILE + TILE * IB + IB * IB + 4) * sizeof(float);
+    const size_t lds_potrf = ((size_t)IB * POTRF_PLD + IB * IB + 4 + 8 * IB * (IB + 1)) * sizeof(float);
     const size_t lds_trsm = ((size_t)TILE * TRSM_LD + NIB * IB * IB + 8 * IB * (IB + 1)) * sizeof(float);
     static unsigned long long attr_seen = 0;
     if (sdm_first_use_on_device(attr_seen)) {

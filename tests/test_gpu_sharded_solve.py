@@ -117,7 +117,7 @@ CASES = {
     # name: (landmark ids, one HoG level, regulariser)           F, factor tiles, RHS tiles
     "rcr22_25_tiles": (ibug.RCR22_IDS, (1, 3, 12, 4, 0.9), (1, 1.5, False)),        # 3169, 25, 1: look-ahead path (> 8 tiles)
     "rcr68_two_rhs_tiles": (ibug.IBUG68_IDS, (1, 2, 14, 4, 0.8), (0, 25.0, True)),  # 4353, 35, 2
-    "rcr22_7_tiles": (ibug.RCR22_IDS, (1, 1, 24, 6, 0.8), (0, 1.0, True)),          # 22*22+1 = 485 ... 4 tiles: no look-ahead
+    "rcr22_4_tiles": (ibug.RCR22_IDS, (1, 1, 24, 6, 0.8), (0, 1.0, True)),          # 22*22+1 = 485, 4 tiles: no look-ahead
 }
 
 

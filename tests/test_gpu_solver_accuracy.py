@@ -1,0 +1,25 @@
+"""The blocked Cholesky behind sdm_solve / sdm_solve_normal_equations (csrc/sdm_solve.hip: potrf_tile_kernel with the tile in
+matrix-core accumulators, trsm_tile_kernel with inverted 16 x 16 diagonal blocks, MFMA substitutions) against an f64 solve of
+the same normal equations (regressors.hpp:199-234), over sizes that exercise partial tiles, one tile, several tiles and the
+two-queue look-ahead (> 8 tiles).  Well-conditioned systems: the tolerance is a few f32 ulps of the solution's scale."""
+import numpy as np
+import pytest
+
+from superviseddescent_amd import Context
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("F", [1, 7, 16, 40, 100, 128, 129, 200, 300, 640, 1300])
+def test_normal_equations_match_f64(built, F):
+    rng = np.random.default_rng(F)
+    N = max(2 * F, 500)
+    A = rng.standard_normal((N, F)).astype(np.float32)
+    b = rng.standard_normal((N, 5)).astype(np.float32)
+    ctx = Context(0)
+    R, lam = ctx.solve_normal_equations(A, b, 0, 1.0, True)
+    ctx.close()
+    assert lam == 1.0
+    G = A.astype(np.float64).T @ A.astype(np.float64) + np.eye(F)
+    want = np.linalg.solve(G, A.astype(np.float64).T @ b.astype(np.float64))
+    assert np.abs(R - want).max() <= 3e-6 * np.abs(want).max()
