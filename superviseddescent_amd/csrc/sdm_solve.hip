@@ -403,7 +403,8 @@ __device__ inline void wave_lds_sync()
 //   (c) every wave w > j applies the rank-16 update to its tiles (rb, w), j < rb <= w, with v_mfma_f32_16x16x4_f32 (operands
 //       straight from the panel).
 // Two barriers per step, 64 KB less LDS than the version that kept the working tile there, and the trailing update -- the
-// only part with flops -- no longer walks LDS element by element: 50 -> 27 us per tile, on the chain of every 128-column step.
+// only part with flops -- no longer walks LDS element by element: 50 -> 38.5 us per tile, on the chain of every 128-column step
+// (what remains is the serial 16 x 16 factor of (a): 16 pivots x (sqrt, divide, 15 v_readlane + FMA), eight times).
 // An accumulator tile is turned into "one column per lane" (and back) through 1 KB of wave-private LDS.
 #define PQ 4
 #define POTRF_PLD (TILE + 16)     // row stride of the panel in LDS (fragment reads of two 16-column halves: disjoint banks)
@@ -536,8 +537,8 @@ potrf_tile_kernel(float* __restrict__ G, long long ldg, int k0, int* __restrict_
 // Both products of a step are v_mfma_f32_16x16x4_f32: the 16 x 16 triangular solve becomes a product with the inverse of
 // the diagonal block D_j (the workgroup's first 128 threads invert the eight blocks once, 136 dependent FMAs each, as the
 // blocked solvers of the GPU linear-algebra libraries do), the update a (112 - 16 j) x 16 x 16 product with L from LDS.
-// Turning an accumulator tile into a B operand is a trip through 1 KB of wave-private LDS.  12 us per tile (the scalar
-// substitution it replaces: 38 us), and the panel solve is on the chain every 128-column step waits for.
+// Turning an accumulator tile into a B operand is a trip through 1 KB of wave-private LDS.  13.7 us per tile (the scalar
+// substitution it replaces: 37.6 us), and the panel solve is on the chain every 128-column step waits for.
 // The extra last workgroup solves for the identity instead and stores U_kk^-T into winv_t: the back substitution then
 // needs only products, no serial solves.
 #define TRSM_LD (TILE + 16)        // row stride of U in LDS: the two 16-column halves a fragment read touches land on disjoint banks
