@@ -652,6 +652,14 @@ backsolve_step_kernel(float* __restrict__ G, long long ldg, int k0, int rhs0, co
     const bool last = (int)blockIdx.x == k;
     const int lr = t >> 5, lc = (t & 31) * 4;
     const float* Yg = G + (long long)k0 * ldg + rhs0;
+    // U_ik of the second product is fetched now, into registers: its memory round trip runs under the first product
+    const long long i0 = (long long)blockIdx.x * TILE;
+    const float* Uik = G + i0 * ldg + k0;
+    f32x4s upre[TILE / 8];
+    if (!last) {
+#pragma unroll
+        for (int q = 0; q < TILE / 8; ++q) upre[q] = *(const f32x4s*)(Uik + (long long)(lr + 8 * q) * ldg + lc);
+    }
     for (int r = lr; r < TILE; r += 8) *(f32x4s*)(A + r * (TILE + 4) + lc) = *(const f32x4s*)(winv_t + r * TILE + lc);
     for (int idx = t; idx < TILE * nrhs; idx += 256) {
         const int r = idx / nrhs, cc = idx - r * nrhs;     // nrhs is a compile-time constant here
@@ -691,10 +699,9 @@ backsolve_step_kernel(float* __restrict__ G, long long ldg, int k0, int rhs0, co
     if (last) return;
     __syncthreads();
     // Y_i -= U_ik * R_k
-    const long long i0 = (long long)blockIdx.x * TILE;
-    const float* Uik = G + i0 * ldg + k0;
     float* Yi = G + i0 * ldg + rhs0;
-    for (int r = lr; r < TILE; r += 8) *(f32x4s*)(A + r * (TILE + 4) + lc) = *(const f32x4s*)(Uik + (long long)r * ldg + lc);
+#pragma unroll
+    for (int q = 0; q < TILE / 8; ++q) *(f32x4s*)(A + (lr + 8 * q) * (TILE + 4) + lc) = upre[q];
     __syncthreads();
 #pragma unroll
     for (int a = 0; a < 2; ++a)
