@@ -652,10 +652,6 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
     }
     const float row_w1 = wx1, row_w2 = wx2;   // weights of coordinate d when it is used as a ROW
     const int row_cell = bxc;
-    // ACC_COLUMNS: row d feeds the cell rows (bands) bxc and bxc + 1; band b lives in slot b & 1.  The bands -1 and C do
-    // not exist (hog.c:713-724 bounds checks): their weight is 0.
-    const float row_wlo = bxc >= 0 ? wx1 : 0.0f, row_whi = bxc + 1 <= C - 1 ? wx2 : 0.0f;
-    const float row_ws0 = (bxc & 1) ? row_whi : row_wlo, row_ws1 = (bxc & 1) ? row_wlo : row_whi;
     const bool col_active = (col >= 1) && (col < S - 1) && (!PAIR || half == 0 || second_valid);
     // padded histogram column of this lane (lanes outside the ROI contribute exact zeros to cell 0)
     const int hcol = col_active ? bxc + 1 : 0;

@@ -165,3 +165,32 @@ def test_sharded_failure_is_seen_by_every_rank(built):
     ref.close()
     out, errors, _ = solve_sharded(3, make_ctx, reg)
     assert all(isinstance(e, SdmError) for e in errors), errors
+
+
+def test_sharding_registration_is_validated_and_collective_failures_surface(built):
+    ids, hp, reg = CASES["rcr22_4_tiles"]
+    images, boxes, gt = synth.make_faces(32, seed=519)
+    x_star, x0, idx = synth.make_samples(boxes, gt, ids, n_perturb=2, seed=520)
+    ctx = prepared_context(images, idx, x_star, x0, ids, [hp])
+    ok = lambda *a: 0
+    with pytest.raises(SdmError, match="0 <= rank < world_size"):
+        ctx.set_solve_sharding(2, 2, ok, ok)
+    with pytest.raises(SdmError, match="0 <= rank < world_size"):
+        ctx.set_solve_sharding(-1, 2, ok, ok)
+    # a broadcast that reports failure aborts the solve with a communication error, it is not swallowed
+    ctx.set_solve_sharding(0, 1, lambda *a: 7, ok)
+    with pytest.raises(SdmError, match="collective failed with status 7"):
+        ctx.solve(0, reg[0], reg[1], reg[2], n_train_global=0)
+    # a Python exception inside a callback never crosses the C boundary: it becomes a failure status
+    def boom(*a):
+        raise RuntimeError("transport down")
+    ctx.gram_rhs(0)
+    ctx.set_solve_sharding(0, 1, ok, boom)
+    with pytest.raises(SdmError, match="collective failed"):
+        ctx.solve(0, reg[0], reg[1], reg[2], n_train_global=0)
+    # uninstalling restores the replicated solve
+    ctx.gram_rhs(0)
+    ctx.set_solve_sharding(0, 0, None, None)
+    R, lam = ctx.solve(0, reg[0], reg[1], reg[2], n_train_global=0)
+    assert np.isfinite(R).all() and lam == reg[1]
+    ctx.close()
