@@ -1069,12 +1069,23 @@ __host__ __device__ inline size_t packed_lds_bytes(int C, int O, int S, int hist
     return al16(HP_ROWS_BYTES(O)) + packed_rowtab_bytes(S) + hist_slots * al16(HP_HIST_BYTES(O, C * C)) + (HP_OVERLAY ? 0 : packed_scratch_bytes(C, O));
 }
 
+// arithmetic type of the packed kernel's normalisation (hog.c:930-1052 computes the block factors and the clamped products in
+// double and stores floats).  In float -- v_rsq_f32 for 1 / sqrt, f32 products -- the features differ from the oracle exactly as
+// much as before (max 1.8e-7, relative L2 7.5e-8 -> 8.0e-8 over 128 faces x 4 levels, scripts/feature_error.py: the separable
+// column sums dominate), and the kernel is 3.7 % faster.  The one-patch-per-wave kernels and the exact modes keep the double path.
+#ifndef HP_FT
+#define HP_FT float
+#endif
+__device__ inline double ft_rsqrt(double v) { return 1.0 / sqrt(v); }
+__device__ inline float ft_rsqrt(float v) { return __builtin_amdgcn_rsqf(v); }
+__device__ inline double ft_min02(double v) { return __builtin_fmin(0.2, v); }
+__device__ inline float ft_min02(float v) { return __builtin_fminf(0.2f, v); }
 // hog_finish_lean with the descriptor written straight to the feature row (no staging copy: 2 KB less LDS per wave)
 template <int TO, int TC>
 __device__ void hog_finish_direct(const float* hist, unsigned char* scratch, float* __restrict__ out_desc,
                                   const HogLevelDev& lv, int lane)
 {
-    typedef double FT;
+    typedef HP_FT FT;
     constexpr int O = TO, C = TC, CC = C * C, CB = C + 1;
     float* nrm = (float*)scratch;
     FT* fac = (FT*)(scratch + al16((size_t)CC * 4));
@@ -1096,10 +1107,10 @@ __device__ void hog_finish_direct(const float* hist, unsigned char* scratch, flo
         const int ya = byb - 1 > 0 ? byb - 1 : 0, yb = byb < C - 1 ? byb : C - 1;
         const FT na = nrm[xa + ya * C], nb = nrm[xb + ya * C];
         const FT nc = nrm[xa + yb * C], nd = nrm[xb + yb * C];
-        fac[t] = (FT)1.0 / (FT)sqrt(na + nb + nc + nd + (FT)1e-4);
+        fac[t] = ft_rsqrt(na + nb + nc + nd + (FT)1e-4);
     }
     wave_sync();
-#define CL02(v) __builtin_fmin(0.2, (v))
+#define CL02(v) ft_min02(v)
     for (int t = lane; t < O * CC; t += 64) {                   // hog.c:985-1033, Matlab order of adaptive_vlhog.hpp:166-175
         const int k = t / CC, c = t - k * CC;
         const int y = c / C, x = c - y * C, ct = x * C + y;
