@@ -1026,7 +1026,10 @@ int sdm_solve(sdm_ctx* c, int level, int reg_type, float reg_param, int regulari
         }
         const int crc = sdm_launch_cholesky_solve(c->G.p, ncols, F, Fp, Mp, c->Rsol.p, Mp, c->winv.p, c->status.p, c->stream,
                                                   &c->solve_aux, sharded ? &shard : nullptr);
-        if (crc) return fail(SDM_ERR_COMM, "sharded factorisation: a collective failed with status " + std::to_string(crc));
+        if (crc) {
+            c->g_level = -1;      // G is partly factored: sdm_gram_rhs has to run again
+            return fail(SDM_ERR_COMM, "sharded factorisation: a collective failed with status " + std::to_string(crc));
+        }
     }
     HIP_TRY(hipGetLastError());
     // R (Fp x Mp) -> Rt (Mp x ldf, zero padded: the apply GEMM's operand) on the device; the host copy only on request

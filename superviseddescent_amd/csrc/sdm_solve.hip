@@ -413,7 +413,7 @@ potrf_tile_kernel(float* __restrict__ G, long long ldg, int k0, int* __restrict_
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* P = sm;                               // [16][POTRF_PLD]  current panel: P[m][c] = U[j0 + m][c]
-    float* Dt = P + IB * POTRF_PLD;              // [16][16]         factor of the current diagonal block, transposed: Dt[i][q] = U[j0+q][j0+i]
+    float* Dt = P + IB * POTRF_PLD;              // [16][16]         factor of the current diagonal block, transposed: Dt[i][q] = U[j0+q][j0+i], q < i; Dt[i][i] = 1 / U[j0+i][j0+i]
     float* badf = Dt + IB * IB;                  // "not positive definite" flag
     float* scratch = badf + 4;                   // [8 waves][16][17]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -444,9 +444,11 @@ potrf_tile_kernel(float* __restrict__ G, long long ldg, int k0, int* __restrict_
 #pragma unroll
             for (int s_ = 0; s_ < IB; ++s_) {
                 const float piv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d[s_]), s_));
-                const float sd = sqrtf(piv);
+                // (hardware sqrt / reciprocal, <= 1 ulp each: this is the engine's own factor, pinned to nothing bit-wise, and
+                //  the IEEE sequences are a third of the serial pivot step every 128-column step of the solve waits for)
+                const float sd = __builtin_amdgcn_sqrtf(piv);
                 bad = bad || !(piv > 0.0f);
-                const float u = (li == s_) ? sd : d[s_] / sd;          // U[s][i] for i >= s
+                const float u = (li == s_) ? sd : d[s_] * __builtin_amdgcn_rcpf(sd);          // U[s][i] for i >= s
                 d[s_] = u;
 #pragma unroll
                 for (int r = s_ + 1; r < IB; ++r) {
@@ -459,7 +461,7 @@ potrf_tile_kernel(float* __restrict__ G, long long ldg, int k0, int* __restrict_
 #pragma unroll
                 for (int r = 0; r < IB; ++r) {
                     const float v = (li >= r) ? d[r] : 0.0f;
-                    Dt[li * IB + r] = v;
+                    Dt[li * IB + r] = (li == r) ? __builtin_amdgcn_rcpf(v) : v;      // (the panel solve multiplies by the diagonal's reciprocal)
                     S[r * (IB + 1) + li] = v;
                 }
             }
@@ -486,11 +488,11 @@ potrf_tile_kernel(float* __restrict__ G, long long ldg, int k0, int* __restrict_
 #pragma unroll
             for (int m = 0; m < IB; ++m) {
                 float dcol[IB];
-                ld16(Dt + m * IB, dcol);                              // U[j0+p][j0+m], p = 0..15
+                ld16(Dt + m * IB, dcol);                              // U[j0+p][j0+m], p < m; 1 / U[j0+m][j0+m] at p = m
                 float a_ = y[m];
 #pragma unroll
                 for (int p_ = 0; p_ < m; ++p_) a_ -= dcol[p_] * y[p_];
-                y[m] = a_ / dcol[m];
+                y[m] = a_ * dcol[m];
             }
             if (lane < IB) {
 #pragma unroll
@@ -575,13 +577,15 @@ trsm_tile_kernel(float* __restrict__ G, long long ldg, int k0, int tile_j0, int 
     if (t < NIB * IB) {
         // column i of the inverse of the upper triangular block D = U[j0 .. j0+15][j0 .. j0+15]: back substitution for e_i
         const int jb = t >> 4, i = t & 15, j0 = jb * IB;
-        float x[IB];
+        float x[IB], rd[IB];
+#pragma unroll
+        for (int r = 0; r < IB; ++r) rd[r] = __builtin_amdgcn_rcpf(Us[(j0 + r) * TRSM_LD + j0 + r]);      // off the serial chain below
 #pragma unroll
         for (int r = IB - 1; r >= 0; --r) {
             float sacc = (r == i) ? 1.0f : 0.0f;
 #pragma unroll
             for (int m = r + 1; m < IB; ++m) sacc -= Us[(j0 + r) * TRSM_LD + j0 + m] * x[m];     // (x[m] = 0 for m > i)
-            x[r] = (r <= i) ? sacc / Us[(j0 + r) * TRSM_LD + j0 + r] : 0.0f;
+            x[r] = (r <= i) ? sacc * rd[r] : 0.0f;
         }
 #pragma unroll
         for (int r = 0; r < IB; ++r) Dinv[(jb * IB + r) * IB + i] = x[r];
@@ -889,7 +893,7 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
             // tiles (g0 .. k, k): the group's panel rows in column k, then the factored diagonal tile
             if (mine) hipLaunchKernelGGL(tiles_gather_kernel, dim3(1, nb + 1, 1), dim3(256), 0, stream, G, ldg, shard->stage, g0, nb + 1, k, k + 1, 1, 0, 1, 0, -1);
             const int rc = shard->bcast(shard->self, shard->stage, (size_t)(nb + 1) * TILE * TILE, k % W, stream);
-            if (rc) return rc;
+            if (rc) { if (tail_pending) (void)hipStreamWaitEvent(stream, aux->tail_done, 0); return rc; }      // (the caller's stream owns G again)
             if (!mine) {
                 hipLaunchKernelGGL(tiles_gather_kernel, dim3(1, nb + 1, 1), dim3(256), 0, stream, G, ldg, shard->stage, g0, nb + 1, k, k + 1, 1, 0, 1, 1, -1);
                 if (nb) sdm_launch_syrk_tn(G + (long long)g0 * TILE * ldg, ldg, nb * TILE, ncols, G, ldg, -1.0f, 1, k, stream, 1, me, W);
@@ -913,7 +917,7 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
                 float* recv = shard->stage + per_rank;
                 hipLaunchKernelGGL(tiles_gather_kernel, dim3(ncmax, nr, 1), dim3(256), 0, stream, G, ldg, send, g0, nr, k + 1, T, W, me, ncmax, 0, -1);
                 const int rc = shard->allgather(shard->self, send, recv, per_rank, stream);
-                if (rc) return rc;
+                if (rc) { if (tail_pending) (void)hipStreamWaitEvent(stream, aux->tail_done, 0); return rc; }
                 hipLaunchKernelGGL(tiles_gather_kernel, dim3(ncmax, nr, W), dim3(256), 0, stream, G, ldg, recv, g0, nr, k + 1, T, W, 0, ncmax, 1, me);
             }
             if (!overlap) {

@@ -181,6 +181,9 @@ def test_sharding_registration_is_validated_and_collective_failures_surface(buil
     ctx.set_solve_sharding(0, 1, lambda *a: 7, ok)
     with pytest.raises(SdmError, match="collective failed with status 7"):
         ctx.solve(0, reg[0], reg[1], reg[2], n_train_global=0)
+    with pytest.raises(SdmError, match="no Gram matrix"):          # the half-factored system is not offered for a second solve
+        ctx.solve(0, reg[0], reg[1], reg[2], n_train_global=0)
+    ctx.gram_rhs(0)
     # a Python exception inside a callback never crosses the C boundary: it becomes a failure status
     def boom(*a):
         raise RuntimeError("transport down")
