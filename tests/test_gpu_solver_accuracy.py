@@ -26,3 +26,19 @@ def test_normal_equations_match_f64(built, F):
     G = A.astype(np.float64).T @ A.astype(np.float64) + np.eye(F)
     want = np.linalg.solve(G, A.astype(np.float64).T @ b.astype(np.float64))
     assert np.abs(R - want).max() <= 6e-6 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("M", [1, 16, 44, 80, 128, 136, 144])
+def test_wide_right_hand_sides(built, M):
+    """One and two right-hand-side tile columns, every chunking of the back substitution (<= 5 column tiles per launch)."""
+    rng = np.random.default_rng(1000 + M)
+    F, N = 260, 900
+    A = rng.standard_normal((N, F)).astype(np.float32)
+    b = rng.standard_normal((N, M)).astype(np.float32)
+    ctx = Context(0)
+    R, _ = ctx.solve_normal_equations(A, b, 0, 2.0, True)
+    ctx.close()
+    G = A.astype(np.float64).T @ A.astype(np.float64) + 2.0 * np.eye(F)
+    want = np.linalg.solve(G, A.astype(np.float64).T @ b.astype(np.float64))
+    assert R.shape == (F, M)
+    assert np.abs(R - want).max() <= 6e-6 * np.abs(want).max()
