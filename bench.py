@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=0,
                     help="faces of the batch timed on the CPU oracle (0 = about 20 core-seconds of work)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--rcr68-shard", type=int, default=8192,
+                    help="faces per GPU of the RCR-68 detect leg (BASELINE config 4: 65 536 faces over 8 GPUs); 0 skips the RCR-68 legs")
     return ap.parse_args()
 
 
@@ -68,6 +70,14 @@ def main():
                                        workers=workers if ib - ia >= 1024 else 0)
     txs, tx0, tidx = synth.make_samples(tbox, tgt, ids, n_perturb=rows_per_image - 1, seed=synth.SEED + 2000 + rank)
     n_train_global = n_img_total * rows_per_image
+    # RCR-68 rows on the SAME images (BASELINE config 5: RCR-68 train, 100k faces): 68 landmarks, same boxes and perturbations
+    ids68 = ibug.IBUG68_IDS
+    if args.rcr68_shard > 0:
+        txs68, tx068, tidx68 = synth.make_samples(tbox, tgt, ids68, n_perturb=rows_per_image - 1, seed=synth.SEED + 2000 + rank)
+    # detect faces of this rank: the headline batch = the first args.batch of them, the RCR-68 shard = all of them
+    n_detect = max(args.batch, args.rcr68_shard)
+    images, boxes, gt = synth.make_faces(n_detect, seed=synth.SEED + 17 * rank, chunk=32,
+                                         workers=workers if n_detect >= 1024 else 0)
     datagen_s = time.time() - t0
 
     import torch
@@ -100,7 +110,7 @@ def main():
     t0 = time.time()
     reg = lambda: Regulariser(Regulariser.RegularisationType.MatrixNorm, 1.5, False)   # rcr-train.cpp:440-443
     sdo = SupervisedDescentOptimiser([LinearRegressor(reg()) for _ in params], device=local_rank, stream=stream)
-    hog = HogTransform(timg, params, ids, ibug.RIGHT_EYE_IDS, ibug.LEFT_EYE_IDS, tidx)
+    hog = HogTransform(timg, params, ids, ibug.RIGHT_EYE_IDS, ibug.LEFT_EYE_IDS, tidx, images_resident=True)   # (uploaded by the first pass)
     allreduce = parallel.make_torch_allreduce(local_rank) if use_dist else None
     # SDM_BENCH_SHARD_SOLVE=1: the summed system is factored by all ranks together (tile-column ownership).  Off by
     # default: at the bench's F = 8 801 the factorisation is bound by its chain of 69 single-workgroup panel steps, which
@@ -136,9 +146,65 @@ def main():
     ctx.set_allreduce(None, 1)
     ctx.set_solve_sharding(0, 0, None, None)
 
+    # ---- BASELINE config 5: RCR-68 (iBUG-68, F = 27 201, M = 136) trained on the same 100k rows, sharded over the ranks.  The
+    # summed system is large enough for the sharded factorisation to pay, so with N > 1 GPUs it is on by default
+    # (SDM_BENCH_SHARD_SOLVE=0 keeps the replicated solve) -------------------------------------------------------------------
+    rcr68 = None
+    if args.rcr68_shard > 0:
+        L68, M68 = len(ids68), 2 * len(ids68)
+        sdo68 = SupervisedDescentOptimiser([LinearRegressor(reg()) for _ in params], device=local_rank, stream=stream)
+        hog68 = HogTransform(timg, params, ids68, ibug.RIGHT_EYE_IDS, ibug.LEFT_EYE_IDS, tidx68, images_resident=True)
+        shard68 = use_dist and world > 1 and os.environ.get("SDM_BENCH_SHARD_SOLVE", "1") == "1"
+        coll68 = parallel.make_torch_solve_collectives(local_rank) if shard68 else None
+        nlsr68, wall68 = [], []
+        for rep in range(2):
+            sdo68.ctx.enable_timing(True)
+            sdo68.ctx.get_timing(reset=True)
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            sdo68.train(txs68, tx068, None, hog68, allreduce=allreduce, world_size=world, n_train_global=n_train_global,
+                        rank=rank if shard68 else None, solve_collectives=coll68,
+                        on_training_epoch_callback=(lambda cur: nlsr68.append(float(np.linalg.norm(cur - txs68) / np.linalg.norm(txs68))))
+                        if rep == 0 else None)
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize()
+            wall68.append(time.perf_counter() - t1)
+            timing68 = sdo68.ctx.get_timing(reset=True)
+        if use_dist:
+            tt = torch.tensor([wall68[-1]], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            wall68[-1] = float(tt.item())
+        ctx68 = sdo68.ctx
+        ctx68.set_allreduce(None, 1)
+        ctx68.set_solve_sharding(0, 0, None, None)
+        F68 = ctx68.feature_dim(0)
+        T68, r68 = (F68 + 127) // 128, (((M68 + 15) // 16) * 16 + 127) // 128
+        n_rows68 = int(txs68.shape[0])
+        gram_exec = (T68 * (T68 + 1) // 2 + T68 * r68) * 128.0 * 128.0 * 2.0 * n_rows68      # upper 128 x 128 tiles + RHS tile columns
+        gram_ms = timing68["gram"][0] / n_levels
+        rcr68 = {
+            "train": {
+                "workload": "BASELINE config 5: RCR-68 (iBUG-68 layout, F=%d, M=%d) train, %d rows over %d GPU(s), 4 cascade levels, "
+                            "MatrixNorm 1.5, synthetic 256x256 faces" % (F68, M68, n_train_global, world),
+                "rows_total": int(n_train_global), "rows_per_gpu": n_rows68,
+                "sec_per_cascade": wall68[-1] / n_levels, "scaling": "strong",
+                "collective": "one all-reduce of {A^T A, A^T b} per level (torch.distributed nccl = RCCL)" if use_dist else "none (1 GPU)",
+                "solve": ("sharded over the ranks by tile column" if shard68 else "replicated on every rank" if use_dist else "single GPU"),
+                "stage_ms_per_level_rank0": {k: v[0] / n_levels for k, v in timing68.items()},
+                "gram": {"kernel": "syrk_tn_glds_kernel", "bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_F32_PEAK_TF,
+                         "achieved": gram_exec / (gram_ms * 1e-3) / 1e12 if gram_ms > 0 else 0.0,
+                         "frac": gram_exec / (gram_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF if gram_ms > 0 else 0.0,
+                         "useful_tflops": (n_rows68 * float(F68) * (F68 + 1) + 2.0 * n_rows68 * F68 * M68) / (gram_ms * 1e-3) / 1e12 if gram_ms > 0 else 0.0,
+                         "note": "achieved = executed flops (upper 128x128 tiles incl. padding + RHS tile columns) / HIP-event time of the stage on rank 0"},
+                "solve_ms": (timing68["factor_solve"][0] + timing68["backsolve"][0]) / n_levels,
+                "nlsr_per_level_rank0": list(nlsr68),
+            }}
+
     # ---- workload: this rank's shard of synthetic faces, resident in HBM --------------------------------
-    images, boxes, gt = synth.make_faces(args.batch, seed=synth.SEED + 17 * rank)
-    x_star, x0, _ = synth.make_samples(boxes, gt, ids, 0, seed=synth.SEED + 17 * rank + 1)
+    x_star, x0, _ = synth.make_samples(boxes[:args.batch], gt[:args.batch], ids, 0, seed=synth.SEED + 17 * rank + 1)
     d_images = torch.from_numpy(images).cuda()
     d_x0 = torch.from_numpy(x0).cuda()
     ctx.set_model_geometry(L, re, le, params)
@@ -186,6 +252,63 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # ---- BASELINE config 4: RCR-68 detect on this rank's shard (65 536 faces over 8 GPUs = 8 192 per GPU), the cascade just
+    # trained, inputs resident; same timing discipline as the headline (barrier + synchronize, max over ranks) ------------------
+    if rcr68 is not None:
+        nb68 = args.rcr68_shard
+        _, x068, _ = synth.make_samples(boxes[:nb68], gt[:nb68], ids68, 0, seed=synth.SEED + 17 * rank + 2)
+        d_x068 = torch.from_numpy(x068).cuda()
+        ctx68.set_images_device(d_images.data_ptr(), nb68, 256, 256, 256)
+        ctx68.set_sample_image_index(None)
+        ctx68.set_templates(None)
+        ctx68.enable_timing(False)
+        ctx68.set_x_device(d_x068.data_ptr(), nb68)
+        hog_bytes68 = 0
+        for l in range(n_levels):
+            ctx68.hog_features(l)
+            h = ctx68.patch_indices()[:, 0].astype(np.int64)
+            hog_bytes68 += int((L68 * (2 * h) ** 2).sum()) + nb68 * (ctx68.feature_dim(l) * 4 + M68 * 4)
+            ctx68.apply(l)
+        steps68 = max(3, min(args.steps, 20))
+
+        def step68():
+            ctx68.set_x_device(d_x068.data_ptr(), nb68)
+            ctx68.detect_batch(fetch=False)
+        for _ in range(2):
+            step68()
+        ctx68.enable_timing(True)
+        ctx68.get_timing(reset=True)
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps68):
+            step68()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt68 = time.perf_counter() - t0
+        tm68 = ctx68.get_timing(reset=True)
+        ctx68.enable_timing(False)
+        if use_dist:
+            t = torch.tensor([dt68], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt68 = float(t.item())
+        hog68_ms = tm68["hog"][0] / max(tm68["hog"][1], 1)
+        app68_ms = tm68["apply"][0] / max(tm68["apply"][1], 1)
+        gbs68 = hog_bytes68 / n_levels / (hog68_ms * 1e-3) / 1e9 if hog68_ms > 0 else 0.0
+        tf68 = 2.0 * nb68 * F68 * M68 / (app68_ms * 1e-3) / 1e12 if app68_ms > 0 else 0.0
+        rcr68["detect_shard"] = {
+            "workload": "BASELINE config 4: RCR-68 detect (F=%d, M=%d), %d synthetic 256x256 faces per GPU (65 536 / 8), 4 cascade levels, "
+                        "the cascade trained above" % (F68, M68, nb68),
+            "value": nb68 * world * steps68 / dt68, "unit": "faces/s", "n_gpus": world, "steps": steps68,
+            "ms_per_step": dt68 / steps68 * 1e3, "scaling": "weak",
+            "hog": {"bound": "hbm", "achieved": gbs68, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs68 / HBM_PEAK_GBS,
+                    "avg_launch_ms": hog68_ms, "algorithmic_bytes_per_launch": hog_bytes68 / n_levels},
+            "apply_gemm": {"kernel": "apply_partial_kernel+apply_reduce_kernel", "bound": "mfma", "achieved": tf68, "peak": MFMA_F32_PEAK_TF,
+                           "unit": "TFLOP/s", "frac": tf68 / MFMA_F32_PEAK_TF, "avg_launch_ms": app68_ms},
+        }
+
     if rank != 0:
         if use_dist:
             dist.destroy_process_group()
@@ -209,7 +332,7 @@ def main():
             tj = json.load(fh)
         ent = tj["kernels"][hog_kernel]
         if int(tj.get("batch", 0)) == args.batch:
-            traffic, traffic_src = float(ent["bytes_per_launch"]), "profiles/hbm_traffic.json (" + tj["source"] + ")"
+            traffic, traffic_src = float(ent["bytes_per_launch"]), "committed-profile: profiles/hbm_traffic.json (" + tj["source"] + ")"
             # what actually limits this kernel is instruction issue: SIMD-cycles per wave-instruction over the launch
             simd_cycles = 256 * 4 * 2.4e9 * hog_avg_ms * 1e-3
             valu_issue = {"valu_insts_per_launch": float(ent["SQ_INSTS_VALU"]), "salu_insts_per_launch": float(ent.get("SQ_INSTS_SALU", 0.0)),
@@ -283,6 +406,10 @@ def main():
             "seconds_data_generation": datagen_s,
         },
     }
+
+    if rcr68 is not None:
+        out["rcr68_train"] = rcr68["train"]
+        out["rcr68_detect_shard"] = rcr68["detect_shard"]
 
     # ---- CPU baseline: the oracle on this box's host cores, bounded sample of the same batch -----------
     if not args.no_cpu:

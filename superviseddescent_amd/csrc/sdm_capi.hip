@@ -431,7 +431,7 @@ int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int*
     for (int i = 0; i < nle; ++i) eyes.le[i] = le[i];
     std::vector<HogLevelDev> n_levels_dev;
     std::vector<sdm_hog_param> n_params;
-    std::vector<int> n_fast_kernel, n_fast_bins;
+    std::vector<int> n_fast_kernel, n_fast_bins, n_raw_sqrt;
     int Fmax = 0;
     for (int l = 0; l < n_levels; ++l) {
         const sdm_hog_param& p = levels[l];
@@ -479,22 +479,24 @@ int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int*
         {
             // exhaustive on-device check of the orientation shortcut for this level's orientation count (levels that share
             // an orientation count share the verdict)
-            int verdict = -1;
+            int verdict = -1, raw_ok = 0;
             for (int q = 0; q < l && verdict < 0; ++q)
-                if (n_levels_dev[q].O == lv.O) verdict = n_fast_bins[q];
+                if (n_levels_dev[q].O == lv.O) { verdict = n_fast_bins[q]; raw_ok = n_raw_sqrt[q]; }
             if (verdict < 0) {
-                int mism[2] = {1, 1};
+                int mism[3] = {1, 1, 1};
                 ScopedBuf<int> dm;
-                int rcv = dm.ensure(2, true, c->stream);
+                int rcv = dm.ensure(3, true, c->stream);
                 if (rcv) return rcv;
                 sdm_launch_verify_fast_bins(lv, dm.p, c->stream);
-                HIP_TRY(hipMemcpyAsync(mism, dm.p, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipMemcpyAsync(mism, dm.p, 3 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
                 HIP_TRY(hipStreamSynchronize(c->stream));
                 dm.release();
                 // 2 = sector count, 1 = un-normalised arg-max, 0 = reference arithmetic
                 verdict = mism[1] == 0 ? 2 : (mism[0] == 0 ? 1 : 0);
+                raw_ok = mism[2] == 0 ? 1 : 0;      // the packed kernel may take v_sqrt_f32 as it comes (else it repairs the ulp)
             }
             n_fast_bins.push_back(verdict);
+            n_raw_sqrt.push_back(raw_ok);
             n_fast_kernel.push_back(sdm_hog_fast_supported(lv) ? 1 : 0);
         }
         const int F = L * lv.P + (lv.fixed_h > 0 ? 0 : 1);
@@ -502,27 +504,31 @@ int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int*
     }
     // lane-packed launch plans (tables in HBM, a few KB per level)
     std::vector<sdm_ctx::Plan> n_plans(n_levels);
+    // whatever n_plans holds when this function returns is freed: the new tables on every error path below (the HIP_TRY
+    // early returns leaked them), the context's previous tables after the swap at the commit
+    struct PlanGuard {
+        std::vector<sdm_ctx::Plan>& v;
+        ~PlanGuard() { for (auto& q : v) { q.lane_tab.release(); q.wb.release(); q.pass_info.release(); } }
+    } plan_guard{n_plans};
     for (int l = 0; l < n_levels; ++l) {
         HogPlanHost hp;
         if (!n_fast_kernel[l] || n_fast_bins[l] != 2 || !sdm_hog_plan_build(n_levels_dev[l], L, hp)) continue;
         sdm_ctx::Plan& pl = n_plans[l];
         int rcp;
         if ((rcp = pl.lane_tab.ensure(hp.lane_tab.size())) || (rcp = pl.wb.ensure(hp.wb.size())) ||
-            (rcp = pl.pass_info.ensure(hp.pass_info.size()))) {
-            for (auto& q : n_plans) { q.lane_tab.release(); q.wb.release(); q.pass_info.release(); }
+            (rcp = pl.pass_info.ensure(hp.pass_info.size())))
             return rcp;
-        }
         HIP_TRY(hipMemcpyAsync(pl.lane_tab.p, hp.lane_tab.data(), hp.lane_tab.size() * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(pl.wb.p, hp.wb.data(), hp.wb.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(pl.pass_info.p, hp.pass_info.data(), hp.pass_info.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));      // (the host vectors go out of scope)
         pl.dev.G = hp.G; pl.dev.P = hp.P; pl.dev.n_main = hp.n_main; pl.dev.Gt = hp.Gt; pl.dev.Pt = hp.Pt; pl.dev.hist_slots = hp.hist_slots;
+        pl.dev.raw_sqrt = n_raw_sqrt[l];
         pl.dev.lane_tab = pl.lane_tab.p; pl.dev.wb = pl.wb.p; pl.dev.pass_info = pl.pass_info.p;
         pl.ok = true;
     }
     // ---- commit ----
-    for (auto& q : c->plans) { q.lane_tab.release(); q.wb.release(); q.pass_info.release(); }
-    c->plans.swap(n_plans);
+    c->plans.swap(n_plans);          // (the previous tables leave with plan_guard)
     c->L = L; c->M = 2 * L;
     c->eyes = eyes;
     c->levels.swap(n_levels_dev); c->params.swap(n_params); c->fast_kernel.swap(n_fast_kernel); c->fast_bins.swap(n_fast_bins);

@@ -41,6 +41,7 @@
 //  * blockIdx is remapped so that the 22/68 patches of one face run on one XCD (its image is then fetched
 //    from HBM into one L2 instead of eight).
 #include "sdm_kernels.h"
+#include <stdlib.h>
 #include <string.h>
 #include <type_traits>
 #include <vector>
@@ -1063,10 +1064,21 @@ __host__ __device__ inline size_t packed_scratch_bytes(int C, int O = 4)
 }
 // per wave: [ column rows | per-row table of the vertical taps, S + 2 entries of 16 bytes | hist_slots histograms ]
 // (the finish scratch overlays the column rows, which are all zero between two passes)
-__host__ __device__ inline size_t packed_rowtab_bytes(int S) { return (size_t)(S + 2) * 16; }
-__host__ __device__ inline size_t packed_lds_bytes(int C, int O, int S, int hist_slots)
+// (the generic instance issues its image loads two rows ahead without looking: entries S and S + 1 repeat the last row; the
+//  instances specialised on the cell size know at compile time where the ROI ends and keep S entries)
+__host__ __device__ inline size_t packed_rowtab_bytes(int S, bool spec = false) { return (size_t)(S + (spec ? 0 : 2)) * 16; }
+__host__ __device__ inline size_t packed_lds_bytes(int C, int O, int S, int hist_slots, bool spec = false)
 {
-    return al16(HP_ROWS_BYTES(O)) + packed_rowtab_bytes(S) + hist_slots * al16(HP_HIST_BYTES(O, C * C)) + (HP_OVERLAY ? 0 : packed_scratch_bytes(C, O));
+    return al16(HP_ROWS_BYTES(O)) + packed_rowtab_bytes(S, spec) + hist_slots * al16(HP_HIST_BYTES(O, C * C)) + (HP_OVERLAY ? 0 : packed_scratch_bytes(C, O));
+}
+// specialised instances: the band-slot weights {ws0, ws1} of every pixel row (level constants, hog.c:697-704) in ONE table per
+// workgroup behind the waves' regions, read per row with a broadcast 8-byte LDS read straight into the register pair the
+// packed multiply-add takes (scalar loads of them cannot stay in SGPRs over an unrolled ROI: the compiler spilled them to
+// vector lanes and paid two v_readlane per row)
+__host__ __device__ inline size_t packed_wstab_bytes(int S) { return al16((size_t)S * 8); }
+__host__ __device__ inline size_t packed_wg_lds_bytes(int C, int O, int S, int hist_slots, bool spec)
+{
+    return packed_lds_bytes(C, O, S, hist_slots, spec) * HP_WAVES + (spec ? packed_wstab_bytes(S) : 0);
 }
 
 // arithmetic type of the packed kernel's normalisation (hog.c:930-1052 computes the block factors and the clamped products in
@@ -1185,7 +1197,19 @@ __device__ inline double resize_scale(const HogLevelDev& lv, int h, int sw)
     return (h < SDM_SCALE_TAB) ? lv.scale_tab[h > 0 ? h : 0] : 1.0 / ((double)lv.S / (double)sw);
 }
 
-template <int TO, int TC>
+// Cell row (band) of resized-ROI row d: floor((d + 0.5) / cell - 0.5) (hog.c:697-704) in integers, for the instances specialised
+// on the cell size; sdm_hog_plan_build checks it against the level's float table before such an instance is chosen.
+__host__ __device__ constexpr int packed_band_of(int d, int cell)
+{
+    return (2 * d + 1 - cell >= 0) ? (2 * d + 1 - cell) / (2 * cell) : -1;      // (d >= 0, cell >= 1: the only negative value is -1)
+}
+
+// CELL > 0: the instance is specialised on the level's cell size: S, the band of every pixel row and
+// hence the fold sites, the band slots and every row-table offset are compile-time constants, the row loop is unrolled over
+// the S rows -- no per-row scalar loads of the band index, no band compare / branch, no loop counter.  CELL == 0: any cell size
+// (the round-2 form of the loop).  RAW: the gradient magnitude is v_sqrt_f32 as the hardware returns it (chosen per level at
+// sdm_set_model_geometry, only if the exhaustive check found it exact or one ulp low on all 511^2 gradients).
+template <int TO, int TC, int CELL, bool RAW>
 __global__ void __launch_bounds__(HP_WAVES * 64, HP_MINW)
 hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float* __restrict__ x, int N, int L,
                   EyeIdxDev eyes, HogLevelDev lv, HogPlanDev plan, float* __restrict__ feat, long long ldf,
@@ -1210,13 +1234,16 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
     const int lm0 = main_group ? g * plan.G : plan.n_main * plan.G;   // first landmark of the group
     const int npass = main_group ? plan.P : plan.Pt;
     const int pass0 = main_group ? 0 : plan.P;
-    const int S = lv.S;
+    constexpr int SC = TC * CELL;                 // (0 for the generic instance)
+    const int S = CELL > 0 ? SC : lv.S;
 
     const int nslots = plan.hist_slots;                                               // 2, or 3 for ROIs under 22 columns
-    unsigned char* lds = smem + (size_t)wave * packed_lds_bytes(C, O, S, nslots);
+    constexpr bool SPEC = CELL > 0;
+    unsigned char* lds = smem + (size_t)wave * packed_lds_bytes(C, O, S, nslots, SPEC);
     float* colrows = (float*)lds;                                                    // [2O][ST][2 band slots]
-    i32x4* rowtab = (i32x4*)(lds + al16(HP_ROWS_BYTES(O)));                          // [S + 2] {row offset 0, row offset 1, weight 0 << 12, weight 1 << 12}
-    float* hist = (float*)(lds + al16(HP_ROWS_BYTES(O)) + packed_rowtab_bytes(S));   // [nslots][2O][CC]
+    i32x4* rowtab = (i32x4*)(lds + al16(HP_ROWS_BYTES(O)));                          // [S (+ 2)] {row offset 0, row offset 1, weight 0 << 12, weight 1 << 12}
+    float* hist = (float*)(lds + al16(HP_ROWS_BYTES(O)) + packed_rowtab_bytes(S, SPEC));   // [nslots][2O][CC]
+    f32x2* wstab = (f32x2*)(smem + (size_t)HP_WAVES * packed_lds_bytes(C, O, S, nslots, SPEC));      // [S] per workgroup (SPEC)
     constexpr int HSTR = (2 * O * CC * 4 + 15) / 16 * 4;      // floats per histogram slot (16-byte multiple)
     unsigned char* scratch = HP_OVERLAY ? lds : (unsigned char*)(hist + nslots * HSTR);
     auto hist_slot = [&](int patch_slot) { return nslots == 2 ? (patch_slot & 1) : patch_slot % 3; };
@@ -1259,8 +1286,19 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
     wave_sync();
     // the per-row table: every lane reads entry y with ONE broadcast LDS read per row (no v_readlane, no scalar decoding);
     // entries S and S + 1 (the row loop issues its loads two rows ahead) repeat the last row
-    if (lane < S + 2) rowtab[lane] = row_ent;
-    if (S + 2 > 64 && lane < S + 2 - 64) {
+    if (SPEC) {
+        // specialised layout: entry e = {offsets of row e + 2, weights of row e}: the row loop wants exactly that pair at row e, in
+        // ONE 16-byte broadcast read; the offsets of rows 0 and 1 (issued before the loop) sit in the last two entries
+        if (lane < S) {
+            const int eo = lane >= 2 ? lane - 2 : lane + S - 2;
+            *(i32x2*)&rowtab[eo] = (i32x2){row_ent.x, row_ent.y};
+            *((i32x2*)&rowtab[lane] + 1) = (i32x2){row_ent.z, row_ent.w};
+        }
+    } else if (lane < S + 2) rowtab[lane] = row_ent;
+    // (every wave of the workgroup writes the same values; a wave's own LDS accesses execute in order, so it reads what it -- or
+    //  a neighbour, identically -- wrote: no workgroup barrier)
+    if (SPEC && lane < S) wstab[lane] = (f32x2){lv.row_tab[lane][0], lv.row_tab[lane][1]};
+    if (!SPEC && S + 2 > 64 && lane < S + 2 - 64) {
         i32x4 last;
 #pragma unroll
         for (int k = 0; k < 4; ++k) last[k] = __builtin_amdgcn_readlane(row_ent[k], 63);
@@ -1327,7 +1365,7 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
         // ---- row loop ----------------------------------------------------------------------------------------------------------
         // the image loads of row y: the two source rows' byte offsets come from the row table (one broadcast 8-byte LDS read)
         auto issue_row = [&](int y, unsigned short& q0, unsigned short& q1) {
-            const i32x2 rr = *(const i32x2*)&rowtab[y];
+            const i32x2 rr = *(const i32x2*)&rowtab[SPEC ? (y >= 2 ? y - 2 : y + S - 2) : y];
             if (HP_ABL == 4) { q0 = (unsigned short)(vb + rr.x); q1 = (unsigned short)(vb + rr.y); return; }
             q0 = __builtin_amdgcn_raw_buffer_load_b16(img_rsrc, vb + rr.x, 0, 0);
             q1 = __builtin_amdgcn_raw_buffer_load_b16(img_rsrc, vb + rr.y, 0, 0);
@@ -1344,10 +1382,13 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
         float rm2 = 0.0f, rm1 = 0.0f;
         constexpr unsigned bin_stride = ST * 8;
         unsigned char* const cbase0 = (unsigned char*)colrows + lane * 8;
-        unsigned col_off1 = bin_stride;
-        asm volatile("" : "+v"(col_off1));
-        unsigned char* const cbase1 = cbase0 + col_off1;
-        f32x2* pend_p = (f32x2*)cbase0;
+        // LDS byte addresses of this lane's column in bin rows 0 and 1, each in a register of its own (opaque to the optimiser:
+        // otherwise the select below becomes base + select(offset, 0), one more add per pixel row)
+        typedef __attribute__((address_space(3))) unsigned char lds_u8;
+        typedef __attribute__((address_space(3))) f32x2 lds_f32x2;
+        unsigned cadr0 = (unsigned)(size_t)(lds_u8*)cbase0, cadr1 = cadr0 + bin_stride;
+        asm volatile("" : "+v"(cadr0), "+v"(cadr1));
+        lds_f32x2* pend_p = (lds_f32x2*)(size_t)cadr0;
         f32x2 pend_v = {0.0f, 0.0f};
         float pend_g = 0.0f;
         int prev_by = -1;
@@ -1397,7 +1438,7 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
         auto row_step = [&](const int j, const int y, const bool grad) __attribute__((always_inline)) {
             int H0, H1;
             horizontal(q0[j], q1[j], H0, H1);
-            issue_row(y + 2, q0[j], q1[j]);      // (past the last row: a harmless extra load of the last row)
+            if (!SPEC || y + 2 < S) issue_row(y + 2, q0[j], q1[j]);      // (generic: past the last row a harmless extra load of the last row)
             f32x2 qv = {0.0f, 0.0f};
             if (grad && HP_ABL != 3) qv = *pend_p;
             const float r0 = vertical(H0, H1, y);
@@ -1406,20 +1447,24 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
                 const float gx = from_right(rm1) - from_left(rm1);
                 const float gy = r0 - rm2;
                 const float g2 = gx * gx + gy * gy;
-                const float gm = HP_RAWSQRT ? __builtin_amdgcn_sqrtf(g2) : sqrt_int_up(g2);
+                const float gm = (HP_RAWSQRT && RAW) ? __builtin_amdgcn_sqrtf(g2) : sqrt_int_up(g2);
                 bool b0, b1, b2;
                 bin_sector4_bits(gx, gy, lv, b0, b1, b2);
                 if (HP_ABL == 3) { f32x2 dz = __builtin_elementwise_fma(pend_v, (f32x2){pend_g, pend_g}, qv); asm volatile("" :: "v"(dz), "v"(pend_p)); }
                 else if (HP_PKFMA) *pend_p = __builtin_elementwise_fma(pend_v, (f32x2){pend_g, pend_g}, qv);
                 else *pend_p = qv + pend_v;
                 const float* rt = lv.row_tab[yy];
-                const float ws0 = rt[0], ws1 = rt[1];
-                const int cby = __builtin_bit_cast(int, rt[2]);
+                f32x2 wsv;
+                if (SPEC) wsv = wstab[yy];
+                else wsv = (f32x2){rt[0], rt[1]};
+                const float ws0 = wsv.x, ws1 = wsv.y;
+                // (specialised instance: yy and with it the band are constants after unrolling; prev_by folds away)
+                const int cby = CELL > 0 ? packed_band_of(yy, CELL) : __builtin_bit_cast(int, rt[2]);
                 if (cby != prev_by) {
                     if (prev_by >= 0) fold_band(prev_by);
                     prev_by = cby;
                 }
-                pend_p = (f32x2*)((b0 ? cbase1 : cbase0) + ((b1 ? 2u * bin_stride : 0u) + (b2 ? 4u * bin_stride : 0u)));
+                pend_p = (lds_f32x2*)(size_t)((b0 ? cadr1 : cadr0) + ((b1 ? 2u * bin_stride : 0u) + (b2 ? 4u * bin_stride : 0u)));
                 if (HP_PKFMA) { pend_v = (f32x2){ws0, ws1}; pend_g = gm; }
                 else pend_v = (f32x2){ws0, ws1} * gm;
             }
@@ -1427,12 +1472,17 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
         };
         row_step(0, 0, false);
         row_step(1, 1, false);
-        int yrow = 2;
-        for (; yrow + 1 < S; yrow += 2) {
-            row_step(0, yrow, true);
-            row_step(1, yrow + 1, true);
+        if constexpr (CELL > 0) {
+#pragma unroll
+            for (int yrow = 2; yrow < SC; ++yrow) row_step(yrow & 1, yrow, true);
+        } else {
+            int yrow = 2;
+            for (; yrow + 1 < S; yrow += 2) {
+                row_step(0, yrow, true);
+                row_step(1, yrow + 1, true);
+            }
+            if (yrow < S) row_step(0, yrow, true);
         }
-        if (yrow < S) row_step(0, yrow, true);
         if (HP_PKFMA) *pend_p = __builtin_elementwise_fma(pend_v, (f32x2){pend_g, pend_g}, *pend_p);
         else *pend_p += pend_v;
         if (prev_by >= 0) fold_band(prev_by);
@@ -1484,6 +1534,9 @@ __global__ void verify_fast_bins_kernel(HogLevelDev lv, int* __restrict__ mismat
     }
     if (a != b || !sqrt2_ok) atomicAdd(mismatches, 1);
     if (!sector_ok || !sqrt1_ok) atomicAdd(mismatches + 1, 1);
+    // the packed kernel's raw v_sqrt_f32: acceptable only if it is the correctly rounded root or exactly one ulp below it
+    const int raw = __builtin_bit_cast(int, __builtin_amdgcn_sqrtf(g2));
+    if (!(raw == want || raw == want - 1)) atomicAdd(mismatches + 2, 1);
 }
 
 }  // namespace
@@ -1535,6 +1588,10 @@ bool sdm_hog_plan_build(const HogLevelDev& lv, int L, HogPlanHost& out)
     out = HogPlanHost();
     if (!(lv.O == 4 && lv.C == 5 && lv.cell <= 12 && lv.S >= 4 && lv.S <= 64 && L >= 1)) return false;
     const int S = lv.S;
+    for (int d = 0; d < S; ++d) {      // the specialised instances compute the band of a row in integers: must equal the table
+        int b; memcpy(&b, &lv.row_tab[d][2], sizeof(int));
+        if (b != packed_band_of(d, lv.cell)) return false;
+    }
     std::vector<std::vector<PlanLane>> tmp;
     // group size: fewest passes per sample; among equals at least two passes per wave (the per-group set-up is then shared),
     // then the smaller group
@@ -1598,9 +1655,23 @@ void sdm_launch_hog_packed(const ImageSetDev& imgs, const int* img_idx, const fl
     const long long total = (long long)N * gpf;
     if (total <= 0) return;
     const unsigned grid = (unsigned)((total + HP_WAVES - 1) / HP_WAVES);
-    const size_t lds = packed_lds_bytes(5, 4, lv.S, plan.hist_slots) * HP_WAVES;
-    hipLaunchKernelGGL((hog_packed_kernel<4, 5>), dim3(grid), dim3(HP_WAVES * 64), lds, stream, imgs, img_idx, x, N, L, eyes, lv, plan,
-                       feat, ldf, idx_out, status);
+#define HP_LAUNCH(CELL, RAW)                                                                                                    \
+    hipLaunchKernelGGL((hog_packed_kernel<4, 5, CELL, RAW>), dim3(grid), dim3(HP_WAVES * 64),                                      \
+                       packed_wg_lds_bytes(5, 4, lv.S, plan.hist_slots, CELL > 0), stream, imgs, img_idx, x, N, L,                \
+                       eyes, lv, plan, feat, ldf, idx_out, status)
+    // instances specialised on the shipped cell sizes (apps/rcr/rcr-train.cpp:447: 11, 10, 8, 6); any other cell size, a level
+    // whose v_sqrt_f32 verdict is negative, or SDM_HOG_NO_SPECIALISE=1 (A/B measurements) run the generic instance
+    static const bool no_spec = getenv("SDM_HOG_NO_SPECIALISE") && getenv("SDM_HOG_NO_SPECIALISE")[0] == '1';
+    if (!plan.raw_sqrt) { HP_LAUNCH(0, false); return; }
+    if (no_spec) { HP_LAUNCH(0, true); return; }
+    switch (lv.cell) {
+    case 11: HP_LAUNCH(11, true); break;
+    case 10: HP_LAUNCH(10, true); break;
+    case 8: HP_LAUNCH(8, true); break;
+    case 6: HP_LAUNCH(6, true); break;
+    default: HP_LAUNCH(0, true); break;
+    }
+#undef HP_LAUNCH
 }
 
 bool sdm_hog_fast_supported(const HogLevelDev& lv)

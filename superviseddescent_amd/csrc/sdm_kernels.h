@@ -73,7 +73,8 @@ void sdm_launch_hog(const ImageSetDev& imgs, const int* img_idx, const float* x,
 // cheaper orientation binning (1 = un-normalised arg-max, 2 = first-quadrant sector count; each only when
 // sdm_launch_verify_fast_bins counted 0 mismatches for it; 0 = the reference arithmetic).
 bool sdm_hog_fast_supported(const HogLevelDev& lv);
-// mismatches_dev[0]: un-normalised arg-max (+ lean sqrt), mismatches_dev[1]: sector method (+ lean sqrt)
+// mismatches_dev[0]: un-normalised arg-max (+ lean sqrt), mismatches_dev[1]: sector method (+ lean sqrt),
+// mismatches_dev[2]: gradients whose raw v_sqrt_f32 is neither the correctly rounded root nor one ulp below it
 void sdm_launch_verify_fast_bins(const HogLevelDev& lv, int* mismatches_dev, hipStream_t stream);
 void sdm_launch_hog_fast(const ImageSetDev& imgs, const int* img_idx, const float* x, int N, int L,
                          const EyeIdxDev& eyes, const HogLevelDev& lv, float* feat, long long ldf, int* idx_out,
@@ -94,6 +95,7 @@ void sdm_launch_hog_fast(const ImageSetDev& imgs, const int* img_idx, const floa
 struct HogPlanDev {
     int G, P, n_main, Gt, Pt;
     int hist_slots;            // patches a pass can touch = histograms a wave keeps in LDS (2; 3 for ROIs under 22 columns)
+    int raw_sqrt;              // v_sqrt_f32 found exact-or-one-ulp-low on all 511^2 gradients on THIS device (else: repaired root)
     const unsigned* lane_tab;
     const float* wb;
     const int* pass_info;

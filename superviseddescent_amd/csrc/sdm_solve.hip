@@ -447,7 +447,9 @@ potrf_tile_kernel(float* __restrict__ G, long long ldg, int k0, int* __restrict_
                 // (hardware sqrt / reciprocal, <= 1 ulp each: this is the engine's own factor, pinned to nothing bit-wise, and
                 //  the IEEE sequences are a third of the serial pivot step every 128-column step of the solve waits for)
                 const float sd = __builtin_amdgcn_sqrtf(piv);
-                bad = bad || !(piv > 0.0f);
+                // v_sqrt_f32 / v_rcp_f32 flush denormals: a pivot below FLT_MIN would give sd = 0, 1 / sd = inf and a factor full
+                // of inf / NaN with the status never set -- such a pivot is "not positive definite" here
+                bad = bad || !(piv >= 1.17549435e-38f);
                 const float u = (li == s_) ? sd : d[s_] * __builtin_amdgcn_rcpf(sd);          // U[s][i] for i >= s
                 d[s_] = u;
 #pragma unroll

@@ -69,6 +69,9 @@ class Context:
             check(self._lib.sdm_set_stream(self._h, ctypes.c_void_p(stream)))
         self.L = 0
         self.n_levels = 0
+        # level -> token of the regressor the DEVICE holds (None: unknown).  Kept here, next to the device copy, so that
+        # two optimisers sharing this context cannot mistake each other's upload for their own.
+        self._resident = {}
 
     def close(self):
         if getattr(self, "_h", None):
@@ -98,6 +101,7 @@ class Context:
         if key != getattr(self, "_geometry_key", None):
             self._geometry_key = key
             self.geometry_epoch = getattr(self, "geometry_epoch", 0) + 1
+            self._resident = {}
 
     def set_hog_mode(self, mode: int):
         """``_lib.SDM_HOG_COLUMNS`` (default: per-pixel-column f32 sums folded into cells on the matrix cores),
@@ -208,11 +212,26 @@ class Context:
         check(self._lib.sdm_get_patch_indices(self._h, _ip(out)))
         return out
 
-    def set_regressor(self, level: int, R: np.ndarray):
+    def set_regressor(self, level: int, R: np.ndarray, token=None):
+        """Uploads R as the regressor of ``level``.  ``token`` (any object) names what the device now holds; whoever writes
+        the level's device copy -- this call or ``solve`` -- replaces it (``resident_token``)."""
         R = np.ascontiguousarray(R, np.float32)
         if R.shape != (self.feature_dim(level), 2 * self.L):
             raise ValueError(f"regressor must be {self.feature_dim(level)} x {2 * self.L}")
+        self._resident.pop(level, None)
         check(self._lib.sdm_set_regressor(self._h, level, _fp(R)))
+        if token is not None:
+            self._resident[level] = token
+
+    def resident_token(self, level: int):
+        return self._resident.get(level)
+
+    def set_resident_token(self, level: int, token):
+        """Names the device copy ``solve`` just left behind (the optimiser that called it knows which regressor it is)."""
+        if token is None:
+            self._resident.pop(level, None)
+        else:
+            self._resident[level] = token
 
     def get_regressor(self, level: int) -> np.ndarray:
         out = np.empty((self.feature_dim(level), 2 * self.L), np.float32)
@@ -259,8 +278,8 @@ class Context:
                     traceback.print_exc()
                     return 1
             cb = _lib.ALLREDUCE_FN(tramp)
-        self._keep.append(cb)
         check(self._lib.sdm_set_allreduce(self._h, cb, None, world_size))
+        self._keep_allreduce = cb       # (replaces the previous thunk, which the library no longer references)
 
     def allreduce_gram_rhs(self):
         check(self._lib.sdm_allreduce_gram_rhs(self._h))
@@ -273,6 +292,7 @@ class Context:
         restores the replicated solve."""
         if bcast is None and allgather is None:
             check(self._lib.sdm_set_solve_sharding(self._h, 0, 0, _lib.BCAST_FN(), _lib.ALLGATHER_FN(), None))
+            self._keep_sharding = None
             return
 
         def guard(fn):
@@ -285,8 +305,8 @@ class Context:
                     return 1
             return tramp
         b, g = _lib.BCAST_FN(guard(bcast)), _lib.ALLGATHER_FN(guard(allgather))
-        self._keep += [b, g]
         check(self._lib.sdm_set_solve_sharding(self._h, rank, world_size, b, g, None))
+        self._keep_sharding = (b, g)    # (replaces the previous pair: nothing accumulates over train() calls)
 
     def set_solve_sharding_rccl(self, comm: Optional[int], rank: int = 0, world_size: int = 1, bcast_fn: Optional[int] = None,
                                 allgather_fn: Optional[int] = None):
@@ -297,6 +317,7 @@ class Context:
               n_train_global: int = 0, fetch: bool = True):
         lam = ctypes.c_float(0.0)
         R = np.empty((self.feature_dim(level), 2 * self.L), np.float32) if fetch else None
+        self._resident.pop(level, None)                     # the device copy of this level is overwritten
         check(self._lib.sdm_solve(self._h, level, reg_type, reg_param, int(regularise_last_row),
                                   n_train_global, _fp(R) if fetch else None, ctypes.byref(lam)))
         return R, lam.value
@@ -314,6 +335,7 @@ class Context:
 
     def train_level(self, level: int, reg_type: int, reg_param: float, regularise_last_row: bool,
                     n_train_global: int = 0):
+        self._resident.pop(level, None)
         check(self._lib.sdm_train_level(self._h, level, reg_type, reg_param, int(regularise_last_row),
                                         n_train_global))
 
@@ -409,14 +431,28 @@ class Regulariser:
         self.regularise_last_row = bool(regularise_last_row)
 
 
+class _ResidentToken:
+    """What a Context's device copy of one level holds: THE array object (a strong reference, so its id cannot be reused by
+    another array) and the regressor's version when it was uploaded."""
+
+    __slots__ = ("array", "version")
+
+    def __init__(self, array, version):
+        self.array, self.version = array, version
+
+
 class LinearRegressor:
-    """regressors.hpp:318-400.  ``x`` is the learned F x M matrix (public, as in the reference).  Assigning ``x`` bumps a
-    version number, which lets the optimiser keep an unchanged regressor resident on the device between calls (modify the
-    array IN PLACE and call ``touch()`` to have it uploaded again)."""
+    """regressors.hpp:318-400.  ``x`` is the learned F x M matrix (public, as in the reference).
+
+    The optimiser keeps an unchanged regressor resident on the device between calls.  "Unchanged" is enforced, not assumed:
+    while a device copy of ``x`` exists the array is read-only, so ``reg.x[...] = v`` or ``reg.x *= s`` raise instead of
+    silently leaving the device with stale coefficients.  Assign a new array (``reg.x = ...``), or call ``touch()`` and then
+    edit in place: both make the next ``test``/``predict``/``detect`` upload the level again."""
 
     def __init__(self, regulariser: Optional[Regulariser] = None):
         self._x: Optional[np.ndarray] = None
         self._version = 0
+        self._frozen = None          # (array, its original writeable flag) while a device copy exists
         self.regulariser = regulariser or Regulariser()
         self.last_lambda: Optional[float] = None
 
@@ -426,11 +462,30 @@ class LinearRegressor:
 
     @x.setter
     def x(self, value):
+        self._thaw()
         self._x = value
         self._version += 1
 
     def touch(self):
+        """Declares ``x`` about to be modified in place: writable again, and uploaded again at the next use."""
+        self._thaw()
         self._version += 1
+
+    def _freeze(self):
+        a = self._x
+        if isinstance(a, np.ndarray) and self._frozen is None:
+            self._frozen = (a, bool(a.flags.writeable))
+            a.flags.writeable = False
+
+    def _thaw(self):
+        if self._frozen is not None:
+            a, was = self._frozen
+            self._frozen = None
+            if was:
+                try:
+                    a.flags.writeable = True
+                except ValueError:      # (a view of a read-only base)
+                    pass
 
 
 class InterEyeDistanceNormalisation:
@@ -479,7 +534,6 @@ class SupervisedDescentOptimiser:
         # the oracle, the product path always builds the HIP context here
         self.ctx = ctx if ctx is not None else Context(device, stream)
         self._bound = None
-        self._resident, self._resident_geom = {}, None      # level -> (id(regressor), version) of what the device holds
 
     def _bind(self, projection: HogTransform, n_rows: int):
         if not isinstance(projection, HogTransform):
@@ -519,7 +573,6 @@ class SupervisedDescentOptimiser:
                 c.set_solve_sharding(rank, world_size, *solve_collectives)
             else:
                 c.set_solve_sharding(0, 0, None, None)
-        self._resident, self._resident_geom = {}, getattr(c, "geometry_epoch", None)
         n_glob = n_train_global or c.N
         for level, reg in enumerate(self.regressors):
             c.hog_features(level)                                            # superviseddescent.hpp:173-189
@@ -528,26 +581,35 @@ class SupervisedDescentOptimiser:
             r = reg.regulariser
             reg.x, reg.last_lambda = c.solve(level, r.regularisation_type, r.param, r.regularise_last_row,
                                              n_glob)                         # :207
-            self._resident[level] = (id(reg), reg._version)                  # (sdm_solve left it on the device)
+            self._mark_resident(level, reg)                                  # (sdm_solve left it on the device)
             c.apply(level)                                                   # :209-216
             if on_training_epoch_callback is not None:
                 on_training_epoch_callback(c.get_x())                        # :217
         return c.get_x()
 
+    def _mark_resident(self, level: int, reg: LinearRegressor):
+        if hasattr(self.ctx, "set_resident_token") and isinstance(reg.x, np.ndarray):
+            self.ctx.set_resident_token(level, _ResidentToken(reg.x, reg._version))
+            reg._freeze()
+
     def _load_regressors(self):
-        """Regressors the device already holds (same object, same version, same geometry since) are not uploaded again: a
-        per-frame ``detect()`` then costs the image upload and the kernels, not 4 x 1.5 MB of regressor traffic."""
-        geom = getattr(self.ctx, "geometry_epoch", None)
-        if self._resident_geom != geom:
-            self._resident = {}
-            self._resident_geom = geom
+        """Regressors the device already holds are not uploaded again: a per-frame ``detect()`` then costs the image upload
+        and the kernels, not 4 x 1.5 MB of regressor traffic.  The record of what the device holds lives in the Context (any
+        ``set_regressor`` / ``solve`` by anyone, or a changed geometry, replaces it), it names the array OBJECT (no id()
+        reuse) and its version, and a resident array is read-only (in-place edits raise; see LinearRegressor)."""
+        c = self.ctx
         for level, reg in enumerate(self.regressors):
             if reg.x is None:
                 raise RuntimeError("regressor level %d has not been learned" % level)
-            key = (id(reg), reg._version)
-            if self._resident.get(level) != key:
-                self.ctx.set_regressor(level, reg.x)
-                self._resident[level] = key
+            tok = c.resident_token(level) if hasattr(c, "resident_token") else None
+            if isinstance(tok, _ResidentToken) and tok.array is reg.x and tok.version == reg._version:
+                continue
+            if hasattr(c, "resident_token"):
+                x = reg.x if isinstance(reg.x, np.ndarray) else np.asarray(reg.x, np.float32)
+                c.set_regressor(level, x, token=_ResidentToken(reg.x, reg._version) if isinstance(reg.x, np.ndarray) else None)
+                reg._freeze()
+            else:
+                c.set_regressor(level, reg.x)
 
     def test(self, initialisations, templates, projection: HogTransform,
              on_regressor_iteration_callback: Optional[Callable[[np.ndarray], None]] = None) -> np.ndarray:

@@ -120,7 +120,7 @@ public:
         using superviseddescent::hip::check;
         if (parameters.rows != 1) throw std::runtime_error("HogTransform: parameters must be a single row");
         std::lock_guard<std::mutex> lock(state->mu);   // the device handle is not thread-safe
-        if (!state->handle) state->handle.reset(new superviseddescent::hip::Handle(0));
+        if (!state->handle) state->handle.reset(new superviseddescent::hip::Handle(superviseddescent::hip::device()));
         sdm_ctx* c = state->handle->get();
         if (!state->images_uploaded) {
             detail::configure(*state->handle, images, hog_params, modelLandmarksList, rightEyeIdentifiers, leftEyeIdentifiers, true);

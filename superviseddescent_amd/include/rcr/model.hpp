@@ -111,7 +111,7 @@ struct BatchedBackend<rcr::HogTransform, LinearRegressor<Solver>, rcr::InterEyeD
                       cv::Mat templates, rcr::HogTransform& hog, Callback on_training_epoch_callback)
     {
         if (hog.get_hog_params().size() != regressors.size()) throw std::runtime_error("one HoGParam per regressor level expected");
-        hip::Handle h(0);
+        hip::Handle h(hip::device());
         sdm_ctx* c = h.get();
         cv::Mat x0 = initialisations.isContinuous() ? initialisations : initialisations.clone();
         cv::Mat xs = parameters.isContinuous() ? parameters : parameters.clone();
@@ -145,7 +145,7 @@ struct BatchedBackend<rcr::HogTransform, LinearRegressor<Solver>, rcr::InterEyeD
                         rcr::HogTransform& hog, Callback on_regressor_iteration_callback)
     {
         if (hog.get_hog_params().size() != regressors.size()) throw std::runtime_error("one HoGParam per regressor level expected");
-        hip::Handle h(0);
+        hip::Handle h(hip::device());
         sdm_ctx* c = h.get();
         cv::Mat x0 = initialisations.isContinuous() ? initialisations : initialisations.clone();
         bind(h, hog, x0.rows);

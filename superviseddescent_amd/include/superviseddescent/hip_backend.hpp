@@ -23,9 +23,20 @@ inline void check(int rc, const char* what)
     if (rc < 0) throw std::runtime_error(std::string(what) + ": " + sdm_last_error());
 }
 
+// The device ordinal the header layer's handles are created on (per thread; default 0).  One process per GPU: a rank whose
+// RCCL communicator lives on device `local_rank` calls set_device(local_rank) -- or passes it to set_data_parallel_rccl --
+// before train()/test()/detect(), unless the launcher isolates each process with HIP_VISIBLE_DEVICES (then 0 is right).
+inline int& device_ordinal()
+{
+    static thread_local int d = 0;
+    return d;
+}
+inline void set_device(int device) { device_ordinal() = device; }
+inline int device() { return device_ordinal(); }
+
 class Handle {
 public:
-    explicit Handle(int device = 0) : ctx_(sdm_create(device))
+    explicit Handle(int device = hip::device()) : ctx_(sdm_create(device))
     {
         if (!ctx_) throw std::runtime_error(std::string("sdm_create: ") + sdm_last_error());
     }
@@ -69,8 +80,10 @@ inline void set_data_parallel(sdm_allreduce_fn fn, void* user, int world_size, l
     dp = DataParallel();
     dp.fn = fn; dp.user = user; dp.world_size = world_size; dp.n_train_global = n_train_global;
 }
-inline void set_data_parallel_rccl(void* nccl_comm, void* nccl_allreduce_fn, int world_size, long long n_train_global)
+// (device >= 0: the ordinal the communicator was created on; the backend's handles must run on that device)
+inline void set_data_parallel_rccl(void* nccl_comm, void* nccl_allreduce_fn, int world_size, long long n_train_global, int device = -1)
 {
+    if (device >= 0) set_device(device);
     DataParallel& dp = data_parallel();
     dp = DataParallel();
     dp.rccl_comm = nccl_comm; dp.rccl_allreduce = nccl_allreduce_fn; dp.world_size = world_size; dp.n_train_global = n_train_global;
@@ -106,7 +119,7 @@ inline void install_data_parallel(sdm_ctx* c)
 inline Handle& default_handle()
 {
     static thread_local std::unique_ptr<Handle> h;
-    if (!h) h.reset(new Handle(0));
+    if (!h) h.reset(new Handle(device()));
     return *h;
 }
 

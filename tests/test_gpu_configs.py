@@ -60,6 +60,50 @@ def test_training_at_baseline_configuration(built, name):
     assert rel_l2(levels[-1], x_star) < 0.5 * rel_l2(x0, x_star)
 
 
+FULL_PATH = os.path.join(os.path.dirname(__file__), "golden", "config_oracle_full.npz")
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_teacher_forced_training_level_by_level(built, name):
+    """the north-star tolerance (landmarks within 1e-4 relative L2 of the reference CPU path ON IDENTICAL
+    INPUTS) at EVERY level of the BASELINE training configurations.  The fixture holds the oracle's full landmark matrix x_k
+    after each level of its free-running cascade (scripts/make_config_fixtures.py, CPU only); level k of the GPU cascade --
+    HOG -> Gram / RHS -> regularise -> Cholesky solve -> apply -- is fed the ORACLE's x_k and must land within 1e-4 of the
+    oracle's x_{k+1}: same inputs, the reference's PartialPivLU on one side, the MFMA Gram + blocked Cholesky on the other.
+    (profiles/r03_cpu_solver_drift.json holds what LAPACK's Cholesky and a float64 solve do on the same inputs, CPU only.)"""
+    if not os.path.exists(FULL_PATH):
+        pytest.skip("tests/golden/config_oracle_full.npz absent: run scripts/make_config_fixtures.py")
+    full = np.load(FULL_PATH)
+    if name + "_x" not in full:
+        pytest.skip("configuration not in the fixture")
+    ids, params, reg, n_img, per, seed, _, _ = CONFIGS[name]
+    images, boxes, gt = synth.make_faces(n_img, seed=seed)
+    x_star, x0, idx = synth.make_samples(boxes, gt, ids, n_perturb=per - 1, seed=seed + 1)
+    digest = hashlib.sha1(images.tobytes() + x0.tobytes() + x_star.tobytes()).digest()
+    assert digest == full[name + "_sha1"].tobytes(), "the synthetic inputs differ from the fixture's"
+    want = full[name + "_x"]                       # [K][N][2L]: the oracle's x_1 .. x_K
+    assert want.shape == (len(params), x0.shape[0], x0.shape[1])
+    sdo = SupervisedDescentOptimiser([LinearRegressor(Regulariser(*reg)) for _ in params])
+    hog = HogTransform(images, [HoGParam(*p) for p in params], ids, ibug.RIGHT_EYE_IDS, ibug.LEFT_EYE_IDS, idx)
+    sdo._bind(hog, x0.shape[0])
+    c = sdo.ctx
+    c.set_templates(None)
+    c.set_targets(x_star)
+    c.set_allreduce(None, 1)
+    errs = []
+    for k in range(len(params)):
+        c.set_x(x0 if k == 0 else want[k - 1])                      # the oracle's landmarks entering level k
+        c.hog_features(k)
+        c.gram_rhs(k)
+        c.allreduce_gram_rhs()
+        c.solve(k, reg[0], reg[1], reg[2], x0.shape[0], fetch=False)
+        c.apply(k)
+        errs.append(rel_l2(c.get_x(), want[k]))
+    print(name, "teacher-forced rel-L2 per level:", " ".join("%.2e" % e for e in errs))
+    for k, e in enumerate(errs):
+        assert e < 1e-4, (name, k, errs)
+
+
 def test_rcr68_detect_shard_matches_oracle(built):
     """Config 4's path (RCR-68 detect, F = 27 201, M = 136) on 512 faces of a rank's shard, free-running, against the oracle
     running the same regressors; the 8 192-face run is recorded in profiles/r02_parity_configs.json."""

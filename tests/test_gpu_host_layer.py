@@ -32,7 +32,7 @@ def test_detect_reads_the_current_frame_and_keeps_regressors_resident(built):
     ctx = model.optimised_model.ctx
     uploads = []
     orig = ctx.set_regressor
-    ctx.set_regressor = lambda level, R: (uploads.append(level), orig(level, R))[1]
+    ctx.set_regressor = lambda level, R, **kw: (uploads.append(level), orig(level, R, **kw))[1]
     frame = np.empty_like(images[0])                     # ONE buffer, refilled per frame as a video loop does
     got = []
     for i in range(3):
@@ -44,10 +44,46 @@ def test_detect_reads_the_current_frame_and_keeps_regressors_resident(built):
     regs[1].x = regs[1].x * np.float32(0.5)              # a new matrix -> that level (only) goes up again
     model.detect(frame, boxes[2])
     assert uploads == [0, 1, 1]
-    regs[0].x[:] = 0.0                                   # in-place change + touch()
-    regs[0].touch()
+    with pytest.raises(ValueError):                      # a resident matrix is read-only: an in-place edit cannot go unnoticed
+        regs[0].x[:] = 0.0
+    with pytest.raises(ValueError):
+        regs[0].x *= np.float32(2.0)
+    regs[0].touch()                                      # touch() + in-place change
+    regs[0].x[:] = 0.0
     model.detect(frame, boxes[2])
     assert uploads == [0, 1, 1, 0]
+
+
+def test_two_optimisers_sharing_a_context_do_not_see_each_others_regressors(built):
+    """the record of what the device holds lives in the Context, names the array object and is replaced by
+    whoever writes the level."""
+    images, boxes, _ = synth.make_faces(2, seed=814)
+    model_a, regs_a = make_model(seed=1)
+    ctx = model_a.optimised_model.ctx
+    rng = np.random.default_rng(2)
+    regs_b = []
+    for _ in range(2):
+        r = LinearRegressor()
+        r.x = (rng.standard_normal((8801, 44)) * 0.003).astype(np.float32)
+        regs_b.append(r)
+    model_b = detection_model(SupervisedDescentOptimiser(regs_b, ctx=ctx), ibug.select_mean(IDS), IDS, model_a.hog_params,
+                              ibug.RIGHT_EYE_IDS, ibug.LEFT_EYE_IDS)
+    want_a = make_model(seed=1)[0].detect(images[0], boxes[0])
+    a1 = model_a.detect(images[0], boxes[0])
+    b1 = model_b.detect(images[0], boxes[0])             # same context, same geometry, other regressors
+    a2 = model_a.detect(images[0], boxes[0])             # must not run with B's coefficients
+    assert np.array_equal(a1, want_a) and np.array_equal(a2, want_a)
+    assert not np.array_equal(b1, a1)
+    # swapping in NEW regressor objects (whose id() may reuse a freed one's) is seen as well
+    opt = model_a.optimised_model
+    for l in range(2):
+        fresh = LinearRegressor()
+        fresh.x = regs_b[l].x.copy()
+        opt.regressors[l] = fresh
+    assert np.array_equal(model_a.detect(images[0], boxes[0]), b1)
+    # a direct Context.set_regressor by a third party invalidates the record too
+    ctx.set_regressor(0, np.zeros((8801, 44), np.float32))
+    assert np.array_equal(model_a.detect(images[0], boxes[0]), b1)
 
 
 def test_resident_images_are_an_explicit_opt_in(built):
