@@ -850,8 +850,10 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
             if (FASTBIN == 2 && TO == 4 && ACC == ACC_COLUMNS && SDM_EXP_BOOLBIN) {
                 // 4 orientations = 8 directed bins of 45 degrees: the three bits of the bin as lane masks (the compiler keeps
                 // them in scalar registers and combines them on the scalar unit), see bin_sector4_bits
-                bool b0, b1, b2;
-                bin_sector4_bits(gx, gy, lv, b0, b1, b2);
+                bool b0 = false, b1 = false, b2 = false;
+                int bin_any = 0;
+                if constexpr (TO == 4) bin_sector4_bits(gx, gy, lv, b0, b1, b2);
+                else bin_sector<TO>(gx, gy, lv, TO, bin_any);      // (a zero gradient lands in bin 0 with magnitude 0)
                 bin_off = (b0 ? col_off1 : col_off) + (b1 ? 2u * bin_stride : 0u) + (b2 ? 4u * bin_stride : 0u);
                 bin = 0;
             } else if (FASTBIN == 2) {
@@ -1218,7 +1220,8 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int O = TO, C = TC, CC = C * C;
     constexpr int ST = HP_ST;
-    static_assert(2 * TO <= 16 && SDM_PLAN_MAX_SEG * TC <= 16, "one 16 x 16 matrix-core tile: 2O bin rows, 3 patches x C cell columns");
+    static_assert(2 * TO <= 32 && SDM_PLAN_MAX_SEG * TC <= 16, "16 x 16 matrix-core tiles: 2O bin rows in one or two tiles, 3 patches x C cell columns");
+    constexpr int MT = (2 * TO + 15) / 16;        // row tiles of a band fold: 1 for 4 orientations, 2 for the 18 bin rows of "31-bin" HOG (hog.c:212-215)
     const int lane = threadIdx.x & 63;
     const int wave = uni(threadIdx.x >> 6);
     // XCD-aware remap (bijective): the workgroups the dispatcher places on XCD b % 8 take a contiguous run of groups, so the
@@ -1354,7 +1357,7 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
         const int* pinfo = plan.pass_info + pt * 4;
         const int sg = li < C ? 0 : (li < 2 * C ? 1 : (li < 3 * C ? 2 : 3));
         const int seg_slot = sg == 0 ? pinfo[0] : (sg == 1 ? pinfo[1] : (sg == 2 ? pinfo[2] : -1));
-        const bool recv = seg_slot >= 0 && lq < (2 * O + 3) / 4;           // rows 4 lq + e < 2O exist
+        const bool recv = seg_slot >= 0;                                   // (rows 16 mt + 4 lq + e >= 2O are skipped at the store)
         float* hrecv = hist + (seg_slot >= 0 ? hist_slot(seg_slot) : 0) * HSTR + (4 * lq) * CC + (li - sg * C);
         const int done = pinfo[3];
         const int nkp = (done >> 16) & 0xff;          // k-step pairs (8 lanes each) that hold columns in this pass
@@ -1397,20 +1400,33 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
             if (HP_ABL == 1) return;
             const int sl = b & 1;
             wave_sync();
-            f32x4 fa0 = {0.0f, 0.0f, 0.0f, 0.0f}, fa1 = fa0;
-            const float* ap = colrows + ((li < 2 * O ? li : 2 * O - 1) * ST + lq) * 2 + sl;
+            f32x4 fa0[MT], fa1[MT];
+            const float* ap[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                fa0[mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; fa1[mt] = fa0[mt];
+                ap[mt] = colrows + ((16 * mt + li < 2 * O ? 16 * mt + li : 2 * O - 1) * ST + lq) * 2 + sl;
+            }
             // the operand reads run two k-step pairs ahead of the products (the scheduling barriers keep that order: with the
             // reads serialised behind the products every fold cost eight LDS round trips)
-            float a0v[3], a1v[3];
+            float a0v[MT][3], a1v[MT][3];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) { a0v[i] = ap[16 * i]; a1v[i] = ap[16 * i + 8]; }
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { a0v[mt][i] = ap[mt][16 * i]; a1v[mt][i] = ap[mt][16 * i + 8]; }
 #pragma unroll
             for (int kp = 0; kp < 8; ++kp) {
-                if (kp + 2 < 8) { a0v[(kp + 2) % 3] = ap[16 * (kp + 2)]; a1v[(kp + 2) % 3] = ap[16 * (kp + 2) + 8]; }
+                if (kp + 2 < 8) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) { a0v[mt][(kp + 2) % 3] = ap[mt][16 * (kp + 2)]; a1v[mt][(kp + 2) % 3] = ap[mt][16 * (kp + 2) + 8]; }
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if (kp < 6 || kp < nkp) {      // (a 55-column pass leaves the last 8 lanes without a column: 14 products instead of 16)
-                    fa0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v[kp % 3], wq[(2 * kp) >> 2][(2 * kp) & 3], fa0, 0, 0, 0);
-                    fa1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v[kp % 3], wq[(2 * kp + 1) >> 2][(2 * kp + 1) & 3], fa1, 0, 0, 0);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        fa0[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v[mt][kp % 3], wq[(2 * kp) >> 2][(2 * kp) & 3], fa0[mt], 0, 0, 0);
+                        fa1[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v[mt][kp % 3], wq[(2 * kp + 1) >> 2][(2 * kp + 1) & 3], fa1[mt], 0, 0, 0);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1419,15 +1435,18 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
 #pragma unroll
             for (int k = 0; k < 2 * O; ++k) cz[k * ST * 2] = 0.0f;
             if (recv) {
-                float* hf = hrecv + b * C;
-                if (first_seen) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (4 * lq + e < 2 * O) hf[e * CC] = fa0[e] + fa1[e];
-                } else {
+                for (int mt = 0; mt < MT; ++mt) {
+                    float* hf = hrecv + b * C + 16 * mt * CC;
+                    if (first_seen) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (4 * lq + e < 2 * O) hf[e * CC] += fa0[e] + fa1[e];
+                        for (int e = 0; e < 4; ++e)
+                            if (16 * mt + 4 * lq + e < 2 * O) hf[e * CC] = fa0[mt][e] + fa1[mt][e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (16 * mt + 4 * lq + e < 2 * O) hf[e * CC] += fa0[mt][e] + fa1[mt][e];
+                    }
                 }
             }
             wave_sync();
@@ -1448,8 +1467,10 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
                 const float gy = r0 - rm2;
                 const float g2 = gx * gx + gy * gy;
                 const float gm = (HP_RAWSQRT && RAW) ? __builtin_amdgcn_sqrtf(g2) : sqrt_int_up(g2);
-                bool b0, b1, b2;
-                bin_sector4_bits(gx, gy, lv, b0, b1, b2);
+                bool b0 = false, b1 = false, b2 = false;
+                int bin_any = 0;
+                if constexpr (TO == 4) bin_sector4_bits(gx, gy, lv, b0, b1, b2);
+                else bin_sector<TO>(gx, gy, lv, TO, bin_any);      // (a zero gradient lands in bin 0 with magnitude 0)
                 if (HP_ABL == 3) { f32x2 dz = __builtin_elementwise_fma(pend_v, (f32x2){pend_g, pend_g}, qv); asm volatile("" :: "v"(dz), "v"(pend_p)); }
                 else if (HP_PKFMA) *pend_p = __builtin_elementwise_fma(pend_v, (f32x2){pend_g, pend_g}, qv);
                 else *pend_p = qv + pend_v;
@@ -1464,7 +1485,10 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
                     if (prev_by >= 0) fold_band(prev_by);
                     prev_by = cby;
                 }
-                pend_p = (lds_f32x2*)(size_t)((b0 ? cadr1 : cadr0) + ((b1 ? 2u * bin_stride : 0u) + (b2 ? 4u * bin_stride : 0u)));
+                if constexpr (TO == 4)
+                    pend_p = (lds_f32x2*)(size_t)((b0 ? cadr1 : cadr0) + ((b1 ? 2u * bin_stride : 0u) + (b2 ? 4u * bin_stride : 0u)));
+                else
+                    pend_p = (lds_f32x2*)(size_t)(cadr0 + (unsigned)bin_any * bin_stride);
                 if (HP_PKFMA) { pend_v = (f32x2){ws0, ws1}; pend_g = gm; }
                 else pend_v = (f32x2){ws0, ws1} * gm;
             }
@@ -1586,7 +1610,7 @@ int plan_pack(int S, int npatch, std::vector<std::vector<PlanLane>>& passes)
 bool sdm_hog_plan_build(const HogLevelDev& lv, int L, HogPlanHost& out)
 {
     out = HogPlanHost();
-    if (!(lv.O == 4 && lv.C == 5 && lv.cell <= 12 && lv.S >= 4 && lv.S <= 64 && L >= 1)) return false;
+    if (!((lv.O == 4 || lv.O == 9) && lv.C == 5 && lv.cell <= 12 && lv.S >= 4 && lv.S <= 64 && L >= 1)) return false;
     const int S = lv.S;
     for (int d = 0; d < S; ++d) {      // the specialised instances compute the band of a row in integers: must equal the table
         int b; memcpy(&b, &lv.row_tab[d][2], sizeof(int));
@@ -1655,10 +1679,20 @@ void sdm_launch_hog_packed(const ImageSetDev& imgs, const int* img_idx, const fl
     const long long total = (long long)N * gpf;
     if (total <= 0) return;
     const unsigned grid = (unsigned)((total + HP_WAVES - 1) / HP_WAVES);
-#define HP_LAUNCH(CELL, RAW)                                                                                                    \
-    hipLaunchKernelGGL((hog_packed_kernel<4, 5, CELL, RAW>), dim3(grid), dim3(HP_WAVES * 64),                                      \
-                       packed_wg_lds_bytes(5, 4, lv.S, plan.hist_slots, CELL > 0), stream, imgs, img_idx, x, N, L,                \
+#define HP_LAUNCH_O(TO, CELL, RAW)                                                                                              \
+    hipLaunchKernelGGL((hog_packed_kernel<TO, 5, CELL, RAW>), dim3(grid), dim3(HP_WAVES * 64),                                     \
+                       packed_wg_lds_bytes(5, TO, lv.S, plan.hist_slots, CELL > 0), stream, imgs, img_idx, x, N, L,               \
                        eyes, lv, plan, feat, ldf, idx_out, status)
+#define HP_LAUNCH(CELL, RAW) HP_LAUNCH_O(4, CELL, RAW)
+    if (lv.O == 9) {      // "31-bin" HOG (9 orientations, hog.c:212-215): 18 bin rows = two matrix-core row tiles per band fold
+        static unsigned long long attr9 = 0;
+        if (sdm_first_use_on_device(attr9)) {
+            SDM_SET_ATTR((const void*)hog_packed_kernel<9, 5, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            SDM_SET_ATTR((const void*)hog_packed_kernel<9, 5, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        }
+        if (plan.raw_sqrt) HP_LAUNCH_O(9, 0, true); else HP_LAUNCH_O(9, 0, false);
+        return;
+    }
     // instances specialised on the shipped cell sizes (apps/rcr/rcr-train.cpp:447: 11, 10, 8, 6); any other cell size, a level
     // whose v_sqrt_f32 verdict is negative, or SDM_HOG_NO_SPECIALISE=1 (A/B measurements) run the generic instance
     static const bool no_spec = getenv("SDM_HOG_NO_SPECIALISE") && getenv("SDM_HOG_NO_SPECIALISE")[0] == '1';
@@ -1672,6 +1706,7 @@ void sdm_launch_hog_packed(const ImageSetDev& imgs, const int* img_idx, const fl
     default: HP_LAUNCH(0, true); break;
     }
 #undef HP_LAUNCH
+#undef HP_LAUNCH_O
 }
 
 bool sdm_hog_fast_supported(const HogLevelDev& lv)

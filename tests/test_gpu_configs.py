@@ -88,6 +88,7 @@ def test_teacher_forced_training_level_by_level(built, name):
     sdo._bind(hog, x0.shape[0])
     c = sdo.ctx
     c.set_templates(None)
+    c.set_x(x0)
     c.set_targets(x_star)
     c.set_allreduce(None, 1)
     errs = []

@@ -78,6 +78,34 @@ def test_packed_other_cell_sizes(gpu_ctx, cell):
     assert np.abs(packed - plain).max() <= 2e-7
 
 
+@pytest.mark.parametrize("variant", [1, 0], ids=["uoctti31", "dalaltriggs36"])
+@pytest.mark.parametrize("level", [0, 1, 2, 3, 4])
+def test_packed_nine_orientations(gpu_ctx, level, variant):
+    """BASELINE config 3's geometry ("31-bin VlHog": 9 orientations, 18 directed bin rows = two matrix-core row tiles per band
+    fold, hog.c:212-215) runs on the packed kernel too: packed = plain = oracle, on patches that also leave
+    the image."""
+    cells = (11, 10, 8, 6, 6)
+    rels = (1.0, 0.7, 0.4, 0.25, 0.25)
+    hps = [HoGParam(variant, 5, c, 9, r) for c, r in zip(cells, rels)]
+    images, boxes, gt = synth.make_faces(48, seed=931)
+    _, x0, _ = synth.make_samples(boxes, gt, IDS22, n_perturb=0, seed=932)
+    x0[:4, :22] -= 140.0                                   # four faces pushed (partly) off the canvas
+    gpu_ctx.set_model_geometry(len(IDS22), RE22, LE22, hps)
+    from superviseddescent_amd.engine import hog_plan
+    assert hog_plan(5, cells[level], 9, len(IDS22)) is not None       # the level HAS a packed plan (no silent fall-back)
+    gpu_ctx.upload_images(images)
+    gpu_ctx.set_sample_image_index(None)
+    gpu_ctx.set_x(x0)
+    packed, pidx, plain, qidx = both_launches(gpu_ctx, level)
+    ofeat, oidx = orc.hog_features_batch(images, None, x0, RE22, LE22, orc.HoGParam(variant, 5, cells[level], 9, rels[level]),
+                                         n_threads=os.cpu_count() or 1, want_idx=True)
+    assert packed.shape[1] == 22 * 25 * (31 if variant == 1 else 36) + 1
+    assert np.array_equal(pidx, oidx) and np.array_equal(qidx, oidx)
+    assert (packed[:, -1] == 1.0).all()
+    assert np.abs(packed - plain).max() <= 2e-7
+    assert np.abs(packed - ofeat).max() <= 1e-6 and rel_l2(packed, ofeat) <= 5e-7
+
+
 def test_packed_on_the_black_canvas(gpu_ctx):
     """Patches straddling or leaving the image: every lane applies the borders of ITS patch (columns by zero weights, rows
     by the buffer range check); Dalal-Triggs variant on the side."""

@@ -124,4 +124,10 @@ def test_plan_packs_the_shipped_levels(built):
     assert (got[10]["G"], got[10]["P"]) == (5, 4)           # five 50-column patches in four passes
     assert (got[8]["G"], got[8]["P"]) == (3, 2)             # three 40-column patches in two passes
     assert (got[6]["G"], got[6]["P"]) == (2, 1)             # 30 columns: two patches per pass
-    assert hog_plan(5, 11, 9, 22) is None                   # 9 orientations: no packed instance (18 bin rows > one 16-row tile)
+    # 9 orientations ("31-bin" HOG, hog.c:212-215): packed since round 3 -- the lane plan does not depend on the orientation count
+    # (18 bin rows are two matrix-core row tiles of the band fold), so it is the 4-orientation plan of the same cell size
+    for cell in (11, 10, 8, 6):
+        p9 = hog_plan(5, cell, 9, 22)
+        assert p9 is not None and (p9["G"], p9["P"]) == (got[cell]["G"], got[cell]["P"])
+        assert np.array_equal(p9["lane_tab"], got[cell]["lane_tab"]) and np.array_equal(p9["wb"], got[cell]["wb"])
+    assert hog_plan(5, 11, 6, 22) is None                   # 6 orientations: no packed instance (its sector shortcut fails the exhaustive check)
