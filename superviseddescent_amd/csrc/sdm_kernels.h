@@ -174,7 +174,7 @@ void sdm_launch_add_diag(float* G, long long ldg, int F, const double* fro2, int
 
 // Blocked Cholesky G = U^T U on the upper triangle of the leading F x F block, with the
 // forward substitution fused into the panel updates for the extra columns [rhs0, rhs0+nrhs),
-// then back substitution; R_out [F][ldr].  work: >= 2*NB*NB floats.
+// then back substitution; R_out [F][ldr].  work: ceil(F/128) * 128 * 128 floats (inverted diagonal tiles) + 2048 (flags).
 // hipFuncSetAttribute (dynamic LDS above 64 KB) is per device: true the first time a call site runs on the current one
 inline bool sdm_first_use_on_device(unsigned long long& seen)
 {

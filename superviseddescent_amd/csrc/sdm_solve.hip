@@ -18,6 +18,7 @@
 //
 // Only 128 x 128 tiles with tile-row <= tile-column are computed and stored (upper triangle).
 #include "sdm_kernels.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -737,6 +738,115 @@ backsolve_step_kernel(float* __restrict__ G, long long ldg, int k0, int rhs0, co
             }
 }
 
+
+// ---- back substitution in ONE launch (round 3) -------------------------------------------------------
+// One persistent workgroup per tile row i (and per chunk of <= 5 right-hand-side column tiles).  Y_i lives in the matrix-core
+// accumulators of its 8 waves for the whole solve: for k = T-1 ... i+1 the workgroup waits for R_k (a flag in global memory,
+// published by workgroup k), multiplies it by U_ik (fetched into registers while the previous product ran) and subtracts; then
+// R_i = U_ii^-1 Y_i from the stored transposed inverse, stored, fenced, flagged.  Workgroups are numbered so that tile row
+// T-1 is dispatched first: a workgroup only ever waits for workgroups dispatched BEFORE it, so the kernel cannot deadlock even
+// when the grid does not fit the chip; the spin is bounded all the same (status bit 4 instead of a hung GPU).
+// Measured (rocprofv3 kernel trace, F = 8 801, 44 right-hand sides): 1.19 ms for the 69 steps = 17 us per step -- the release /
+// acquire round trip through memory, the R_k fetch and the two products -- against 69 launches x 19.9 us = 1.38 ms; F = 27 201,
+// 136 right-hand sides (two column chunks side by side): factor + solve 86.6 -> 83.1 ms.
+#define BSP_WAVES 8
+#define BSP_SPIN_LIMIT (1 << 22)
+template <int NJ>
+__global__ void __launch_bounds__(BSP_WAVES * 64)
+backsolve_persistent_kernel(const float* __restrict__ G, long long ldg, int Tf, int rhs0, int nrhs, const float* __restrict__ winv_t,
+                            float* __restrict__ R, long long ldr, int* __restrict__ flags, int* __restrict__ status)
+{
+    constexpr int ncb = NJ * 16;                       // columns of this chunk
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* A = sm;                                     // [128][128 + 4]: -U_ik (row-major), at the end W_i^T (k-major)
+    float* Bk = sm + TILE * (TILE + 4);                // [128][ncb]: R_k, at the end Y_i
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int i = Tf - 1 - (int)blockIdx.x;            // tile row of this workgroup
+    const int col0 = (int)blockIdx.y * ncb;            // first right-hand-side column of this chunk
+    int* flag = flags + (size_t)blockIdx.y * Tf;
+    const long long i0 = (long long)i * TILE;
+    const int lr = t >> 5, lc = (t & 31) * 4;          // staging: thread -> rows lr + 16 q, columns lc .. lc + 3
+    // Y_i into the accumulators: wave w owns rows 16 w .. 16 w + 15; C/D layout row = 4 lq + e, col = li
+    f32x4 acc[NJ];
+    const float* Yg = G + i0 * ldg + rhs0 + col0;
+#pragma unroll
+    for (int b = 0; b < NJ; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[b][e] = Yg[(long long)(16 * wave + 4 * lq + e) * ldg + 16 * b + li];
+    f32x4s pre[TILE / 16];
+    auto fetch_tile = [&](const float* src, long long ld) {
+#pragma unroll
+        for (int q = 0; q < TILE / 16; ++q) pre[q] = *(const f32x4s*)(src + (long long)(lr + 16 * q) * ld + lc);
+    };
+    if (i < Tf - 1) fetch_tile(G + i0 * ldg + (long long)(Tf - 1) * TILE, ldg);
+    else fetch_tile(winv_t + (size_t)i * TILE * TILE, TILE);
+    for (int k = Tf - 1; k > i; --k) {
+        if (t == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(&flag[k], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > BSP_SPIN_LIMIT) { atomicOr(status, 4); break; }
+            }
+        }
+        __syncthreads();                                               // R_k is published (and the previous product has left A / Bk)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // -U_ik -> A, R_k -> Bk
+#pragma unroll
+        for (int q = 0; q < TILE / 16; ++q) *(f32x4s*)(A + (lr + 16 * q) * (TILE + 4) + lc) = -pre[q];
+        const float* Rk = R + (long long)k * TILE * ldr + col0;
+        for (int idx = t; idx < TILE * ncb; idx += BSP_WAVES * 64) {
+            const int r = idx / ncb, cc = idx - r * ncb;
+            Bk[idx] = (col0 + cc < nrhs) ? Rk[(long long)r * ldr + cc] : 0.0f;
+        }
+        __syncthreads();
+        // the next operand's memory round trip runs under this product
+        if (k - 1 > i) fetch_tile(G + i0 * ldg + (long long)(k - 1) * TILE, ldg);
+        else fetch_tile(winv_t + (size_t)i * TILE * TILE, TILE);
+#pragma unroll 4
+        for (int kk = 0; kk < TILE / 4; ++kk) {
+            const int m = 4 * kk + lq;
+            const float av = A[(16 * wave + li) * (TILE + 4) + m];
+            float bv[NJ];
+#pragma unroll
+            for (int b = 0; b < NJ; ++b) bv[b] = Bk[m * ncb + 16 * b + li];
+#pragma unroll
+            for (int b = 0; b < NJ; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[b], acc[b], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    // R_i[r][c] = sum_m W^T[m][r] Y_i[m][c]: W_i^T -> A (k-major as stored), Y_i -> Bk
+#pragma unroll
+    for (int q = 0; q < TILE / 16; ++q) *(f32x4s*)(A + (lr + 16 * q) * (TILE + 4) + lc) = pre[q];
+#pragma unroll
+    for (int b = 0; b < NJ; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Bk[(16 * wave + 4 * lq + e) * ncb + 16 * b + li] = acc[b][e];
+    __syncthreads();
+    f32x4 r4[NJ];
+#pragma unroll
+    for (int b = 0; b < NJ; ++b) r4[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int kk = 0; kk < TILE / 4; ++kk) {
+        const int m = 4 * kk + lq;
+        const float av = A[m * (TILE + 4) + 16 * wave + li];
+        float bv[NJ];
+#pragma unroll
+        for (int b = 0; b < NJ; ++b) bv[b] = Bk[m * ncb + 16 * b + li];
+#pragma unroll
+        for (int b = 0; b < NJ; ++b) r4[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[b], r4[b], 0, 0, 0);
+    }
+    float* Ri = R + i0 * ldr + col0;
+#pragma unroll
+    for (int b = 0; b < NJ; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (col0 + 16 * b + li < nrhs) Ri[(long long)(16 * wave + 4 * lq + e) * ldr + 16 * b + li] = r4[b][e];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                     // every thread's stores, before the flag
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(&flag[i], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 }  // namespace
 
 void sdm_launch_syrk_tn(const float* A, long long lda, int rows, int ncols, float* C, long long ldc,
@@ -939,6 +1049,26 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
     }
     if (tail_pending) (void)hipStreamWaitEvent(stream, aux->tail_done, 0);
     const int nj = nrhs / 16;   // nrhs is a multiple of 16, <= 144
+    static const bool bs_steps = getenv("SDM_BACKSOLVE_STEPS") && getenv("SDM_BACKSOLVE_STEPS")[0] == '1';   // (A/B: the round-2 launch per step)
+    if (!bs_steps) {
+        // one persistent launch: Tf workgroups x chunks of <= 5 column tiles; flags (one int per tile row and chunk) behind the
+        // inverses in `work`, cleared on the stream
+        const int nchunks = (nj + 4) / 5, NJ = (nj + nchunks - 1) / nchunks;
+        int* flags = (int*)(work + (size_t)Tf * TILE * TILE);
+        (void)hipMemsetAsync(flags, 0, (size_t)nchunks * Tf * sizeof(int), stream);
+        static unsigned long long attr_bsp = 0;
+        if (sdm_first_use_on_device(attr_bsp)) {
+#define BSPATTR(NJv) SDM_SET_ATTR((const void*)backsolve_persistent_kernel<NJv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+            BSPATTR(1); BSPATTR(2); BSPATTR(3); BSPATTR(4); BSPATTR(5);
+#undef BSPATTR
+        }
+#define BSP(NJv) hipLaunchKernelGGL(backsolve_persistent_kernel<NJv>, dim3(Tf, nchunks), dim3(BSP_WAVES * 64),                         \
+                                    ((size_t)TILE * (TILE + 4) + (size_t)TILE * NJv * 16) * sizeof(float), stream, G, ldg, Tf, rhs0, nrhs, \
+                                    work, R_out, ldr, flags, status)
+        switch (NJ) { case 1: BSP(1); break; case 2: BSP(2); break; case 3: BSP(3); break; case 4: BSP(4); break; default: BSP(5); break; }
+#undef BSP
+        return 0;
+    }
     for (int k = Tf - 1; k >= 0; --k) {
         float* wk = work + (size_t)k * TILE * TILE;
 #define BS(NJv, C0) hipLaunchKernelGGL(backsolve_step_kernel<NJv>, dim3(k + 1), dim3(256), \

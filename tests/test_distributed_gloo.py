@@ -131,7 +131,8 @@ def test_two_rank_training_equals_single_process(tmp_path):
         assert np.array_equal(r0[f"R{lvl}"], r1[f"R{lvl}"])
         # ... which is the single-process one up to the summation order of the Gram matrix
         ref = single[f"R{lvl}"]
-        assert np.linalg.norm(r0[f"R{lvl}"] - ref) / np.linalg.norm(ref) < 2e-3
-        assert r0["lam"][lvl] == pytest.approx(single["lam"][lvl], rel=1e-5)
+        # (measured 7.7e-6 / 9.9e-6: two f32 partial Gram sums added in f32 instead of one sgemm; lambda 9e-8 / 0)
+        assert np.linalg.norm(r0[f"R{lvl}"] - ref) / np.linalg.norm(ref) < 5e-5
+        assert r0["lam"][lvl] == pytest.approx(single["lam"][lvl], rel=1e-6)
     x = np.concatenate([r0["x"], r1["x"]])
-    assert np.linalg.norm(x - single["x"]) / np.linalg.norm(single["x"]) < 1e-5
+    assert np.linalg.norm(x - single["x"]) / np.linalg.norm(single["x"]) < 1e-6      # (measured 1.8e-8)

@@ -197,3 +197,83 @@ def test_sharding_registration_is_validated_and_collective_failures_surface(buil
     R, lam = ctx.solve(0, reg[0], reg[1], reg[2], n_train_global=0)
     assert np.isfinite(R).all() and lam == reg[1]
     ctx.close()
+
+
+def _allreduce_of(group, rank):
+    """sum over the ranks of a packed {Gram || RHS} buffer, in place, every rank adding the buffers in rank order (so all ranks
+    hold bit-identical sums, as after an RCCL all-reduce): stream sync + barrier + device-to-device adds."""
+    def fn(ptr, count, stream):
+        torch = group.torch
+        st = group._stream(stream)
+        st.synchronize()
+        group.slots[rank] = ptr
+        group.barrier.wait()
+        with torch.cuda.stream(st):
+            total = group._view(group.slots[0], count).clone()
+            for r in range(1, group.world):
+                total += group._view(group.slots[r], count)
+        st.synchronize()
+        group.barrier.wait()                  # everybody has read everybody's buffer
+        with torch.cuda.stream(st):
+            group._view(ptr, count).copy_(total)
+        st.synchronize()
+        group.calls[rank]["allreduce"] = group.calls[rank].get("allreduce", 0) + 1
+        return 0
+    return fn
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_train_path_two_ranks_at_the_shipped_size(built, world):
+    """the code an N-GPU run of bench.py executes -- SupervisedDescentOptimiser.train with an all-reduce
+    callback, the global row count, rank + sharded-solve collectives -- exercised at the REAL size of the bench model (RCR-22,
+    shipped geometry, F = 8 801: 69 factor tiles, look-ahead over two queues) with `world` ranks as threads on one GPU.
+    Every rank must end up with bit-identical regressors, equal to single-context training on all rows up to the summation
+    order of the Gram matrix, and its rows' landmarks must be the single-context ones within the north-star tolerance."""
+    from superviseddescent_amd import HogTransform, LinearRegressor, Regulariser, SupervisedDescentOptimiser, parallel
+    ids = ibug.RCR22_IDS
+    params = [HoGParam(*p) for p in ibug.SHIPPED_HOG_PARAMS[:2]]
+    images, boxes, gt = synth.make_faces(120, seed=7101)
+    x_star, x0, idx = synth.make_samples(boxes, gt, ids, n_perturb=9, seed=7102)          # 1 200 rows
+    N = x0.shape[0]
+    reg = lambda: Regulariser(Regulariser.RegularisationType.MatrixNorm, 1.5, False)      # bench.py / rcr-train.cpp:440-443
+    single = SupervisedDescentOptimiser([LinearRegressor(reg()) for _ in params])
+    x_single = single.train(x_star, x0, None, HogTransform(images, params, ids, ibug.RIGHT_EYE_IDS, ibug.LEFT_EYE_IDS, idx))
+    assert single.regressors[0].x.shape == (8801, 44)
+
+    group = LocalGroup(world)
+    out, errors = [None] * world, [None] * world
+
+    def work(rank):
+        try:
+            a, b = parallel.shard_range(N, rank, world)
+            imgs = sorted(set(int(i) for i in idx[a:b]))            # every rank owns the images of ITS rows only
+            remap = {g: k for k, g in enumerate(imgs)}
+            local_idx = np.array([remap[int(i)] for i in idx[a:b]], np.int32)
+            sdo = SupervisedDescentOptimiser([LinearRegressor(reg()) for _ in params])
+            hog = HogTransform(images[imgs], params, ids, ibug.RIGHT_EYE_IDS, ibug.LEFT_EYE_IDS, local_idx)
+            x = sdo.train(x_star[a:b], x0[a:b], None, hog, allreduce=_allreduce_of(group, rank), world_size=world,
+                          n_train_global=N, rank=rank, solve_collectives=(group.bcast(rank), group.allgather(rank)))
+            out[rank] = (x, [r.x.copy() for r in sdo.regressors], [r.last_lambda for r in sdo.regressors], (a, b))
+            sdo.ctx.close()
+        except Exception as e:  # noqa: BLE001
+            errors[rank] = e
+            group.barrier.abort()
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert errors == [None] * world, errors
+    for lvl in range(len(params)):
+        for rank in range(1, world):
+            assert np.array_equal(out[rank][1][lvl].view(np.uint32), out[0][1][lvl].view(np.uint32)), (lvl, rank)
+            assert out[rank][2][lvl] == out[0][2][lvl]
+        assert out[0][2][lvl] == pytest.approx(single.regressors[lvl].last_lambda, rel=1e-5)        # global ||G||_F and row count
+    x_all = np.concatenate([out[r][0] for r in range(world)])
+    assert [out[r][3] for r in range(world)] == [parallel.shard_range(N, r, world) for r in range(world)]
+    rel = float(np.linalg.norm((x_all - x_single).astype(np.float64)) / np.linalg.norm(x_single.astype(np.float64)))
+    print("bench train path, %d ranks on one GPU: landmarks vs single context %.2e" % (world, rel))
+    assert rel < 1e-4
+    for rank in range(world):
+        assert group.calls[rank]["allreduce"] == len(params)
+        assert group.calls[rank]["bcast"] == 69 * len(params) and group.calls[rank]["allgather"] == 18 * len(params)
