@@ -333,14 +333,19 @@ def main():
         ent = tj["kernels"][hog_kernel]
         if int(tj.get("batch", 0)) == args.batch:
             traffic, traffic_src = float(ent["bytes_per_launch"]), "committed-profile: profiles/hbm_traffic.json (" + tj["source"] + ")"
-            # what actually limits this kernel is instruction issue: SIMD-cycles per wave-instruction over the launch
+            # vector-unit occupancy of the launch from the same PMC passes: SQ_ACTIVE_INST_VALU counts quad-cycles summed over the
+            # waves; x 4 / (1024 SIMDs x launch cycles) = the fraction of SIMD cycles with a vector instruction executing
             simd_cycles = 256 * 4 * 2.4e9 * hog_avg_ms * 1e-3
             valu_issue = {"valu_insts_per_launch": float(ent["SQ_INSTS_VALU"]), "salu_insts_per_launch": float(ent.get("SQ_INSTS_SALU", 0.0)),
                           "simd_cycles_per_valu_inst": simd_cycles / float(ent["SQ_INSTS_VALU"]),
                           "valu_insts_per_patch": float(ent["SQ_INSTS_VALU"]) / (args.batch * L),
-                          "note": "measured issue cost per wave-instruction on gfx950 (profiles/r02_ubench_valu_rates.txt): ~2.7 cycles "
-                                  "for 2-operand add/mul/logic, ~4.4 for VOP3 / compares / conversions / DPP / 24-bit multiplies, 8.3 for "
-                                  "v_sqrt_f32, 16.4 for f64 transcendentals; a scalar instruction beside each vector one costs ~2 more"}
+                          "frac": (4.0 * float(ent["SQ_ACTIVE_INST_VALU"]) / simd_cycles) if "SQ_ACTIVE_INST_VALU" in ent else None,
+                          "lds_bank_conflict_ratio": (float(ent["SQ_LDS_BANK_CONFLICT"]) / float(ent["SQ_LDS_IDX_ACTIVE"]))
+                          if "SQ_LDS_IDX_ACTIVE" in ent and ent["SQ_LDS_IDX_ACTIVE"] else None,
+                          "note": "frac = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x 2.4 GHz x this run's average launch time), counters from the "
+                                  "committed profile of the same command; round 3 measured that the launch time does not follow the "
+                                  "instruction count (-8 % vector, -33 % scalar instructions: +-0 % time, profiles/r03_hog_experiments.txt), "
+                                  "so this is an occupancy figure, not a bound"}
     except (OSError, KeyError, ValueError, ZeroDivisionError):
         pass
 
@@ -377,8 +382,9 @@ def main():
             "traffic_source": traffic_src,
             "valu_issue": valu_issue,
             "algorithmic_bytes_per_launch": bytes_per_launch,
-            "note": "the kernel is instruction-issue bound, not HBM bound (bit-exact integer resize + IEEE sqrt + reference binning "
-                    "cost ~37 vector instructions per pixel row): see valu_issue; HBM traffic is at or below the algorithmic bytes",
+            "note": "not HBM bound (traffic = 1.1 x the algorithmic bytes) and not instruction-issue bound either: ~33 vector instructions "
+                    "per pixel row (bit-exact integer resize, sqrt, reference binning, LDS column sums), vector units ~70 % busy; what "
+                    "removing each phase buys is in profiles/r03_hog_experiments.txt",
             "avg_launch_ms": hog_avg_ms,
             "launches": hog_n,
         },

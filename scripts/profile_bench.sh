@@ -7,7 +7,7 @@ REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/profile_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 20 --warmup 2 --no-cpu --train-rows 20000"
+CMD="python $REPO/bench.py --steps 20 --warmup 2 --no-cpu --train-rows 20000 --rcr68-shard 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $CMD > $OUT/bench_under_trace.json 2> $OUT/trace_stderr.log
 cp $OUT/trace/t_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 i=0
@@ -16,13 +16,41 @@ for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GR
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $OUT/p$i -o pmc -- $CMD > /dev/null 2> $OUT/p${i}_stderr.log
 done
+# the full default command (RCR-22 headline + RCR-68 train 100k rows + RCR-68 detect shard): kernel stats only
+CMD68="python $REPO/bench.py --steps 20 --warmup 2 --no-cpu"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace68 -o t -- $CMD68 > $OUT/bench_full_under_trace.json 2> $OUT/trace68_stderr.log
+python - <<PY
+import csv, glob, collections, re
+out="$OUT"
+def short(n):
+    m=re.search(r'(\w+_kernel)', n); return m.group(1) if m else n.split("(")[0][:40]
+try:
+    with open(out+"/summary_full_bench.txt","w") as fh:
+        fh.write("== rocprofv3 --kernel-trace --stats : python bench.py --steps 20 --warmup 2 --no-cpu  (RCR-22 train 100k + detect 4096, RCR-68 train 100k + detect 8192) ==\n")
+        fh.write("%-32s %7s %13s %11s %7s\n" % ("kernel","calls","total_us","avg_us","%"))
+        for r in list(csv.DictReader(open(out+"/trace68/t_kernel_stats.csv")))[:18]:
+            fh.write("%-32s %7s %13.1f %11.2f %7.2f\n" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"])/1e3, float(r["AverageNs"])/1e3, float(r["Percentage"])))
+        geo=collections.defaultdict(list)
+        for f in glob.glob(out+"/trace68/*kernel_trace.csv"):
+            for r in csv.DictReader(open(f)):
+                k=short(r["Kernel_Name"])
+                if k in ("hog_packed_kernel","apply_partial_kernel","apply_tiled_kernel","apply_reduce_kernel","syrk_tn_glds_kernel","backsolve_persistent_kernel","potrf_tile_kernel","trsm_tile_kernel"):
+                    geo[(k,"x".join(r.get(c,"?") for c in ("Grid_Size_X","Grid_Size_Y","Grid_Size_Z")))].append((float(r["End_Timestamp"])-float(r["Start_Timestamp"]))/1e3)
+        fh.write("\n== by launch geometry (avg over dispatches) ==\n%-32s %16s %7s %11s\n" % ("kernel","grid","calls","avg_us"))
+        for (k,g),v in sorted(geo.items(), key=lambda kv:(kv[0][0],-len(kv[1]))):
+            if len(v)>=4 or k=="syrk_tn_glds_kernel": fh.write("%-32s %16s %7d %11.2f\n" % (k,g,len(v),sum(v)/len(v)))
+    print(open(out+"/summary_full_bench.txt").read())
+except Exception as e:
+    print("full-bench summary failed:", e)
+PY
+rm -rf $OUT/trace68/*kernel_trace.csv
 python - <<PY
 import csv, glob, collections, re
 out="$OUT"
 def short(n):
     m=re.search(r'(\w+_kernel)', n); return m.group(1) if m else n.split("(")[0][:40]
 with open(out+"/summary.txt","w") as fh:
-    fh.write("== rocprofv3 --kernel-trace --stats : python bench.py --steps 20 --warmup 2 --no-cpu --train-rows 20000 ==\n")
+    fh.write("== rocprofv3 --kernel-trace --stats : python bench.py --steps 20 --warmup 2 --no-cpu --train-rows 20000 --rcr68-shard 0 ==\n")
     fh.write("%-28s %7s %13s %11s %7s\n" % ("kernel","calls","total_us","avg_us","%"))
     for r in list(csv.DictReader(open(out+"/kernel_stats.csv")))[:14]:
         fh.write("%-28s %7s %13.1f %11.2f %7.2f\n" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"])/1e3, float(r["AverageNs"])/1e3, float(r["Percentage"])))
@@ -76,6 +104,6 @@ for k,v in rows.items():
                                    "launch_geometry": k.split(" grid=")[1], "dispatches": cnt[(k,"FETCH_SIZE")]}
         for c in ("SQ_INSTS_VALU","SQ_INSTS_SALU","SQ_INSTS_LDS","SQ_WAVES","SQ_ACTIVE_INST_VALU","SQ_LDS_BANK_CONFLICT","SQ_LDS_IDX_ACTIVE","SQ_VALU_MFMA_BUSY_CYCLES","SQ_BUSY_CYCLES","GRBM_GUI_ACTIVE"):
             if c in v: hbm[k.split(" grid=")[0]][c]=v[c]/cnt[(k,c)]
-json.dump({"batch": 4096, "source": "scripts/profile_bench.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of python bench.py --steps 20 --warmup 2 --no-cpu --train-rows 20000; FETCH_SIZE x2 (gfx950), KB units", "kernels": hbm}, open(out+"/hbm_traffic.json","w"), indent=1)
+json.dump({"batch": 4096, "source": "scripts/profile_bench.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of python bench.py --steps 20 --warmup 2 --no-cpu --train-rows 20000 --rcr68-shard 0; FETCH_SIZE x2 (gfx950), KB units", "kernels": hbm}, open(out+"/hbm_traffic.json","w"), indent=1)
 print(open(out+"/summary.txt").read())
 PY
