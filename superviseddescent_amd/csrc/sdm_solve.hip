@@ -249,36 +249,40 @@ syrk_tn_glds_kernel(const float* __restrict__ A, long long lda, int rows, float*
 // ---- the Gram instance (round 3): EIGHT waves per 128 x 128 tile -- wave = (32-row strip wr of 4) x (64-column half wc of 2), two
 // 32 x 32 matrix-core tiles each -- i.e. four waves per SIMD at two workgroups per CU instead of two: more threads to cover the
 // fragment reads and the per-slab barrier.  Same staging, same order of summation per element (bit-identical sums), same two-level
-// accumulation.  68.4 -> 66.8 ms at 100 000 rows x 8 801 features (119.0 -> 121.8 TF executed, 77.4 % of the f32 matrix-core peak).
-__global__ void __launch_bounds__(512)
-syrk_tn_glds8_kernel(const float* __restrict__ A, long long lda, int rows, float* __restrict__ C, long long ldc,
+// accumulation.  68.4 -> 66.8 ms at 100 000 rows x 8 801 features (119.0 -> 121.8 TF executed, 77.4 % of the f32 matrix-core peak);
+// sixteen waves (one tile each, NW = 16) measure the same as eight: 66.5 - 66.6 ms.
+template <int NW>      // waves per tile: 8 (wave = 32-row strip x 64-column half, two matrix-core tiles) or 16 (32 x 32, one tile)
+__global__ void __launch_bounds__(NW * 64)
+syrk_tn_gldsw_kernel(const float* __restrict__ A, long long lda, int rows, float* __restrict__ C, long long ldc,
                      float alpha, int accumulate, int tile_i0, int own_first, int own_stride)
 {
+    constexpr int NN = NW == 8 ? 2 : 1;               // column tiles per wave
+    constexpr int RPI = NW * 2;                       // slab rows one staging instruction of the workgroup covers
     const int ti = blockIdx.y + tile_i0, tj = tile_i0 + own_first + blockIdx.x * own_stride;
     if (tj < ti) return;
     extern __shared__ __attribute__((aligned(16))) float glds[];      // [2 buffers][A | B][SYRK_GBK][TILE]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = NW == 8 ? wave >> 1 : wave >> 2, wc = NW == 8 ? wave & 1 : wave & 3;
     const bool diag = (ti == tj);
     const float* Ai = A + (long long)ti * TILE;
     const float* Aj = A + (long long)tj * TILE;
-    f32x16 acc[2], tot[2];
+    f32x16 acc[NN], tot[NN];
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int n = 0; n < NN; ++n)
 #pragma unroll
         for (int e = 0; e < 16; ++e) { acc[n][e] = 0.0f; tot[n][e] = 0.0f; }
-    // thread t fetches float4 number (t % 32) of slab rows t/32 + 16p; a wave's 64 lanes cover rows 2w + 16p, 2w + 16p + 1
+    // thread t fetches float4 number (t % 32) of slab rows t/32 + RPI p; a wave's 64 lanes cover rows 2w + RPI p, 2w + RPI p + 1
     const int lrow = t >> 5, lcol = (t & 31) * 4;
     auto issue = [&](int s, int buf) {
         float* a = glds + (size_t)buf * 2 * SYRK_GBK * TILE;
         float* b = a + SYRK_GBK * TILE;
 #pragma unroll
-        for (int p = 0; p < SYRK_GBK / 16; ++p) {
-            const long long n = (long long)s * SYRK_GBK + lrow + 16 * p;
-            float* la = a + (2 * wave + 16 * p) * TILE;
+        for (int p = 0; p < SYRK_GBK / RPI; ++p) {
+            const long long n = (long long)s * SYRK_GBK + lrow + RPI * p;
+            float* la = a + (2 * wave + RPI * p) * TILE;
             __builtin_amdgcn_global_load_lds(Ai + n * lda + lcol, (__attribute__((address_space(3))) void*)la, 16, 0, 0);
             if (!diag) {
-                float* lb = b + (2 * wave + 16 * p) * TILE;
+                float* lb = b + (2 * wave + RPI * p) * TILE;
                 __builtin_amdgcn_global_load_lds(Aj + n * lda + lcol, (__attribute__((address_space(3))) void*)lb, 16, 0, 0);
             }
         }
@@ -297,25 +301,25 @@ syrk_tn_glds8_kernel(const float* __restrict__ A, long long lda, int rows, float
             for (int kk = 0; kk < SYRK_GBK; kk += 2) {
                 const int k = kk + (lane >> 5);
                 const float a = As[k][wr * 32 + (lane & 31)];
-                float b[2];
+                float b[NN];
 #pragma unroll
-                for (int n = 0; n < 2; ++n) b[n] = Bp[k][wc * 64 + n * 32 + (lane & 31)];
+                for (int n = 0; n < NN; ++n) b[n] = Bp[k][wc * 32 * NN + n * 32 + (lane & 31)];
 #pragma unroll
-                for (int n = 0; n < 2; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[n], acc[n], 0, 0, 0);
+                for (int n = 0; n < NN; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[n], acc[n], 0, 0, 0);
             }
         }
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < NN; ++n)
 #pragma unroll
             for (int e = 0; e < 16; ++e) { tot[n][e] += acc[n][e]; acc[n][e] = 0.0f; }
     }
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int n = 0; n < NN; ++n)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int r = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
             const long long gi = (long long)ti * TILE + wr * 32 + r;
-            const long long gj = (long long)tj * TILE + wc * 64 + n * 32 + (lane & 31);
+            const long long gj = (long long)tj * TILE + wc * 32 * NN + n * 32 + (lane & 31);
             float* p = C + gi * ldc + gj;
             float v = alpha * tot[n][e];
             if (accumulate) v += *p;
@@ -961,9 +965,10 @@ void sdm_launch_syrk_tn(const float* A, long long lda, int rows, int ncols, floa
         static const bool w8 = !(getenv("SDM_GRAM_W4") && getenv("SDM_GRAM_W4")[0] == '1');      // (SDM_GRAM_W4=1: the four-wave instance, A/B)
         if (chunked && w8) {
             static unsigned long long attr8 = 0;
-            if (sdm_first_use_on_device(attr8))
-                sdm_check_launch_attr(hipFuncSetAttribute((const void*)syrk_tn_glds8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "syrk_tn_glds8_kernel");
-            hipLaunchKernelGGL(syrk_tn_glds8_kernel, dim3(Tx, Ty), dim3(512), lds, stream, A, lda, rows, C, ldc, alpha, accumulate, tile_i0, first, W);
+            if (sdm_first_use_on_device(attr8)) {
+                sdm_check_launch_attr(hipFuncSetAttribute((const void*)syrk_tn_gldsw_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "syrk_tn_gldsw_kernel<8>");
+            }
+            hipLaunchKernelGGL(syrk_tn_gldsw_kernel<8>, dim3(Tx, Ty), dim3(512), lds, stream, A, lda, rows, C, ldc, alpha, accumulate, tile_i0, first, W);
         } else if (chunked)
             hipLaunchKernelGGL(syrk_tn_glds_kernel<true>, dim3(Tx, Ty), dim3(256), lds, stream, A, lda, rows, C, ldc, alpha, accumulate, tile_i0, first, W);
         else
