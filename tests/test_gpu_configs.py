@@ -6,12 +6,20 @@ the full numbers of that run are in profiles/r02_parity_configs.json):
   rcr22     RCR-22 train at the shipped geometry (F = 8 801), MatrixNorm 1.5, 10 000 rows
   rcr68t    RCR-68 train (F = 27 201, two RHS tiles), 4 000 rows
 
-The cascades run FREE: from level 1 on the two sides no longer see identical inputs, and the GPU solves with Cholesky on an
-MFMA Gram matrix where the oracle (like the reference) uses LU -- two float32 solutions of normal equations that are
-rank-deficient for config3 (10 000 rows < 17 051 features, lambda = 1).  Level 0, where the inputs ARE identical, must meet
-the north-star tolerance 1e-4; later levels are bounded by the distance two CPU float32 solvers of the same system keep
-from each other (profiles/r02_cpu_solver_noise_config3.json), and the error against the ground truth (NLSR) must agree."""
+Two tests per configuration:
+
+* TEACHER-FORCED (round 3): level k of the GPU cascade is fed the oracle's landmarks x_k and must reproduce the oracle's x_{k+1}
+  within the north-star tolerance 1e-4 -- identical inputs at EVERY level (fixture tests/golden/config_oracle_full.npz,
+  scripts/make_config_fixtures.py).  Measured: config3 4.8e-5 / 7.8e-6 / 2.8e-6 / 9.2e-7 / 3.9e-7, rcr22 1.0e-6 / 7.7e-7 /
+  2.3e-7 / 3.4e-7, rcr68t 1.5e-6 / 4.9e-7 -- what LAPACK's Cholesky does against the oracle's LU on the CPU (4.5e-5 / 7.4e-6 / ...).
+* FREE-RUNNING: from level 1 on the two sides no longer see identical inputs, and the GPU solves with Cholesky on an MFMA Gram
+  matrix where the oracle (like the reference) uses LU.  Level 0, where the inputs ARE identical, must meet 1e-4; a later level
+  is bounded by TWICE the distance two CPU float32 solvers (LAPACK LU vs LAPACK Cholesky on the same Gram matrix) have drifted
+  apart at that level when both run free (profiles/r03_cpu_solver_drift.json, CPU only: config3 1.7e-4 ... 2.2e-4, rcr22
+  2.4e-5 / 5.4e-5 / 1.1e-4 -- the GPU's 1.8e-4 ... 2.2e-4 and 2.1e-5 / 6.5e-5 / 1.35e-4 are that same drift), and the error
+  against the ground truth (NLSR) must agree to 1e-3."""
 import hashlib
+import json
 import os
 
 import numpy as np
@@ -22,13 +30,21 @@ from superviseddescent_amd import HoGParam, HogTransform, LinearRegressor, Regul
 pytestmark = pytest.mark.gpu
 
 FIX = np.load(os.path.join(os.path.dirname(__file__), "golden", "config_oracle_levels.npz"))
+DRIFT = json.load(open(os.path.join(os.path.dirname(__file__), "..", "profiles", "r03_cpu_solver_drift.json")))
 CONFIGS = {
-    # name: (ids, HoG parameters, regulariser, images, rows per image, seed, tolerance level 0, tolerance later levels)
+    # name: (ids, HoG parameters, regulariser, images, rows per image, seed, tolerance level 0, unused)
     "config3": (ibug.RCR22_IDS, [(1, 5, 11, 9, 1.0), (1, 5, 10, 9, 0.7), (1, 5, 8, 9, 0.4), (1, 5, 6, 9, 0.25), (1, 5, 6, 9, 0.25)],
-                (0, 1.0, True), 1000, 10, 31003, 1e-4, 4e-4),
-    "rcr22": (ibug.RCR22_IDS, list(ibug.SHIPPED_HOG_PARAMS), (1, 1.5, False), 1000, 10, 31022, 1e-4, 2.5e-4),
-    "rcr68t": (ibug.IBUG68_IDS, list(ibug.SHIPPED_HOG_PARAMS[:2]), (1, 1.5, False), 400, 10, 31068, 1e-4, 1e-4),
+                (0, 1.0, True), 1000, 10, 31003, 1e-4, None),
+    "rcr22": (ibug.RCR22_IDS, list(ibug.SHIPPED_HOG_PARAMS), (1, 1.5, False), 1000, 10, 31022, 1e-4, None),
+    "rcr68t": (ibug.IBUG68_IDS, list(ibug.SHIPPED_HOG_PARAMS[:2]), (1, 1.5, False), 400, 10, 31068, 1e-4, None),
 }
+
+
+def free_running_tolerance(name, level):
+    """1e-4 where the inputs are identical (level 0); afterwards twice the free-running distance of two CPU float32 solvers."""
+    if level == 0:
+        return 1e-4
+    return 2.0 * float(DRIFT[name]["free_running_rel_l2_chol32_vs_lu32_per_level"][level])
 
 
 def rel_l2(a, b):
@@ -37,7 +53,7 @@ def rel_l2(a, b):
 
 @pytest.mark.parametrize("name", sorted(CONFIGS))
 def test_training_at_baseline_configuration(built, name):
-    ids, params, reg, n_img, per, seed, tol0, tol = CONFIGS[name]
+    ids, params, reg, n_img, per, seed, _, _ = CONFIGS[name]
     images, boxes, gt = synth.make_faces(n_img, seed=seed)
     x_star, x0, idx = synth.make_samples(boxes, gt, ids, n_perturb=per - 1, seed=seed + 1)
     digest = hashlib.sha1(images.tobytes() + x0.tobytes() + x_star.tobytes()).digest()
@@ -52,11 +68,13 @@ def test_training_at_baseline_configuration(built, name):
     assert len(levels) == want.shape[0] == len(params)
     assert sdo.regressors[0].x.shape == (len(ids) * params[0][1] ** 2 * (3 * params[0][3] + 4) + 1, 2 * len(ids))
     for l, cur in enumerate(levels):
-        assert rel_l2(cur[rows], want[l]) < (tol0 if l == 0 else tol), (name, l)
+        assert rel_l2(cur[rows], want[l]) < free_running_tolerance(name, l), (name, l)
         # the norm of ALL rows agrees with the oracle's, and so does the distance to the ground truth on the fixture rows
         assert np.linalg.norm(cur.astype(np.float64)) == pytest.approx(float(FIX[name + "_norms"][l]), rel=1e-5)
         e_gpu, e_orc = rel_l2(cur[rows], x_star[rows]), rel_l2(want[l], x_star[rows])
-        assert e_gpu == pytest.approx(e_orc, rel=0.1), (name, l)      # (config3 ends at 2e-4 of |x|: the float32 floor of its normal equations)
+        # (measured: 1e-6 ... 4e-5 for rcr22 / rcr68t; config3 ends at an NLSR of 2.2e-4 -- the size of the float32 solver noise itself --
+        #  where the two sides agree to 4e-4 ... 4e-3)
+        assert e_gpu == pytest.approx(e_orc, rel=1e-2 if name == "config3" else 1e-3), (name, l)
     assert rel_l2(levels[-1], x_star) < 0.5 * rel_l2(x0, x_star)
 
 
