@@ -23,6 +23,7 @@
 // Roofline: 2*N*F*M flops over N*F*4 feature bytes = M/2 flop/B (22 | 68): HBM-bound for RCR-22,
 // MFMA-bound for RCR-68.
 #include "sdm_kernels.h"
+#include <stdlib.h>
 
 #pragma clang fp contract(off)  // update = u*scale, then x - update: two roundings as in the reference
 
@@ -155,40 +156,46 @@ __device__ inline void glds16(const float* g, float* lds_dst)
     __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <int NT>
-__global__ void __launch_bounds__(256)
+template <int NT, int BM = AT_BM>      // BM rows per workgroup (64: four waves; 128: eight waves), wave w multiplies rows 16w .. 16w+15
+__global__ void __launch_bounds__(BM * 4)
 apply_tiled_kernel(const float* __restrict__ feat, long long ldf, int N, int kslabs,
                    const float* __restrict__ Rt, long long ldr, float* __restrict__ partial, int splits)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // [2 buffers][AT_BM + NT*16 rows][AT_BK]
-    constexpr int ROWS = AT_BM + NT * 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [2 buffers][BM + NT*16 rows][AT_BK]
+    constexpr int ROWS = BM + NT * 16;
+    constexpr int RPP = BM / 4;                                   // tile rows one staging pass of the workgroup covers (threads / 16)
+    constexpr int BP = (NT * 16 + RPP - 1) / RPP;                 // staging passes over the regressor rows
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 15, lq = lane >> 4;
-    const int row0 = blockIdx.x * AT_BM;
+    const int row0 = blockIdx.x * BM;
     const int split = blockIdx.y;
     const int s0 = (int)(((long long)kslabs * split) / splits), s1 = (int)(((long long)kslabs * (split + 1)) / splits);
-    // staging: thread t fills position (t % 16) of tile rows t/16 + 16p, i.e. loads chunk (t % 16) ^ (row & 15)
+    // staging: thread t fills position (t % 16) of tile rows t/16 + RPP p, i.e. loads chunk (t % 16) ^ (row & 15)
     const int srow = t >> 4, spos = t & 15;
-    const int schunk = spos ^ (srow & 15);                       // (16p does not change row & 15)
-    const float* ap[AT_BM / 16];
+    const int schunk = spos ^ (srow & 15);                       // (RPP p is a multiple of 16: it does not change row & 15)
+    const float* ap[BM / RPP];
 #pragma unroll
-    for (int p = 0; p < AT_BM / 16; ++p) {
-        int row = row0 + srow + 16 * p;
+    for (int p = 0; p < BM / RPP; ++p) {
+        int row = row0 + srow + RPP * p;
         if (row > N - 1) row = N - 1;                            // clamp: duplicates are never stored
         ap[p] = feat + (long long)row * ldf + 4 * schunk;
     }
-    const float* bp[NT];
+    const float* bp[BP];
 #pragma unroll
-    for (int c = 0; c < NT; ++c) bp[c] = Rt + (long long)(srow + 16 * c) * ldr + 4 * schunk;
+    for (int c = 0; c < BP; ++c) {
+        int brow = srow + RPP * c;
+        if (brow > NT * 16 - 1) brow = NT * 16 - 1;              // (a partial last pass: its waves beyond the matrix do not issue)
+        bp[c] = Rt + (long long)brow * ldr + 4 * schunk;
+    }
     auto issue = [&](int s, int buf) {
         float* base = lds + (size_t)buf * ROWS * AT_BK;
         const long long k0 = (long long)s * AT_BK;
 #pragma unroll
-        for (int p = 0; p < AT_BM / 16; ++p)      // wave w: tile rows 4w..4w+3 (+16p), 1 KB contiguous
-            glds16(ap[p] + k0, base + (4 * wave + 16 * p) * AT_BK);
+        for (int p = 0; p < BM / RPP; ++p)      // wave w: tile rows 4w..4w+3 (+RPP p), 1 KB contiguous
+            glds16(ap[p] + k0, base + (4 * wave + RPP * p) * AT_BK);
 #pragma unroll
-        for (int c = 0; c < NT; ++c)
-            glds16(bp[c] + k0, base + (AT_BM + 4 * wave + 16 * c) * AT_BK);
+        for (int c = 0; c < BP; ++c)
+            if (4 * wave + RPP * c < NT * 16) glds16(bp[c] + k0, base + (BM + 4 * wave + RPP * c) * AT_BK);
     };
 
     f32x4 acc[NT];
@@ -199,7 +206,7 @@ apply_tiled_kernel(const float* __restrict__ feat, long long ldf, int N, int ksl
         __syncthreads();                 // slab s has landed (the barrier drains the LDS-direct loads); the other buffer is free
         if (s + 1 < s1) issue(s + 1, (s - s0 + 1) & 1);
         const float* a = lds + (size_t)((s - s0) & 1) * ROWS * AT_BK + (16 * wave + li) * AT_BK;
-        const float* b = lds + (size_t)((s - s0) & 1) * ROWS * AT_BK + (AT_BM + li) * AT_BK;
+        const float* b = lds + (size_t)((s - s0) & 1) * ROWS * AT_BK + (BM + li) * AT_BK;
 #pragma unroll
         for (int kg = 0; kg < AT_BK / 16; ++kg) {
             const int pos = 4 * ((lq + 4 * kg) ^ li);            // swizzled position of chunk lq + 4kg in a row with r & 15 == li
@@ -414,13 +421,24 @@ void sdm_launch_landmark_errors(const float* x, const float* xstar, int N, int L
 }
 
 // the LDS-staged kernel serves narrow outputs (<= 3 column tiles) on batches that fill the chip
-static bool apply_use_tiled(int N, int M) { return (M + 15) / 16 <= 3 && N >= 2048; }
+// The LDS-staged kernel serves every output width on batches that fill the chip: 64-row blocks (four waves) for narrow outputs
+// (<= 3 column tiles: RCR-22), 128-row blocks (eight waves, the regressor slab staged once per 128 rows) for 4 ... 9 column tiles
+// (RCR-68: 703 -> 544 us per level at 8 192 x 27 201 x 136, 86 -> 111.5 TF; 64-row blocks: 632 us).  SDM_APPLY_PARTIAL=1 forces the
+// direct-to-register kernel (A/B).
+static bool apply_use_tiled(int N, int M)
+{
+    static const bool force_partial = getenv("SDM_APPLY_PARTIAL") && getenv("SDM_APPLY_PARTIAL")[0] == '1';
+    const int nt = (M + 15) / 16;
+    return !force_partial && nt <= 9 && N >= 2048;
+}
+static int apply_bm(int M) { return (M + 15) / 16 <= 3 ? AT_BM : 128; }
 
 int sdm_apply_splits(int N, int F, int M)
 {
     if (apply_use_tiled(N, M)) {
-        const int row_blocks = (N + AT_BM - 1) / AT_BM, kslabs = (F + AT_BK - 1) / AT_BK;
-        int splits = (512 + row_blocks - 1) / row_blocks;     // two 61 KB workgroups per CU
+        const int bm = apply_bm(M);
+        const int row_blocks = (N + bm - 1) / bm, kslabs = (F + AT_BK - 1) / AT_BK;
+        int splits = ((bm == 128 ? 256 : 512) + row_blocks - 1) / row_blocks;     // two 61 KB workgroups per CU (64 rows), one of 90 - 139 KB (128 rows)
         if (splits > kslabs / 4) splits = kslabs / 4;
         return splits < 1 ? 1 : (splits > 64 ? 64 : splits);
     }
@@ -455,17 +473,22 @@ void sdm_launch_apply(const float* feat, long long ldf, int N, int F, const floa
     if (apply_use_tiled(N, M)) {
         // (feat / Rt rows are zero padded up to ldf >= round_up(F, 128): whole 64-wide slabs are readable)
         const int kslabs = (F + AT_BK - 1) / AT_BK;
-        const dim3 grid((N + AT_BM - 1) / AT_BM, splits);
+        const int bm = apply_bm(M);
+        const dim3 grid((N + bm - 1) / bm, splits);
+        const size_t lds = (size_t)2 * (bm + NT * 16) * AT_BK * sizeof(float);
         static unsigned long long attr_seen = 0;
         if (sdm_first_use_on_device(attr_seen)) {
-            SDM_SET_ATTR((const void*)apply_tiled_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            SDM_SET_ATTR((const void*)apply_tiled_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            SDM_SET_ATTR((const void*)apply_tiled_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define ATATTR(...) SDM_SET_ATTR((const void*)apply_tiled_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+            ATATTR(1); ATATTR(2); ATATTR(3); ATATTR(4, 128); ATATTR(5, 128); ATATTR(6, 128); ATATTR(7, 128); ATATTR(8, 128); ATATTR(9, 128);
+#undef ATATTR
         }
-        const size_t lds = (size_t)2 * (AT_BM + NT * 16) * AT_BK * sizeof(float);
-        if (NT == 1) hipLaunchKernelGGL(apply_tiled_kernel<1>, grid, dim3(256), lds, stream, feat, ldf, N, kslabs, Rt, ldr, partial, splits);
-        else if (NT == 2) hipLaunchKernelGGL(apply_tiled_kernel<2>, grid, dim3(256), lds, stream, feat, ldf, N, kslabs, Rt, ldr, partial, splits);
-        else hipLaunchKernelGGL(apply_tiled_kernel<3>, grid, dim3(256), lds, stream, feat, ldf, N, kslabs, Rt, ldr, partial, splits);
+#define ATL(...) hipLaunchKernelGGL((apply_tiled_kernel<__VA_ARGS__>), grid, dim3(bm * 4), lds, stream, feat, ldf, N, kslabs, Rt, ldr, partial, splits)
+        switch (NT) {
+            case 1: ATL(1); break; case 2: ATL(2); break; case 3: ATL(3); break;
+            case 4: ATL(4, 128); break; case 5: ATL(5, 128); break; case 6: ATL(6, 128); break;
+            case 7: ATL(7, 128); break; case 8: ATL(8, 128); break; default: ATL(9, 128); break;
+        }
+#undef ATL
     } else
     switch (NT) {
         case 1: launch_partial<2, 1>(feat, ldf, N, kgroups, Rt, ldr, partial, splits, stream); break;
