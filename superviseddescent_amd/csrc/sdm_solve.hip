@@ -251,7 +251,7 @@ syrk_tn_glds_kernel(const float* __restrict__ A, long long lda, int rows, float*
 // fragment reads and the per-slab barrier.  Same staging, same order of summation per element (bit-identical sums), same two-level
 // accumulation.  68.4 -> 66.8 ms at 100 000 rows x 8 801 features (119.0 -> 121.8 TF executed, 77.4 % of the f32 matrix-core peak);
 // sixteen waves (one tile each, NW = 16) measure the same as eight: 66.5 - 66.6 ms.
-template <int NW>      // waves per tile: 8 (wave = 32-row strip x 64-column half, two matrix-core tiles) or 16 (32 x 32, one tile)
+template <int NW, bool CHUNKED = true>      // waves per tile: 8 (wave = 32-row strip x 64-column half, two matrix-core tiles) or 16 (32 x 32, one tile)
 __global__ void __launch_bounds__(NW * 64)
 syrk_tn_gldsw_kernel(const float* __restrict__ A, long long lda, int rows, float* __restrict__ C, long long ldc,
                      float alpha, int accumulate, int tile_i0, int own_first, int own_stride)
@@ -290,8 +290,9 @@ syrk_tn_gldsw_kernel(const float* __restrict__ A, long long lda, int rows, float
     const int nslabs = rows / SYRK_GBK;
     constexpr int chunk = SYRK_CHUNK * SYRK_BK / SYRK_GBK;
     issue(0, 0);
-    for (int c0 = 0; c0 < nslabs; c0 += chunk) {
-        const int c1 = c0 + chunk < nslabs ? c0 + chunk : nslabs;
+    const int step = CHUNKED ? chunk : nslabs;
+    for (int c0 = 0; c0 < nslabs; c0 += step) {
+        const int c1 = c0 + step < nslabs ? c0 + step : nslabs;
         for (int s = c0; s < c1; ++s) {
             __syncthreads();
             if (s + 1 < nslabs) issue(s + 1, (s + 1) & 1);
@@ -308,10 +309,12 @@ syrk_tn_gldsw_kernel(const float* __restrict__ A, long long lda, int rows, float
                 for (int n = 0; n < NN; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[n], acc[n], 0, 0, 0);
             }
         }
+        if (CHUNKED) {
 #pragma unroll
-        for (int n = 0; n < NN; ++n)
+            for (int n = 0; n < NN; ++n)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { tot[n][e] += acc[n][e]; acc[n][e] = 0.0f; }
+                for (int e = 0; e < 16; ++e) { tot[n][e] += acc[n][e]; acc[n][e] = 0.0f; }
+        }
     }
 #pragma unroll
     for (int n = 0; n < NN; ++n)
@@ -321,7 +324,7 @@ syrk_tn_gldsw_kernel(const float* __restrict__ A, long long lda, int rows, float
             const long long gi = (long long)ti * TILE + wr * 32 + r;
             const long long gj = (long long)tj * TILE + wc * 32 * NN + n * 32 + (lane & 31);
             float* p = C + gi * ldc + gj;
-            float v = alpha * tot[n][e];
+            float v = alpha * (CHUNKED ? tot[n][e] : acc[n][e]);
             if (accumulate) v += *p;
             *p = v;
         }
@@ -966,13 +969,21 @@ void sdm_launch_syrk_tn(const float* A, long long lda, int rows, int ncols, floa
         if (chunked && w8) {
             static unsigned long long attr8 = 0;
             if (sdm_first_use_on_device(attr8)) {
-                sdm_check_launch_attr(hipFuncSetAttribute((const void*)syrk_tn_gldsw_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "syrk_tn_gldsw_kernel<8>");
+                sdm_check_launch_attr(hipFuncSetAttribute((const void*)syrk_tn_gldsw_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "syrk_tn_gldsw_kernel<8>");
             }
-            hipLaunchKernelGGL(syrk_tn_gldsw_kernel<8>, dim3(Tx, Ty), dim3(512), lds, stream, A, lda, rows, C, ldc, alpha, accumulate, tile_i0, first, W);
+            hipLaunchKernelGGL((syrk_tn_gldsw_kernel<8, true>), dim3(Tx, Ty), dim3(512), lds, stream, A, lda, rows, C, ldc, alpha, accumulate, tile_i0, first, W);
         } else if (chunked)
             hipLaunchKernelGGL(syrk_tn_glds_kernel<true>, dim3(Tx, Ty), dim3(256), lds, stream, A, lda, rows, C, ldc, alpha, accumulate, tile_i0, first, W);
-        else
-            hipLaunchKernelGGL(syrk_tn_glds_kernel<false>, dim3(Tx, Ty), dim3(256), lds, stream, A, lda, rows, C, ldc, alpha, accumulate, tile_i0, first, W);
+        else {
+            // (round 3: eight waves per tile for the Cholesky's trailing updates as well: factor + solve 83.5 -> 78.7 ms at F = 27 201,
+            //  7.22 -> 7.07 ms at F = 8 801; SDM_UPDATE_W4=1: the four-wave instance, A/B)
+            static const bool upd8 = !(getenv("SDM_UPDATE_W4") && getenv("SDM_UPDATE_W4")[0] == '1');
+            static unsigned long long attru = 0;
+            if (sdm_first_use_on_device(attru))
+                sdm_check_launch_attr(hipFuncSetAttribute((const void*)syrk_tn_gldsw_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "syrk_tn_gldsw_kernel<8,false>");
+            if (upd8) hipLaunchKernelGGL((syrk_tn_gldsw_kernel<8, false>), dim3(Tx, Ty), dim3(512), lds, stream, A, lda, rows, C, ldc, alpha, accumulate, tile_i0, first, W);
+            else hipLaunchKernelGGL(syrk_tn_glds_kernel<false>, dim3(Tx, Ty), dim3(256), lds, stream, A, lda, rows, C, ldc, alpha, accumulate, tile_i0, first, W);
+        }
     } else if (chunked)
         hipLaunchKernelGGL(syrk_tn_kernel<true>, dim3(Tx, Ty), dim3(256), 0, stream, A, lda, rows, C, ldc, alpha,
                            accumulate, tile_i0, first, W);
