@@ -631,15 +631,20 @@ potrf_tile_kernel(float* __restrict__ G, long long ldg, int k0, int* __restrict_
 // substitution it replaces: 37.6 us), and the panel solve is on the chain every 128-column step waits for.
 // The extra last workgroup solves for the identity instead and stores U_kk^-T into winv_t: the back substitution then
 // needs only products, no serial solves.
-#define TRSM_LD (TILE + 16)        // row stride of U in LDS: the two 16-column halves a fragment read touches land on disjoint banks
+// Round 3: U_kk sits in LDS as its 36 upper 16 x 16 blocks only (block (jb, rb), rb >= jb, row-major 16 x 16; the fragment reads
+// of a block -- rows 4s + lq, column li -- fall into 32 different banks per half wave), 54 KB with the inverses and the waves'
+// scratch instead of 91 KB: a panel-solve workgroup now fits on a CU beside ONE trailing-update workgroup (64 KB), i.e. it is
+// placed as soon as one of the two finishes instead of waiting for both while the dispatcher refills the freed half.
+__host__ __device__ constexpr int trsm_blk(int jb, int rb) { return jb * (17 - jb) / 2 + rb - jb; }
+#define TRSM_LDS_FLOATS (36 * IB * IB + NIB * IB * IB + 8 * IB * (IB + 1))
 __global__ void __launch_bounds__(TILE * PQ)
 trsm_tile_kernel(float* __restrict__ G, long long ldg, int k0, int tile_j0, int n_tiles, float* __restrict__ winv_t, int own_stride,
                  int* __restrict__ status)
 {
     // workgroup b < n_tiles: tile column tile_j0 + b * own_stride (the caller's columns: all of them, or the owned ones)
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* Us = sm;                              // [128][TRSM_LD]   U_kk, row-major: Us[m][r] = U[m][r]
-    float* Dinv = sm + TILE * TRSM_LD;           // [8][16][16]      inverses of the diagonal blocks: Dinv[j][r][c] = (D_j^-1)[r][c]
+    float* Up = sm;                              // [36 blocks][16][16]   the upper blocks of U_kk
+    float* Dinv = sm + 36 * IB * IB;             // [8][16][16]      inverses of the diagonal blocks: Dinv[j][r][c] = (D_j^-1)[r][c]
     float* scratch = Dinv + NIB * IB * IB;       // [8 waves][16][16 + 1]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 15, lq = lane >> 4;
@@ -660,19 +665,23 @@ trsm_tile_kernel(float* __restrict__ G, long long ldg, int k0, int tile_j0, int 
         }
     const int lr = t >> 5, lc = (t & 31) * 4;
 #pragma unroll 8
-    for (int r = lr; r < TILE; r += 16) *(f32x4s*)(Us + r * TRSM_LD + lc) = *(const f32x4s*)(Gk + (long long)r * ldg + lc);
+    for (int r = lr; r < TILE; r += 16) {
+        const int jb_ = r >> 4, rb_ = lc >> 4;           // (r >> 4 is the unrolled trip number: a constant)
+        if (rb_ >= jb_) *(f32x4s*)(Up + trsm_blk(jb_, rb_) * IB * IB + (r & 15) * IB + (lc & 15)) = *(const f32x4s*)(Gk + (long long)r * ldg + lc);
+    }
     __syncthreads();
     if (t < NIB * IB) {
         // column i of the inverse of the upper triangular block D = U[j0 .. j0+15][j0 .. j0+15]: back substitution for e_i
-        const int jb = t >> 4, i = t & 15, j0 = jb * IB;
+        const int jb = t >> 4, i = t & 15;
         float x[IB], rd[IB];
+        const float* Dj = Up + trsm_blk(jb, jb) * IB * IB;                                                  // the diagonal block D_jb
 #pragma unroll
-        for (int r = 0; r < IB; ++r) rd[r] = __builtin_amdgcn_rcpf(Us[(j0 + r) * TRSM_LD + j0 + r]);      // off the serial chain below
+        for (int r = 0; r < IB; ++r) rd[r] = __builtin_amdgcn_rcpf(Dj[r * IB + r]);      // off the serial chain below
 #pragma unroll
         for (int r = IB - 1; r >= 0; --r) {
             float sacc = (r == i) ? 1.0f : 0.0f;
 #pragma unroll
-            for (int m = r + 1; m < IB; ++m) sacc -= Us[(j0 + r) * TRSM_LD + j0 + m] * x[m];     // (x[m] = 0 for m > i)
+            for (int m = r + 1; m < IB; ++m) sacc -= Dj[r * IB + m] * x[m];     // (x[m] = 0 for m > i)
             x[r] = (r <= i) ? sacc * rd[r] : 0.0f;
         }
 #pragma unroll
@@ -682,7 +691,6 @@ trsm_tile_kernel(float* __restrict__ G, long long ldg, int k0, int tile_j0, int 
     float* S = scratch + wave * IB * (IB + 1);
 #pragma unroll
     for (int jb = 0; jb < NIB; ++jb) {
-        const int j0 = jb * IB;
         // B_j (accumulator layout) -> B operand: k-step s needs rows 4 s + lq
 #pragma unroll
         for (int e = 0; e < 4; ++e) S[(4 * lq + e) * (IB + 1) + li] = acc[jb][e];
@@ -710,7 +718,7 @@ trsm_tile_kernel(float* __restrict__ G, long long ldg, int k0, int tile_j0, int 
             for (int rb = jb + 1; rb < NIB; ++rb)
 #pragma unroll
                 for (int s_ = 0; s_ < 4; ++s_)
-                    acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Us[(j0 + 4 * s_ + lq) * TRSM_LD + IB * rb + li], bop[s_], acc[rb], 0, 0, 0);
+                    acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Up[trsm_blk(jb, rb) * IB * IB + (4 * s_ + lq) * IB + li], bop[s_], acc[rb], 0, 0, 0);
         }
     }
 #pragma unroll
@@ -1064,7 +1072,7 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
     const int ncols = rhs0 + TILE * ((nrhs + TILE - 1) / TILE);   // factor tiles + one or two RHS tile columns
     const int T = ncols / TILE;
     const size_t lds_potrf = ((size_t)IB * POTRF_PLD + IB * IB + 4 + 8 * IB * (IB + 1)) * sizeof(float);
-    const size_t lds_trsm = ((size_t)TILE * TRSM_LD + NIB * IB * IB + 8 * IB * (IB + 1)) * sizeof(float);
+    const size_t lds_trsm = (size_t)TRSM_LDS_FLOATS * sizeof(float);
     static unsigned long long attr_seen = 0;
     if (sdm_first_use_on_device(attr_seen)) {
         SDM_SET_ATTR((const void*)potrf_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
