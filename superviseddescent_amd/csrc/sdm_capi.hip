@@ -1016,7 +1016,7 @@ int sdm_solve(sdm_ctx* c, int level, int reg_type, float reg_param, int regulari
     int rc;
     if ((rc = c->fro.ensure((size_t)F + 1))) return rc;
     if ((rc = c->Rsol.ensure((size_t)Fp * Mp))) return rc;
-    if ((rc = c->winv.ensure((size_t)Fp * 128 + 2048 /* + the back substitution's flags */))) return rc;
+    if ((rc = c->winv.ensure((size_t)Fp * 128 + sdm_backsolve_flag_floats(Fp) /* + the back substitution's flags */))) return rc;
     if ((rc = c->Rt[level].ensure((size_t)Mp * c->ldf))) return rc;
     {
         Timer t(c, SDM_T_REG);
@@ -1070,7 +1070,7 @@ int sdm_solve_normal_equations(sdm_ctx* c, const float* A, int N, int F, const f
     ScopedBuf<float> dA, dG, dR, dW; ScopedBuf<double> dfro;
     int rc;
     if ((rc = dA.ensure((size_t)N * ncols, true, c->stream)) || (rc = dG.ensure((size_t)ncols * ncols)) ||
-        (rc = dR.ensure((size_t)Fp * Mp)) || (rc = dW.ensure((size_t)Fp * 128 + 2048 /* + the back substitution's flags */)) || (rc = dfro.ensure((size_t)F + 1)))
+        (rc = dR.ensure((size_t)Fp * Mp)) || (rc = dW.ensure((size_t)Fp * 128 + sdm_backsolve_flag_floats(Fp) /* + the back substitution's flags */)) || (rc = dfro.ensure((size_t)F + 1)))
         return rc;
     HIP_TRY(hipMemcpy2DAsync(dA.p, (size_t)ncols * sizeof(float), A, (size_t)F * sizeof(float), (size_t)F * sizeof(float), N,
                              hipMemcpyHostToDevice, c->stream));

@@ -174,7 +174,8 @@ void sdm_launch_add_diag(float* G, long long ldg, int F, const double* fro2, int
 
 // Blocked Cholesky G = U^T U on the upper triangle of the leading F x F block, with the
 // forward substitution fused into the panel updates for the extra columns [rhs0, rhs0+nrhs),
-// then back substitution; R_out [F][ldr].  work: ceil(F/128) * 128 * 128 floats (inverted diagonal tiles) + 2048 (flags).
+// then back substitution; R_out [F][ldr].  work: ceil(F/128) * 128 * 128 floats (inverted diagonal tiles) + sdm_backsolve_flag_floats(Fp)
+// (one int per tile row and right-hand-side chunk: the persistent back substitution's flags).
 // hipFuncSetAttribute (dynamic LDS above 64 KB) is per device: true the first time a call site runs on the current one
 inline bool sdm_first_use_on_device(unsigned long long& seen)
 {
@@ -212,6 +213,7 @@ struct SolveShard {
 };
 inline size_t sdm_solve_shard_stage_tiles(int ncols, int world) { return (size_t)(world + 1) * 4 * (size_t)(ncols / 128 / world + 1); }
 // returns 0, or the non-zero result of a failed collective
+inline size_t sdm_backsolve_flag_floats(int Fp) { return (size_t)2 * (size_t)(Fp / 128) + 64; }      // (<= 144 right-hand sides: <= 2 chunks)
 int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs, float* R_out,
                               long long ldr, float* work, int* status, hipStream_t stream, const SolveAux* aux = nullptr,
                               const SolveShard* shard = nullptr);

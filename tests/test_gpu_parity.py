@@ -272,6 +272,37 @@ def test_apply_update(gpu_ctx, faces, n):
     assert rel_l2(x1, ref) < 1e-6
 
 
+@pytest.mark.parametrize("L,n", [(25, 2100), (33, 2049), (40, 2100), (47, 2303), (55, 2100), (61, 2048), (68, 2100), (68, 8192)])
+def test_apply_wide_outputs_on_large_batches(faces, L, n):
+    """Round 3: outputs of 4 ... 9 column tiles (2L = 50 ... 136) on batches >= 2 048 rows run on the LDS-staged GEMM with 128-row
+    blocks and eight waves (apply_tiled_kernel<NT, 128>; regressors.hpp:377-381 + the update of superviseddescent.hpp:209-215):
+    every column-tile count, ragged last row blocks, RCR-68's M = 136 at the shard size of BASELINE config 4."""
+    images, boxes, gt, _, _ = faces
+    ids = ibug.IBUG68_IDS[:L]
+    re_, le_ = [0], [L - 1]
+    _, x0, _ = synth.make_samples(boxes[:64], gt[:64], ids, 0, seed=19)
+    idx = (np.arange(n) % 64).astype(np.int32)
+    x = (x0[idx] + (np.arange(n)[:, None] // 64).astype(np.float32) * 0.21).astype(np.float32)
+    ctx = Context(0)
+    ctx.set_model_geometry(L, re_, le_, [HoGParam(1, 2, 10, 4, 0.5)])           # F = L * 4 * 16 + 1
+    ctx.upload_images(images[:64])
+    ctx.set_sample_image_index(idx)
+    ctx.set_x(x)
+    feat = ctx.hog_features(0, fetch=True)
+    assert feat.shape == (n, 64 * L + 1)
+    rng = np.random.default_rng(L * 7 + n)
+    R = (rng.standard_normal((feat.shape[1], 2 * L)) * 0.01).astype(np.float32)
+    ctx.set_regressor(0, R)
+    ctx.apply(0)
+    x1 = ctx.get_x()
+    u = (feat.astype(np.float64) @ R.astype(np.float64)).astype(np.float32)
+    ref = (x - u * (np.float32(1.0) / orc.InterEyeDistanceNormalisation(re_, le_)(x))).astype(np.float32)
+    assert rel_l2(x1, ref) < 1e-6
+    ctx.apply(0)                                                                 # (a second level-0 step from the updated landmarks:
+    assert np.isfinite(ctx.get_x()).all()                                        #  the ping-pong of the two landmark buffers)
+    ctx.close()
+
+
 # ------------------------------------------------------------------------------------------ train / detect
 def small_params():
     # RCR-22 landmarks with 3x3 cells: F = 22*9*16+1 = 3169, so that the oracle's LAPACK LU stays cheap
