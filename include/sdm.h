@@ -245,6 +245,10 @@ int sdm_debug_download_images(sdm_ctx* ctx, uint8_t* out, int n, int width, int 
  * ROI then fills the wave).  Same integer decisions; a patch cut by a pass boundary sums its cells from two partial folds.
  * Off = one patch (or one landmark pair) per wave, for A/B comparison in tests. */
 int sdm_debug_set_hog_packing(sdm_ctx* ctx, int on);
+/* How many sdm_gram_rhs launches of this context had to be repeated with three bf16 pieces because an operand left float16's
+ * range (the Gram matrix A^T A / A^T b of regressors.hpp:208,225 is formed on the 16-bit matrix cores from two float16 pieces per
+ * f32 operand -- float32 accuracy, see csrc/sdm_gram_bf16.hip; the repeat keeps float32's range).  Tests. */
+int sdm_debug_gram_fallbacks(sdm_ctx* ctx);
 /* The packing plan of a level geometry (host only, no device needed): info5 = {G, P, n_main, Gt, Pt} (G == 0: no packed
  * instance for this geometry); lane_tab [passes][64], wb [passes][64][16], pass_info [passes][4] as documented in
  * superviseddescent_amd/csrc/sdm_kernels.h (HogPlanDev); passes = P + Pt <= max_passes. */

@@ -128,6 +128,9 @@ struct sdm_ctx {
     DevBuf<double> fro;
     DevBuf<float> Rsol;    // [Fp][Mp_ld]
     DevBuf<float> winv;    // [Fp/128][128][128] transposed inverses of the diagonal factor tiles
+    DevBuf<int> gram_flag;               // raised by the float16 split when an operand leaves float16's range
+    int gram_fallbacks = 0;              // launches repeated with three bf16 pieces (sdm_debug_gram_fallbacks)
+    DevBuf<unsigned char> gram_planes;   // the feature matrix as three bf16 planes (sdm_gram_bf16.hip), scratch of sdm_gram_rhs
     DevBuf<float> lambda_dev;
 
     sdm_allreduce_fn allreduce = nullptr;
@@ -375,7 +378,7 @@ void sdm_destroy(sdm_ctx* c)
     c->img_owned.release(); c->img_off.release(); c->img_w.release(); c->img_h.release();
     c->img_stride.release(); c->img_idx.release(); c->x[0].release(); c->x[1].release();
     c->xstar.release(); c->tmpl.release(); c->feat.release(); c->patch_idx.release(); c->status.release();
-    c->partial.release(); c->shard_stage.release(); c->G.release(); c->gpack.release(); c->fro.release(); c->Rsol.release(); c->winv.release(); c->lambda_dev.release();
+    c->partial.release(); c->shard_stage.release(); c->G.release(); c->gpack.release(); c->fro.release(); c->Rsol.release(); c->winv.release(); c->gram_planes.release(); c->gram_flag.release(); c->lambda_dev.release();
     for (auto& r : c->Rt) r.release();
     for (auto& q : c->plans) { q.lane_tab.release(); q.wb.release(); q.pass_info.release(); }
     if (c->own_stream) e = hipStreamDestroy(c->stream);
@@ -894,6 +897,27 @@ int sdm_gram_rhs(sdm_ctx* c, int level)
     // the tail tile of every feature row holds b; clear it first (columns beyond 2L must be 0)
     HIP_TRY(hipMemset2DAsync(c->feat.p + Fp, (size_t)c->ldf * sizeof(float), 0, 128 * c->rhs_tiles * sizeof(float), c->N, c->stream));
     sdm_launch_targets(c->x[c->cur].p, c->xstar.p, c->N, c->L, c->eyes, c->feat.p, c->ldf, Fp, c->stream);
+    // Round 3: the Gram launch runs on the 16-bit matrix cores with float32 accuracy (sdm_gram_bf16.hip): every operand split into two
+    // float16 pieces (x 2^12), four piece products per product; should an operand leave float16's range -- a training target beyond
+    // 14 inter-eye distances -- the launch is repeated with three bf16 pieces (float32's range, six products).  SDM_GRAM_F32=1: the
+    // f32 matrix-core kernel of rounds 1-2 (A/B); SDM_GRAM_BF16X3=1: always the three-bf16 form.
+    static const bool gram_f32 = getenv("SDM_GRAM_F32") && getenv("SDM_GRAM_F32")[0] == '1';
+    static const bool gram_bf16 = getenv("SDM_GRAM_BF16X3") && getenv("SDM_GRAM_BF16X3")[0] == '1';
+    if (!gram_f32) {
+        if ((rc = c->gram_planes.ensure(sdm_gram_bf16x3_plane_bytes(c->N, ncols)))) return rc;
+        bool done = false;
+        if (!gram_bf16) {
+            if ((rc = c->gram_flag.ensure(1))) return rc;
+            HIP_TRY(hipMemsetAsync(c->gram_flag.p, 0, sizeof(int), c->stream));
+            sdm_launch_gram_bf16x3(c->feat.p, c->ldf, c->N, ncols, c->gram_planes.p, c->G.p, ncols, c->stream, c->gram_flag.p);
+            int over = 0;
+            HIP_TRY(hipMemcpyAsync(&over, c->gram_flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            done = over == 0;
+            c->gram_fallbacks += done ? 0 : 1;
+        }
+        if (!done) sdm_launch_gram_bf16x3(c->feat.p, c->ldf, c->N, ncols, c->gram_planes.p, c->G.p, ncols, c->stream);
+    } else
     sdm_launch_syrk_tn(c->feat.p, c->ldf, c->N, ncols, c->G.p, ncols, 1.0f, 0, 0, c->stream);
     HIP_TRY(hipGetLastError());
     c->g_ncols = ncols; c->g_fp = Fp; c->g_level = level;
@@ -1186,6 +1210,12 @@ int sdm_debug_hog_profile(sdm_ctx* c, int level, unsigned long long* out8)
     d.release();
     c->feat_level = level;
     return SDM_OK;
+}
+
+int sdm_debug_gram_fallbacks(sdm_ctx* c)
+{
+    if (!c) return fail(SDM_ERR_INVALID, "null context");
+    return c->gram_fallbacks;
 }
 
 int sdm_debug_set_hog_packing(sdm_ctx* c, int on)

@@ -390,6 +390,10 @@ class Context:
         """Lane packing of the HOG launch (include/sdm.h: sdm_debug_set_hog_packing); on by default."""
         check(self._lib.sdm_debug_set_hog_packing(self._h, int(on)))
 
+    def gram_fallbacks(self) -> int:
+        """Gram launches of this context repeated with three bf16 pieces (an operand beyond float16's range); tests."""
+        return check(self._lib.sdm_debug_gram_fallbacks(self._h))
+
     def debug_gradient_table(self, level: int):
         g = np.empty((511, 511), np.float32)
         b = np.empty((511, 511), np.int32)

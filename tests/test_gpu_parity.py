@@ -303,6 +303,52 @@ def test_apply_wide_outputs_on_large_batches(faces, L, n):
     ctx.close()
 
 
+def _gram_of(ctx, F, M):
+    """The upper triangle of A^T A and A^T b as sdm_gram_rhs left them on the device."""
+    import torch
+    ptr, count = ctx.gram_device_ptr()
+    ncols = -(-F // 128) * 128 + 128 * (-(-(-(-M // 16) * 16) // 128))
+
+    class Span:
+        __cuda_array_interface__ = {"shape": (count,), "typestr": "<f4", "data": (ptr, False), "version": 3, "strides": None}
+    G = torch.as_tensor(Span(), device="cuda:0").cpu().numpy().reshape(-1, ncols).astype(np.float64)
+    Fp = -(-F // 128) * 128
+    return G[:F, :F], G[:F, Fp:Fp + M]
+
+
+@pytest.mark.parametrize("far", [False, True], ids=["float16_pieces", "target_beyond_float16_range"])
+def test_gram_on_the_16_bit_matrix_cores_has_float32_accuracy(faces, far):
+    """Round 3: A^T A and A^T b (regressors.hpp:208,225) are formed from two float16 pieces per f32 operand, four piece products per
+    product (csrc/sdm_gram_bf16.hip) -- against a float64 product of the same features the result must be as close as a float32
+    accumulation is (measured 1.1e-7 ... 2.9e-7 relative Frobenius; the f32 matrix-core kernel: 2.4e-7 ... 3.5e-7).  Training targets
+    beyond float16's range (a landmark 30 inter-eye distances off) make the launch repeat itself with three bf16 pieces: same
+    accuracy, and the repeat is counted."""
+    images, boxes, gt, _, _ = faces
+    x_star, x0, idx = synth.make_samples(boxes[:160], gt[:160], IDS, n_perturb=4, seed=71)      # 800 rows
+    if far:
+        x_star = x_star.copy()
+        x_star[5, 3] += 2500.0
+    ctx = Context(0)
+    ctx.set_model_geometry(len(IDS), RE, LE, [HoGParam(1, 3, 12, 4, 0.9)])                       # F = 3169
+    ctx.upload_images(images[:160])
+    ctx.set_sample_image_index(idx)
+    ctx.set_x(x0)
+    ctx.set_targets(x_star)
+    A = ctx.hog_features(0, fetch=True).astype(np.float64)
+    ctx.gram_rhs(0)
+    ctx.synchronize()
+    assert ctx.gram_fallbacks() == (1 if far else 0)
+    n = orc.InterEyeDistanceNormalisation(RE, LE)(x0)
+    b = ((x0 - x_star) * n).astype(np.float32).astype(np.float64)                               # superviseddescent.hpp:199-205
+    G, B = _gram_of(ctx, A.shape[1], 2 * len(IDS))
+    iu = np.triu_indices(A.shape[1])
+    ref = A.T @ A
+    assert np.linalg.norm(G[iu] - ref[iu]) / np.linalg.norm(ref[iu]) < 1e-6
+    refb = A.T @ b
+    assert np.linalg.norm(B - refb) / np.linalg.norm(refb) < 1e-6
+    ctx.close()
+
+
 # ------------------------------------------------------------------------------------------ train / detect
 def small_params():
     # RCR-22 landmarks with 3x3 cells: F = 22*9*16+1 = 3169, so that the oracle's LAPACK LU stays cheap
