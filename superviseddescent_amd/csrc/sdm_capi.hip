@@ -71,7 +71,9 @@ struct sdm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    SolveAux solve_aux = {nullptr, nullptr, nullptr};   // second queue of the Cholesky look-ahead
+    SolveAux solve_aux = {nullptr, nullptr, nullptr, nullptr, nullptr};   // second queue of the Cholesky look-ahead (+ the scratch of its float16 updates, set per solve)
+    DevBuf<unsigned char> upd_planes;    // one panel group as float16 planes (sdm_update_f16_plane_bytes)
+    DevBuf<unsigned> upd_maxdiag;
 
     // geometry
     int L = 0, M = 0;
@@ -213,6 +215,7 @@ int check_status(sdm_ctx* c)
             return fail(SDM_ERR_EMPTY_PATCH, "patch_width_half <= 0 for at least one sample (inter-eye distance too small)");
         if (st & 2) return fail(SDM_ERR_NOT_SPD, "regularised Gram matrix is not positive definite; increase lambda");
         if (st & 4) return fail(SDM_ERR_HIP, "back substitution: a tile row waited for its predecessor beyond the spin limit");
+        if (st & 8) return fail(SDM_ERR_NOT_SPD, "Cholesky update: a factor entry exceeds the square root of the largest diagonal entry (matrix not positive definite?)");
     }
     return SDM_OK;
 }
@@ -378,7 +381,7 @@ void sdm_destroy(sdm_ctx* c)
     c->img_owned.release(); c->img_off.release(); c->img_w.release(); c->img_h.release();
     c->img_stride.release(); c->img_idx.release(); c->x[0].release(); c->x[1].release();
     c->xstar.release(); c->tmpl.release(); c->feat.release(); c->patch_idx.release(); c->status.release();
-    c->partial.release(); c->shard_stage.release(); c->G.release(); c->gpack.release(); c->fro.release(); c->Rsol.release(); c->winv.release(); c->gram_planes.release(); c->gram_flag.release(); c->lambda_dev.release();
+    c->partial.release(); c->shard_stage.release(); c->G.release(); c->gpack.release(); c->fro.release(); c->Rsol.release(); c->winv.release(); c->gram_planes.release(); c->gram_flag.release(); c->upd_planes.release(); c->upd_maxdiag.release(); c->lambda_dev.release();
     for (auto& r : c->Rt) r.release();
     for (auto& q : c->plans) { q.lane_tab.release(); q.wb.release(); q.pass_info.release(); }
     if (c->own_stream) e = hipStreamDestroy(c->stream);
@@ -1003,6 +1006,16 @@ int sdm_set_solve_sharding_rccl(sdm_ctx* c, void* nccl_comm, int rank, int world
     return SDM_OK;
 }
 
+// scratch of the Cholesky's float16 trailing updates: one panel group (512 rows) of the system as float16 planes
+int solve_update_scratch(sdm_ctx* c, int ncols)
+{
+    int rc;
+    if ((rc = c->upd_planes.ensure(sdm_update_f16_plane_bytes(512, ncols))) || (rc = c->upd_maxdiag.ensure(3))) return rc;
+    c->solve_aux.upd_planes = c->upd_planes.p;
+    c->solve_aux.upd_maxdiag = c->upd_maxdiag.p;
+    return SDM_OK;
+}
+
 int sdm_allreduce_gram_rhs(sdm_ctx* c)
 {
     if (!c || c->g_level < 0) return fail(SDM_ERR_INVALID, "no Gram matrix to reduce");
@@ -1061,6 +1074,7 @@ int sdm_solve(sdm_ctx* c, int level, int reg_type, float reg_param, int regulari
             static const int emulate = getenv("SDM_SOLVE_SHARD_EMULATE") ? atoi(getenv("SDM_SOLVE_SHARD_EMULATE")) : 0;
             shard.emulate_chain = emulate;
         }
+        if ((rc = solve_update_scratch(c, ncols))) return rc;
         const int crc = sdm_launch_cholesky_solve(c->G.p, ncols, F, Fp, Mp, c->Rsol.p, Mp, c->winv.p, c->status.p, c->stream,
                                                   &c->solve_aux, sharded ? &shard : nullptr);
         if (crc) {
@@ -1106,6 +1120,7 @@ int sdm_solve_normal_equations(sdm_ctx* c, const float* A, int N, int F, const f
         if (reg_type == SDM_REG_MATRIX_NORM) sdm_launch_fro2_upper(dG.p, ncols, F, dfro.p, c->stream);
         sdm_launch_add_diag(dG.p, ncols, F, dfro.p + F, reg_type, reg_param, N, regularise_last_row, c->lambda_dev.p, c->stream);
     }
+    if ((rc = solve_update_scratch(c, ncols))) return rc;
     { Timer t(c, SDM_T_FACTOR); (void)sdm_launch_cholesky_solve(dG.p, ncols, F, Fp, Mp, dR.p, Mp, dW.p, c->status.p, c->stream, &c->solve_aux); }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy2DAsync(R_host, (size_t)M * sizeof(float), dR.p, (size_t)Mp * sizeof(float), (size_t)M * sizeof(float), F,

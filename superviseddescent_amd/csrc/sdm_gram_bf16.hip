@@ -234,7 +234,7 @@ syrk_tn_bf16x3_w_kernel(const bf16x8* __restrict__ planes, int NG, int ncols2, i
 // so the fragment reads are issued by hand (ds_read_b128) and waited for by count: LDS reads return in order, eight reads per set.
 // Two float16 pieces only; eight waves make the load schedule static (three pieces per wave and slab, two on the diagonal).
 #define G8P_READ(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
-template <int NBUF, bool DIAG>
+template <int NBUF, bool DIAG, bool FOLD = true>      // FOLD: 256-row chunks folded into the second accumulator set `tot`
 __device__ inline void gram_w8p_body(const bf16x8* __restrict__ planes, int NG, int ncols2, int I, int j, bf16x8* lds,
                                      f32x16 (&acc)[2][2], f32x16 (&tot)[2][2])
 {
@@ -281,7 +281,7 @@ __device__ inline void gram_w8p_body(const bf16x8* __restrict__ planes, int NG, 
         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[SET][m][PA]),                            \
                                                            __builtin_bit_cast(f16x8, fb[SET][n][PB]), acc[m][n], 0, 0, 0);
 #define G8P_FOLD(S)                                                                                               \
-    if ((((S) + 1) & (GB_CHUNK_SLABS - 1)) == 0) {                                                                \
+    if (FOLD && (((S) + 1) & (GB_CHUNK_SLABS - 1)) == 0) {                                                                \
         _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                             \
         _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                             \
         _Pragma("unroll") for (int e = 0; e < 16; ++e) { tot[m][n][e] += acc[m][n][e]; acc[m][n][e] = 0.0f; }    \
@@ -383,6 +383,127 @@ syrk_tn_split_w8p_kernel(const bf16x8* __restrict__ planes, int NG, int ncols2, 
             }
 }
 
+// ---- the Cholesky's trailing update C -= P^T P on the float16 matrix cores (round 3): P = the 512 rows of a panel group
+// (sdm_solve.hip), i.e. rows of the upper factor U and of the forward-substituted right-hand sides.  |U_kj| <= sqrt(G_jj) for a
+// positive definite matrix, so ONE power-of-two scale per factorisation, taken from the largest diagonal entry before the
+// factorisation, keeps every scaled factor entry below 2^15; entries keep 22 significant bits down to 2^-18 of that bound and an
+// absolute error of 2^-40 of it below.  The right-hand-side columns are not bounded by the diagonal: their scale is taken per
+// group from the largest entry of the group's rows.  scales[0] = bits of the largest diagonal entry, scales[1 + slot] = bits of the
+// group's largest right-hand-side entry (two slots, alternating by group: the kernel that fills one clears the other for the next
+// group -- its last reader, the previous group's tail update, has finished by then).
+__device__ inline int f16_exponent_of(float bound)
+{
+    if (!(bound > 0.0f) || !(bound < 3.0e38f)) return 14;                              // (scale 1)
+    return (int)((__builtin_bit_cast(unsigned, bound) >> 23) & 0xff) - 127;            // floor(log2 bound): |entries| < 2^(e + 1)
+}
+__device__ inline int f16_factor_exponent(const unsigned* scales) { return f16_exponent_of(__builtin_sqrtf(__builtin_bit_cast(float, scales[0]))); }
+__device__ inline int f16_rhs_exponent(const unsigned* scales, int slot) { return f16_exponent_of(__builtin_bit_cast(float, scales[1 + slot])); }
+
+__global__ void __launch_bounds__(256) diag_absmax_kernel(const float* __restrict__ G, long long ldg, int F, unsigned* __restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float v = i < F ? __builtin_fabsf(G[(long long)i * ldg + i]) : 0.0f;
+    for (int o = 32; o; o >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __builtin_bit_cast(unsigned, v));      // (non-negative floats order like their bit patterns)
+}
+
+// largest |entry| of a rows x cols block (a panel group's right-hand-side columns, <= 512 x 256): one workgroup per 8 rows
+__global__ void __launch_bounds__(256) block_absmax_kernel(const float* __restrict__ P, long long ldp, int rows, int cols, unsigned* __restrict__ scales, int slot)
+{
+    float v = 0.0f;
+    for (int r = blockIdx.x * 8; r < blockIdx.x * 8 + 8 && r < rows; ++r)
+        for (int c = threadIdx.x; c < cols; c += 256) v = __builtin_fmaxf(v, __builtin_fabsf(P[(long long)r * ldp + c]));
+    for (int o = 32; o; o >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(scales + 1 + slot, __builtin_bit_cast(unsigned, v));
+    if (blockIdx.x == 0 && threadIdx.x == 0) scales[1 + (slot ^ 1)] = 0;
+}
+
+__global__ void __launch_bounds__(256)
+split_planes_f16_scaled_kernel(const float* __restrict__ A, long long lda, int N, int ncols_src, int ncols, int NG, f16x8* __restrict__ planes,
+                               const unsigned* __restrict__ scales, int slot, int rhs_col0, int* __restrict__ status)
+{
+    const int col = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+    if (col >= ncols) return;
+    const float scale = __builtin_ldexpf(1.0f, 14 - (col >= rhs_col0 ? f16_rhs_exponent(scales, slot) : f16_factor_exponent(scales)));
+    f16x8 p1, p2;
+    bool big = false;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const long long n = 8ll * g + j;
+        const float v = ((n < N && col < ncols_src) ? A[n * lda + col] : 0.0f) * scale;      // (a power of two: exact)
+        big = big || !(__builtin_fabsf(v) < 6.0e4f);
+        const _Float16 h1 = (_Float16)v;
+        const float r1 = v - (float)h1;                 // exact
+        p1[j] = h1; p2[j] = (_Float16)r1;
+    }
+    const size_t o = (size_t)g * ncols + col, plane = (size_t)NG * ncols;
+    planes[o] = p1; planes[plane + o] = p2;
+    if (big) atomicOr(status, 8);
+}
+
+// Workgroup -> (super-row I, tile column j).  The dispatcher deals consecutive workgroups round-robin to the eight XCDs, 32 CUs each
+// with one workgroup per CU: the upper triangle is listed in blocks of 4 super-rows x 8 columns, the list cut into eight equal
+// chunks, one per XCD, so the 32 workgroups in flight on an XCD share four row panels and eight column panels (4 x 512 KB +
+// 8 x 256 KB at 512 rows: the L2 of the XCD).
+template <int NBUF>
+__global__ void __launch_bounds__(512)
+syrk_update_f16_kernel(const bf16x8* __restrict__ planes, int NG, int ncols2, int Tloc, int TlocF, float* __restrict__ C, long long ldc,
+                       const unsigned* __restrict__ scales, int slot, int I_lo, int I_hi, int own_first, int own_stride, int chunk)
+{
+    // workgroup = super-row I (local tile rows 2 I, 2 I + 1) x local tile column j; C points at the trailing matrix' origin
+    int I, j;
+    if (!chunk) {     // a few super-rows (the head of the look-ahead): column by column over all XCDs
+        const int nI = I_hi - I_lo;
+        I = I_lo + (int)(blockIdx.x % nI);
+        j = (int)(blockIdx.x / nI);
+    } else {
+        // block b of the list (groups of four super-rows, each from its diagonal block to the right); XCD x = blockIdx.x % 8 serves
+        // the blocks x chunk ... (x + 1) chunk - 1, 32 workgroups per block
+        const int x = blockIdx.x & 7, q = blockIdx.x >> 3, NJB = (Tloc + 7) / 8, G = (I_hi - I_lo + 3) / 4;
+        int b = x * chunk + (q >> 5), Ig = 0, jb0 = 0;
+        if ((q >> 5) >= chunk) return;
+        for (;; ++Ig) {
+            if (Ig >= G) return;
+            jb0 = (I_lo + 4 * Ig) / 4;                      // column block of the group's first diagonal tile (2 I / 8)
+            if (b < NJB - jb0) break;
+            b -= NJB - jb0;
+        }
+        I = I_lo + 4 * Ig + ((q & 31) >> 3);
+        j = (jb0 + b) * 8 + (q & 7);
+    }
+    if (I >= I_hi || j >= Tloc || j < 2 * I || j < own_first || (j - own_first) % own_stride) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char gb_raw[];
+    bf16x8* lds = (bf16x8*)gb_raw;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
+    const long long gi0 = (long long)I * 256 + wr * 64;
+    const bool writes = !((gi0 >> 7) > j || gi0 >= (long long)TlocF * 128);      // (rows below the factor: right-hand sides x right-hand sides, never read)
+    // this wave's part of C is requested before the products (at most 512 rows, i.e. two 256-row chunks: one accumulator level,
+    // the registers of the second hold C): the read of the read-modify-write costs no time behind the last slab
+    float* Cw = C + (gi0 + 4 * (lane >> 5)) * ldc + (long long)j * 128 + wc * 64 + (lane & 31);
+    f32x16 acc[2][2], cin[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                acc[m][n][e] = 0.0f;
+                cin[m][n][e] = writes ? Cw[(long long)(m * 32 + (e & 3) + 8 * (e >> 2)) * ldc + n * 32] : 0.0f;
+            }
+    if ((j >> 1) == I) gram_w8p_body<NBUF, true, false>(planes, NG, ncols2, I, j, lds, acc, acc);
+    else gram_w8p_body<NBUF, false, false>(planes, NG, ncols2, I, j, lds, acc, acc);
+    if (!writes) return;
+    const int ef = f16_factor_exponent(scales);
+    const float unscale = __builtin_ldexpf(1.0f, (ef - 14) + ((j >= TlocF ? f16_rhs_exponent(scales, slot) : ef) - 14));
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                Cw[(long long)(m * 32 + (e & 3) + 8 * (e >> 2)) * ldc + n * 32] = cin[m][n][e] - acc[m][n][e] * unscale;
+}
+
 }  // namespace
 
 // (super-row I, tile column j >= 2 I) pairs of the 256 x 128 kernels in the order the workgroups take them: listed block by block
@@ -448,4 +569,55 @@ void sdm_launch_gram_bf16x3(const float* A, long long lda, int N, int ncols, voi
     else
         hipLaunchKernelGGL((syrk_tn_bf16x3_w_kernel<3, 3, false>), dim3((unsigned)ow.size()), dim3(1024), (size_t)3 * (3 * 2 * 384) * 16, stream,
                            (const bf16x8*)planes, NG, ncols2, ncols, C, ldc, d_ow, (int)ow.size());
+}
+
+// ---- trailing update of the blocked Cholesky on the float16 matrix cores (see syrk_update_f16_kernel) ----
+size_t sdm_update_f16_plane_bytes(int rows_max, int ncols)
+{
+    const size_t NG = (size_t)((rows_max + 31) / 32) * 4;
+    return 2 * NG * ((size_t)((ncols + 255) / 256) * 256) * 16;
+}
+
+void sdm_launch_diag_absmax(const float* G, long long ldg, int F, unsigned* scales, hipStream_t stream)
+{
+    (void)hipMemsetAsync(scales, 0, 3 * sizeof(unsigned), stream);
+    hipLaunchKernelGGL(diag_absmax_kernel, dim3((F + 255) / 256), dim3(256), 0, stream, G, ldg, F, scales);
+}
+
+void sdm_launch_update_split_f16(const float* P, long long ldp, int rows, int wcols, int wcols_factor, void* planes, unsigned* scales,
+                                 int slot, int* status, hipStream_t stream)
+{
+    // P: rows x wcols (the group's panel rows, from the first trailing column on); columns >= wcols_factor are right-hand sides
+    const int NG = ((rows + 31) / 32) * 4, ncols2 = ((wcols + 255) / 256) * 256;
+    if (wcols > wcols_factor)
+        hipLaunchKernelGGL(block_absmax_kernel, dim3((rows + 7) / 8), dim3(256), 0, stream, P + wcols_factor, ldp, rows, wcols - wcols_factor, scales, slot);
+    hipLaunchKernelGGL(split_planes_f16_scaled_kernel, dim3(ncols2 / 256, NG), dim3(256), 0, stream, P, ldp, rows, wcols, ncols2, NG,
+                       (f16x8*)planes, scales, slot, wcols_factor, status);
+}
+
+void sdm_launch_update_f16(const void* planes, int rows, int wcols, int wcols_factor, float* C, long long ldc, const unsigned* scales,
+                           int slot, int I_lo, int I_hi, int own_first, int own_stride, hipStream_t stream)
+{
+    // super-rows I_lo <= I < I_hi of the trailing matrix (local tile rows 2 I, 2 I + 1), local tile columns own_first + n own_stride
+    const int NG = ((rows + 31) / 32) * 4, ncols2 = ((wcols + 255) / 256) * 256, Tloc = wcols / GB_TILE, TlocF = wcols_factor / GB_TILE;
+    const int TI = (TlocF + 1) / 2;                      // super-rows that hold factor rows
+    if (I_hi > TI) I_hi = TI;
+    if (I_lo >= I_hi || own_first >= Tloc) return;
+    static unsigned long long attr = 0;
+    if (sdm_first_use_on_device(attr))
+        SDM_SET_ATTR((const void*)syrk_update_f16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const int nI = I_hi - I_lo;
+    unsigned grid;
+    int chunk = 0;
+    if (nI <= 4) grid = (unsigned)(nI * Tloc);
+    else {
+        const int NJB = (Tloc + 7) / 8, G = (nI + 3) / 4;
+        int blocks = 0;
+        for (int Ig = 0; Ig < G; ++Ig) blocks += NJB - (I_lo + 4 * Ig) / 4;
+        chunk = (blocks + 7) / 8;
+        grid = (unsigned)(8 * chunk * 32);
+    }
+    if (!grid) return;
+    hipLaunchKernelGGL(syrk_update_f16_kernel<4>, dim3(grid), dim3(512), (size_t)4 * (2 * 2 * 384) * 16, stream,
+                       (const bf16x8*)planes, NG, ncols2, Tloc, TlocF, C, ldc, scales, slot, I_lo, I_hi, own_first, own_stride, chunk);
 }

@@ -203,7 +203,18 @@ inline void sdm_check_launch_attr(hipError_t e, const char* what)
 #define SDM_SET_ATTR(...) sdm_check_launch_attr(hipFuncSetAttribute(__VA_ARGS__), #__VA_ARGS__)
 
 // second queue + two events for the look-ahead of the blocked Cholesky (optional)
-struct SolveAux { hipStream_t stream; hipEvent_t chain_done, tail_done; };
+struct SolveAux {
+    hipStream_t stream; hipEvent_t chain_done, tail_done;
+    // scratch of the float16 trailing update (sdm_gram_bf16.hip): planes of one panel group (sdm_update_f16_plane_bytes(512, ncols))
+    // and three scale words (largest diagonal entry, largest right-hand-side entry of the group x two slots); null = every trailing update on the f32 matrix-core kernel
+    void* upd_planes; unsigned* upd_maxdiag;
+};
+size_t sdm_update_f16_plane_bytes(int rows_max, int ncols);
+void sdm_launch_diag_absmax(const float* G, long long ldg, int F, unsigned* scales, hipStream_t stream);
+void sdm_launch_update_split_f16(const float* P, long long ldp, int rows, int wcols, int wcols_factor, void* planes, unsigned* scales,
+                                 int slot, int* status, hipStream_t stream);
+void sdm_launch_update_f16(const void* planes, int rows, int wcols, int wcols_factor, float* C, long long ldc, const unsigned* scales,
+                           int slot, int I_lo, int I_hi, int own_first, int own_stride, hipStream_t stream);
 // Sharded factorisation: every rank holds the same regularised system; rank r performs the tile operations of
 // the tile columns j with j % world == r.  Per 128-column step the owner of the step's column broadcasts its factored
 // diagonal tile and the column's tiles of the open panel group (<= 4 tiles); per group of 4 steps the ranks all-gather the

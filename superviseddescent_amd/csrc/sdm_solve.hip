@@ -1098,6 +1098,10 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
     // sides; the back substitution is replicated.
     const int LAZY = 4;
     const bool overlap = aux && aux->stream && Tf > 2 * LAZY;
+    static const bool upd_f32_only = getenv("SDM_UPDATE_F32") && getenv("SDM_UPDATE_F32")[0] == '1';      // (A/B: every trailing update on the f32 kernel)
+    static const int upd_min_tiles = getenv("SDM_UPDATE_F16_MIN_TILES") ? atoi(getenv("SDM_UPDATE_F16_MIN_TILES")) : 40;
+    const bool upd_f16 = aux && aux->upd_planes && aux->upd_maxdiag && !upd_f32_only;
+    if (upd_f16) sdm_launch_diag_absmax(G, ldg, F, aux->upd_maxdiag, stream);
     const int W = shard ? shard->world : 1, me = shard ? shard->rank : 0;
     bool tail_pending = false;
     for (int k = 0; k < Tf; ++k) {
@@ -1140,15 +1144,28 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
                 if (rc) { if (tail_pending) (void)hipStreamWaitEvent(stream, aux->tail_done, 0); return rc; }
                 hipLaunchKernelGGL(tiles_gather_kernel, dim3(ncmax, nr, W), dim3(256), 0, stream, G, ldg, recv, g0, nr, k + 1, T, W, 0, ncmax, 1, me);
             }
+            // A wide trailing matrix is updated on the float16 matrix cores (sdm_gram_bf16.hip: two pieces per entry; one scale per
+            // factorisation for the factor columns, from the largest diagonal entry, one per group for the right-hand-side columns).
+            // Chosen from the global shape only: the same tile is computed by the same instructions for any number of ranks.
+            const int Tloc = Tf - (k + 1);
+            const bool f16u = upd_f16 && Tloc >= upd_min_tiles;
+            auto update = [&](int ti0, int tile_rows, hipStream_t st) {
+                if (!f16u) { sdm_launch_syrk_tn(panels, ldg, prow, ncols, G, ldg, -1.0f, 1, ti0, st, tile_rows, me, W); return; }
+                const int r0 = ti0 - (k + 1);                       // first local tile row: 0 (head / everything) or LAZY (tail)
+                const int first = (((me - (k + 1)) % W) + W) % W;   // first owned local column
+                sdm_launch_update_f16(aux->upd_planes, prow, ntr * TILE, Tloc * TILE, G + (long long)(k + 1) * TILE * ldg + (long long)(k + 1) * TILE, ldg,
+                                      aux->upd_maxdiag, (k / LAZY) & 1, r0 / 2, tile_rows > 0 ? (r0 + tile_rows) / 2 : (1 << 30), first, W, st);
+            };
+            if (overlap && tail_pending) (void)hipStreamWaitEvent(stream, aux->tail_done, 0);   // head rows were tail rows of the last group (and its tail read the planes)
+            if (f16u) sdm_launch_update_split_f16(panels + (long long)(k + 1) * TILE, ldg, prow, ntr * TILE, Tloc * TILE, aux->upd_planes, aux->upd_maxdiag, (k / LAZY) & 1, status, stream);
             if (!overlap) {
-                sdm_launch_syrk_tn(panels, ldg, prow, ncols, G, ldg, -1.0f, 1, k + 1, stream, 0, me, W);
+                update(k + 1, 0, stream);
             } else {
                 (void)hipEventRecord(aux->chain_done, stream);
-                if (tail_pending) (void)hipStreamWaitEvent(stream, aux->tail_done, 0);   // head rows were tail rows of the last group
-                sdm_launch_syrk_tn(panels, ldg, prow, ncols, G, ldg, -1.0f, 1, k + 1, stream, LAZY, me, W);
+                update(k + 1, LAZY, stream);
                 if (k + 1 + LAZY < T) {
                     (void)hipStreamWaitEvent(aux->stream, aux->chain_done, 0);
-                    sdm_launch_syrk_tn(panels, ldg, prow, ncols, G, ldg, -1.0f, 1, k + 1 + LAZY, aux->stream, 0, me, W);
+                    update(k + 1 + LAZY, 0, aux->stream);
                     (void)hipEventRecord(aux->tail_done, aux->stream);
                     tail_pending = true;
                 }
