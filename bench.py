@@ -37,18 +37,19 @@ MFMA_F16_PEAK_TF = 2500.0  # f16 / bf16-input MFMA dense peak (the Gram launch: 
 
 
 def gram_report(exec_flops, useful_flops, ms):
-    """The Gram launch forms every f32 product from four float16 piece products on the 16-bit matrix cores (csrc/sdm_gram_bf16.hip):
+    """The Gram launch forms every f32 product from three float16 piece products on the 16-bit matrix cores (csrc/sdm_gram_bf16.hip):
     `achieved` counts f32-equivalent flops (upper 128 x 128 tiles incl. padding + right-hand-side tile columns), `peak` is the f16
-    matrix-core peak / 4; the split pre-pass is inside the timed stage."""
+    matrix-core peak / 3; the split pre-pass is inside the timed stage."""
     if ms <= 0:
         return None
     tf = exec_flops / (ms * 1e-3) / 1e12
-    return {"kernel": "split_planes_f16_kernel+syrk_tn_bf16x3_w_kernel", "bound": "mfma", "unit": "TFLOP/s (f32-equivalent)",
-            "peak": MFMA_F16_PEAK_TF / 4.0, "achieved": tf, "frac": tf / (MFMA_F16_PEAK_TF / 4.0),
+    return {"kernel": "split_planes_f16_kernel+syrk_tn_split_w8p_kernel", "bound": "mfma", "unit": "TFLOP/s (f32-equivalent)",
+            "peak": MFMA_F16_PEAK_TF / 3.0, "achieved": tf, "frac": tf / (MFMA_F16_PEAK_TF / 3.0),
             "useful_tflops": useful_flops / (ms * 1e-3) / 1e12, "times_f32_mfma_peak": tf / MFMA_F32_PEAK_TF,
             "stage_ms": ms,
-            "note": "every f32 operand = two float16 pieces (x 2^12), four piece products per product, float32 accumulation; measured "
-                    "against a float64 product: 1.1e-7 ... 2.9e-7 relative (the f32 matrix-core kernel it replaces: 2.4e-7 ... 3.5e-7)"}
+            "note": "every f32 operand = two float16 pieces (x 2^12), three piece products per product (low x low is below float32's "
+                    "rounding), float32 accumulation; measured against a float64 product: 1.1e-7 ... 2.9e-7 relative (the f32 "
+                    "matrix-core kernel it replaces: 2.4e-7 ... 3.5e-7)"}
 
 
 def parse():

@@ -901,7 +901,7 @@ int sdm_gram_rhs(sdm_ctx* c, int level)
     HIP_TRY(hipMemset2DAsync(c->feat.p + Fp, (size_t)c->ldf * sizeof(float), 0, 128 * c->rhs_tiles * sizeof(float), c->N, c->stream));
     sdm_launch_targets(c->x[c->cur].p, c->xstar.p, c->N, c->L, c->eyes, c->feat.p, c->ldf, Fp, c->stream);
     // Round 3: the Gram launch runs on the 16-bit matrix cores with float32 accuracy (sdm_gram_bf16.hip): every operand split into two
-    // float16 pieces (x 2^12), four piece products per product; should an operand leave float16's range -- a training target beyond
+    // float16 pieces (x 2^12), three piece products per product; should an operand leave float16's range -- a training target beyond
     // 14 inter-eye distances -- the launch is repeated with three bf16 pieces (float32's range, six products).  SDM_GRAM_F32=1: the
     // f32 matrix-core kernel of rounds 1-2 (A/B); SDM_GRAM_BF16X3=1: always the three-bf16 form.
     static const bool gram_f32 = getenv("SDM_GRAM_F32") && getenv("SDM_GRAM_F32")[0] == '1';

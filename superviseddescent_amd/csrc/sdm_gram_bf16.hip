@@ -4,8 +4,10 @@
 // gfx950 multiplies f32 operands on its matrix cores at 64 flop / clk / SIMD (157 TF, the vector rate) but 16-bit operands at 16x
 // that.  Every f32 feature a is therefore split, once per launch, into 16-bit pieces whose products are EXACT in float32 and are
 // accumulated in float32 by the matrix core:
-//   * shipped form: two float16 pieces of a 2^12 (11 + 11 significant bits = float32's own rounding unit), four piece products per
-//     product -- 4/16 of one f32 product, 4 bytes per element;
+//   * shipped form: two float16 pieces of a 2^12 (11 + 11 significant bits = float32's own rounding unit), three piece products per
+//     product (high x high, high x low, low x high; low x low is at most 2^-22 of the product, 2^-26 typically, of either sign --
+//     below float32's rounding of the sum: measured error against float64 identical with and without it) -- 3/16 of one f32
+//     product, 4 bytes per element;
 //   * fallback with float32's RANGE: three bf16 pieces a = a1 + a2 + a3 (|a - (a1 + a2 + a3)| <= 2^-26 |a|) and the six piece products
 //     that matter, a1 b1 + (a1 b2 + a2 b1) + (a2 b2 + a1 b3 + a3 b1); the dropped terms are below 2^-26 |a b|.  Taken when an
 //     operand would overflow float16 (the split kernel raises a flag, the caller repeats the launch).
@@ -59,7 +61,7 @@ split_planes_kernel(const float* __restrict__ A, long long lda, int N, int ncols
 }
 
 // The same with TWO float16 pieces of the operand scaled by 2^12: a 2^12 = h1 + h2, 11 + 11 significant bits (|a 2^12 - h1 - h2| <=
-// 2^-23 |a 2^12|: float32's own rounding unit), products h1 h1 + h1 h2 + h2 h1 + h2 h2 exact in float32 -- four f16 products per
+// 2^-23 |a 2^12|: float32's own rounding unit), products h1 h1 + h1 h2 + h2 h1 (+ h2 h2, dropped by the eight-wave kernel) exact in float32 -- three or four f16 products per
 // product instead of six bf16 ones, 4 bytes per element instead of 6.  float16 overflows at 65 504: HOG features are below 0.43 and
 // the bias is 1 (x 4096: 4096), the training targets are landmark distances over the inter-eye distance; should any |a| 2^12 reach
 // 6 x 10^4 the kernel raises `flag` and the caller repeats the launch with the three-bf16 kernels.
@@ -280,6 +282,13 @@ __device__ inline void gram_w8p_body(const bf16x8* __restrict__ planes, int NG, 
     _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                                                \
         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[SET][m][PA]),                            \
                                                            __builtin_bit_cast(f16x8, fb[SET][n][PB]), acc[m][n], 0, 0, 0);
+    // the product of the two low pieces is at most 2^-22 of the product (2^-26 typically, either sign): below float32's own rounding
+    // of the sum, and a quarter of the matrix instructions (SDM_GRAM_4PRODUCTS=1 at build time keeps it, A/B)
+#ifdef SDM_GRAM_4PRODUCTS
+#define G8P_LL(SET) G8P_M(SET, 1, 1)
+#else
+#define G8P_LL(SET)
+#endif
 #define G8P_FOLD(S)                                                                                               \
     if (FOLD && (((S) + 1) & (GB_CHUNK_SLABS - 1)) == 0) {                                                                \
         _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                             \
@@ -293,7 +302,7 @@ __device__ inline void gram_w8p_body(const bf16x8* __restrict__ planes, int NG, 
     {                                                                                              \
         __builtin_amdgcn_s_waitcnt(0xc07f);          /* lgkmcnt(0): set CUR has arrived */         \
         __builtin_amdgcn_sched_barrier(0);                                                         \
-        G8P_M(CUR, 1, 1) G8P_M(CUR, 0, 1)                                                          \
+        G8P_LL(CUR) G8P_M(CUR, 0, 1)                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         __builtin_amdgcn_s_waitcnt(0x0f70 | (MINE * (NBUF - 3)));                                  \
         __builtin_amdgcn_s_barrier();                                                              \
@@ -309,7 +318,7 @@ __device__ inline void gram_w8p_body(const bf16x8* __restrict__ planes, int NG, 
     {                                                                                              \
         __builtin_amdgcn_s_waitcnt(0xc07f);                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                         \
-        G8P_M(CUR, 1, 1) G8P_M(CUR, 0, 1)                                                          \
+        G8P_LL(CUR) G8P_M(CUR, 0, 1)                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         if ((S) + 1 < nslabs) {                                                                    \
             __builtin_amdgcn_s_waitcnt(0x0f70);                                                    \
@@ -343,6 +352,7 @@ __device__ inline void gram_w8p_body(const bf16x8* __restrict__ planes, int NG, 
 #undef G8P_TAIL
 #undef G8P_STEP
 #undef G8P_FOLD
+#undef G8P_LL
 #undef G8P_M
 #undef G8P_READSET
 }

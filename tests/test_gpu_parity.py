@@ -318,8 +318,8 @@ def _gram_of(ctx, F, M):
 
 @pytest.mark.parametrize("far", [False, True], ids=["float16_pieces", "target_beyond_float16_range"])
 def test_gram_on_the_16_bit_matrix_cores_has_float32_accuracy(faces, far):
-    """Round 3: A^T A and A^T b (regressors.hpp:208,225) are formed from two float16 pieces per f32 operand, four piece products per
-    product (csrc/sdm_gram_bf16.hip) -- against a float64 product of the same features the result must be as close as a float32
+    """Round 3: A^T A and A^T b (regressors.hpp:208,225) are formed from two float16 pieces per f32 operand, three piece products per
+    product (csrc/sdm_gram_bf16.hip; the low x low product is below float32's rounding) -- against a float64 product of the same features the result must be as close as a float32
     accumulation is (measured 1.1e-7 ... 2.9e-7 relative Frobenius; the f32 matrix-core kernel: 2.4e-7 ... 3.5e-7).  Training targets
     beyond float16's range (a landmark 30 inter-eye distances off) make the launch repeat itself with three bf16 pieces: same
     accuracy, and the repeat is counted."""
