@@ -134,6 +134,8 @@ def main():
     # sharding does not shorten (profiles/r02_sharded_solve_timing.json); it pays at F = 27 201 (RCR-68)
     shard_solve = use_dist and os.environ.get("SDM_BENCH_SHARD_SOLVE", "0") == "1"
     solve_collectives = parallel.make_torch_solve_collectives(local_rank) if shard_solve else None
+    # with a sharded solve the exchange is a reduce-scatter of the owned tile columns + a small all-reduce (half the ring traffic)
+    reduce_scatter = parallel.make_torch_reduce_scatter(local_rank) if use_dist else None
     nlsr = []
     train_wall = []
     for rep in range(2):    # the second pass is the measured one (buffers allocated, code loaded)
@@ -145,6 +147,7 @@ def main():
         t1 = time.perf_counter()
         sdo.train(txs, tx0, None, hog, allreduce=allreduce, world_size=world, n_train_global=n_train_global,
                   rank=rank if shard_solve else None, solve_collectives=solve_collectives,
+                  reduce_scatter=reduce_scatter if shard_solve else None,
                   on_training_epoch_callback=(lambda cur: nlsr.append(float(np.linalg.norm(cur - txs) / np.linalg.norm(txs))))
                   if rep == 0 else None)
         if use_dist:
@@ -182,7 +185,7 @@ def main():
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             sdo68.train(txs68, tx068, None, hog68, allreduce=allreduce, world_size=world, n_train_global=n_train_global,
-                        rank=rank if shard68 else None, solve_collectives=coll68,
+                        rank=rank if shard68 else None, solve_collectives=coll68, reduce_scatter=reduce_scatter if shard68 else None,
                         on_training_epoch_callback=(lambda cur: nlsr68.append(float(np.linalg.norm(cur - txs68) / np.linalg.norm(txs68))))
                         if rep == 0 else None)
             if use_dist:
@@ -208,7 +211,9 @@ def main():
                             "MatrixNorm 1.5, synthetic 256x256 faces" % (F68, M68, n_train_global, world),
                 "rows_total": int(n_train_global), "rows_per_gpu": n_rows68,
                 "sec_per_cascade": wall68[-1] / n_levels, "scaling": "strong",
-                "collective": "one all-reduce of {A^T A, A^T b} per level (torch.distributed nccl = RCCL)" if use_dist else "none (1 GPU)",
+                "collective": ("one reduce-scatter of the owned tile columns of {A^T A, A^T b} + an all-reduce of F + 1 floats per level "
+                               "(torch.distributed nccl = RCCL)" if shard68 else
+                               "one all-reduce of {A^T A, A^T b} per level (torch.distributed nccl = RCCL)" if use_dist else "none (1 GPU)"),
                 "solve": ("sharded over the ranks by tile column" if shard68 else "replicated on every rank" if use_dist else "single GPU"),
                 "stage_ms_per_level_rank0": {k: v[0] / n_levels for k, v in timing68.items()},
                 "gram": gram_report(gram_exec, n_rows68 * float(F68) * (F68 + 1) + 2.0 * n_rows68 * F68 * M68, gram_ms),
@@ -418,7 +423,9 @@ def main():
             "rows_per_gpu": int(txs.shape[0]),
             "sec_per_cascade": train_wall[-1] / n_levels,
             "scaling": "strong",
-            "collective": "one all-reduce of {A^T A, A^T b} per level (torch.distributed nccl = RCCL)" if use_dist else "none (1 GPU)",
+            "collective": ("one reduce-scatter of the owned tile columns of {A^T A, A^T b} + an all-reduce of F + 1 floats per level "
+                           "(torch.distributed nccl = RCCL)" if shard_solve else
+                           "one all-reduce of {A^T A, A^T b} per level (torch.distributed nccl = RCCL)" if use_dist else "none (1 GPU)"),
             "solve": ("sharded over the ranks by tile column: one <= 4-tile broadcast per 128-column step, one all-gather per 4 steps"
                       if shard_solve else "replicated on every rank" if use_dist else "single GPU"),
             "stage_ms_per_level_rank0": {k: v[0] / n_levels for k, v in train_timing.items()},

@@ -205,6 +205,18 @@ int sdm_set_solve_sharding(sdm_ctx* ctx, int rank, int world_size, sdm_bcast_fn 
  * ncclBroadcast / ncclAllGather in the process, then in librccl.so). */
 int sdm_set_solve_sharding_rccl(sdm_ctx* ctx, void* nccl_comm, int rank, int world_size, void* nccl_broadcast_fn,
                                 void* nccl_allgather_fn);
+/* Reduce-scatter form of the exchange (the reference trains in one process: regressors.hpp:208,225 form A^T A / A^T b once; here
+ * every rank forms them of ITS rows).  With the factorisation sharded over the same ranks (above) rank r only ever reads the tile
+ * columns it owns, so sdm_allreduce_gram_rhs then ships every rank the SUM of its own columns -- tiles grouped by owner, one
+ * reduce-scatter of world_size equal chunks: half the ring traffic of the all-reduce -- followed by one all-reduce of F + 1 floats
+ * (the summed diagonal and the ranks' shares of ||G||_F^2) through the callback / communicator registered with sdm_set_allreduce*.
+ *   reduce_scatter: every rank contributes world_size * count_f32 floats at send_ptr (chunk r destined for rank r); recv_ptr
+ *                   receives the element-wise sum over the ranks of this rank's chunk (count_f32 floats); stream-ordered
+ * Without it, or with a replicated solve, the exchange stays the all-reduce.  NULL / enable = 0 removes it. */
+typedef int (*sdm_reduce_scatter_fn)(const void* send_ptr, void* recv_ptr, size_t count_f32, void* hip_stream, void* user);
+int sdm_set_reduce_scatter(sdm_ctx* ctx, sdm_reduce_scatter_fn fn, void* user);
+/* The same through RCCL on the communicator given to sdm_set_allreduce_rccl; the address may be NULL (looked up as ncclReduceScatter). */
+int sdm_set_reduce_scatter_rccl(sdm_ctx* ctx, int enable, void* nccl_reduce_scatter_fn);
 /* Regulariser::get_matrix (regressors.hpp:126-148) with n_train = the GLOBAL sample count, add to the
  * diagonal (regressors.hpp:215-221), factor and solve (regressors.hpp:224-225; Cholesky instead of
  * PartialPivLU: the regularised Gram matrix is SPD).  Stores R as the level's regressor; R_host may be NULL. */

@@ -26,7 +26,7 @@ EXPORTED = [
     "sdm_set_sample_image_index", "sdm_set_x", "sdm_get_x", "sdm_set_x_device", "sdm_get_x_device",
     "sdm_hog_features", "sdm_get_patch_indices", "sdm_set_regressor", "sdm_get_regressor", "sdm_apply",
     "sdm_detect_batch", "sdm_set_targets", "sdm_gram_rhs", "sdm_set_allreduce", "sdm_set_allreduce_rccl", "sdm_allreduce_gram_rhs",
-    "sdm_set_solve_sharding", "sdm_set_solve_sharding_rccl",
+    "sdm_set_solve_sharding", "sdm_set_solve_sharding_rccl", "sdm_set_reduce_scatter", "sdm_set_reduce_scatter_rccl",
     "sdm_set_templates", "sdm_init_from_boxes", "sdm_normalised_errors", "sdm_solve", "sdm_solve_normal_equations", "sdm_train_level", "sdm_gram_device_ptr", "sdm_x_device_ptr", "sdm_features_device_ptr",
     "sdm_enable_timing", "sdm_get_timing", "sdm_debug_patch", "sdm_debug_hog_profile", "sdm_debug_gradient_table",
     "sdm_debug_set_hog_packing", "sdm_debug_gram_fallbacks", "sdm_debug_hog_plan", "sdm_upload_images_bgr_u8", "sdm_debug_download_images",
@@ -126,6 +126,8 @@ def lib() -> ctypes.CDLL:
             "sdm_set_allreduce_rccl": [c_void_p, c_void_p, c_void_p, c_int],
             "sdm_set_solve_sharding": [c_void_p, c_int, c_int, BCAST_FN, ALLGATHER_FN, c_void_p],
             "sdm_set_solve_sharding_rccl": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
+            "sdm_set_reduce_scatter": [c_void_p, ALLGATHER_FN, c_void_p],          # (same shape: send, recv, count per rank, stream, user)
+            "sdm_set_reduce_scatter_rccl": [c_void_p, c_int, c_void_p],
             "sdm_solve": [c_void_p, c_int, c_int, ctypes.c_float, c_int, ctypes.c_longlong, c_float_p, c_float_p],
             "sdm_train_level": [c_void_p, c_int, c_int, ctypes.c_float, c_int, ctypes.c_longlong],
             "sdm_solve_normal_equations": [c_void_p, c_float_p, c_int, c_int, c_float_p, c_int, c_int, ctypes.c_float, c_int,

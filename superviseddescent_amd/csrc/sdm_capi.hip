@@ -150,6 +150,12 @@ struct sdm_ctx {
     int (*rccl_bcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*rccl_allgather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     DevBuf<float> shard_stage;
+    // reduce-scatter exchange of the Gram matrix (sdm_set_reduce_scatter*): used by sdm_allreduce_gram_rhs when the solve is sharded
+    sdm_reduce_scatter_fn reduce_scatter = nullptr;
+    void* reduce_scatter_user = nullptr;
+    int (*rccl_reduce_scatter)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    bool g_scattered = false;                     // the Gram matrix holds the summed tiles of the OWNED tile columns only
+    DevBuf<float> gsmall;                         // summed diagonal + the Frobenius share (the small all-reduce of that exchange)
 
     // timing
     bool timing = false;
@@ -896,6 +902,7 @@ int sdm_gram_rhs(sdm_ctx* c, int level)
     const int Fp = round_up(F, 128), ncols = Fp + 128 * c->rhs_tiles;
     int rc = c->G.ensure((size_t)ncols * ncols);
     if (rc) return rc;
+    c->g_scattered = false;
     Timer t(c, SDM_T_GRAM);
     // the tail tile of every feature row holds b; clear it first (columns beyond 2L must be 0)
     HIP_TRY(hipMemset2DAsync(c->feat.p + Fp, (size_t)c->ldf * sizeof(float), 0, 128 * c->rhs_tiles * sizeof(float), c->N, c->stream));
@@ -962,6 +969,24 @@ int sdm_set_allreduce_rccl(sdm_ctx* c, void* nccl_comm, void* nccl_allreduce_fn,
     return SDM_OK;
 }
 
+int sdm_set_reduce_scatter(sdm_ctx* c, sdm_reduce_scatter_fn fn, void* user)
+{
+    if (!c) return fail(SDM_ERR_INVALID, "null handle");
+    c->reduce_scatter = fn; c->reduce_scatter_user = user; c->rccl_reduce_scatter = nullptr;
+    return SDM_OK;
+}
+
+int sdm_set_reduce_scatter_rccl(sdm_ctx* c, int enable, void* nccl_reduce_scatter_fn)
+{
+    if (!c) return fail(SDM_ERR_INVALID, "null handle");
+    c->reduce_scatter = nullptr; c->reduce_scatter_user = nullptr; c->rccl_reduce_scatter = nullptr;
+    if (!enable) return SDM_OK;
+    if (!nccl_reduce_scatter_fn) nccl_reduce_scatter_fn = find_rccl_symbol("ncclReduceScatter");
+    if (!nccl_reduce_scatter_fn) return fail(SDM_ERR_COMM, "ncclReduceScatter not found: pass its address, or make librccl.so loadable");
+    c->rccl_reduce_scatter = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))nccl_reduce_scatter_fn;
+    return SDM_OK;
+}
+
 namespace {
 int shard_bcast_thunk(void* self, float* buf, size_t count, int root, hipStream_t stream)
 {
@@ -1024,6 +1049,43 @@ int sdm_allreduce_gram_rhs(sdm_ctx* c)
     // only the tiles the solve reads travel: upper Gram tiles + RHS tile columns, packed back to back
     HIP_TRY(hipSetDevice(c->device));
     const int F = level_F(c, c->g_level);
+    // Reduce-scatter instead, when the factorisation is sharded over the same ranks: a rank's share of the factorisation reads its
+    // own tile columns only, so each rank needs the SUM of its columns, not of the whole matrix -- half the bytes on the ring.  What
+    // every rank needs of the others' columns is small and follows in ONE all-reduce of F + 1 floats: the summed diagonal (the
+    // float16 updates' scale is taken from its largest entry) and the ranks' shares of ||G||_F^2 (MatrixNorm).
+    const bool sharded = c->shard_world >= 1 && (c->shard_comm || c->shard_bcast) && c->shard_world == c->world_size;
+    const bool can_rs = c->reduce_scatter || (c->rccl_reduce_scatter && c->rccl_comm);
+    if (sharded && can_rs) {
+        const int W = c->shard_world, me = c->shard_rank;
+        const size_t chunk = sdm_owned_chunk_tiles(F, c->rhs_tiles, W) * 128 * 128;
+        int rc = c->gpack.ensure((size_t)(W + 1) * chunk);
+        if (rc) return rc;
+        if ((rc = c->gsmall.ensure((size_t)F + 1)) || (rc = c->fro.ensure((size_t)F + 1))) return rc;
+        float* send = c->gpack.p;
+        float* recv = c->gpack.p + (size_t)W * chunk;
+        sdm_launch_tiles_pack_owned(c->G.p, c->g_ncols, F, c->rhs_tiles, W, me, send, 0, c->stream);
+        HIP_TRY(hipGetLastError());
+        int rcn;
+        if (c->rccl_reduce_scatter)   // ncclReduceScatter(sendbuff, recvbuff, recvcount, ncclFloat32 = 7, ncclSum = 0, comm, stream)
+            rcn = c->rccl_reduce_scatter(send, recv, chunk, 7, 0, c->rccl_comm, c->stream);
+        else
+            rcn = c->reduce_scatter(send, recv, chunk, (void*)c->stream, c->reduce_scatter_user);
+        if (rcn != 0) return fail(SDM_ERR_COMM, "reduce-scatter failed with status " + std::to_string(rcn));
+        sdm_launch_tiles_pack_owned(c->G.p, c->g_ncols, F, c->rhs_tiles, W, me, recv, 1, c->stream);
+        // the small exchange: [diagonal of the owned columns, 0 elsewhere | this rank's share of ||G||_F^2]
+        sdm_launch_diag_owned(c->G.p, c->g_ncols, F, W, me, c->gsmall.p, 0, c->stream);
+        sdm_launch_fro2_upper(c->G.p, c->g_ncols, F, c->fro.p, c->stream, me, W);
+        sdm_launch_small_exchange_pack(c->fro.p + F, c->gsmall.p + F, 0, nullptr, c->stream);
+        HIP_TRY(hipGetLastError());
+        if (c->rccl_comm) rcn = c->rccl_allreduce(c->gsmall.p, c->gsmall.p, (size_t)F + 1, 7, 0, c->rccl_comm, c->stream);
+        else rcn = c->allreduce(c->gsmall.p, (size_t)F + 1, (void*)c->stream, c->allreduce_user);
+        if (rcn != 0) return fail(SDM_ERR_COMM, "all-reduce of the diagonal failed with status " + std::to_string(rcn));
+        sdm_launch_diag_owned(c->G.p, c->g_ncols, F, W, me, c->gsmall.p, 1, c->stream);
+        sdm_launch_small_exchange_pack(nullptr, c->gsmall.p + F, 1, c->fro.p + F, c->stream);
+        HIP_TRY(hipGetLastError());
+        c->g_scattered = true;
+        return SDM_OK;
+    }
     const size_t count = sdm_packed_tiles_count(F, c->rhs_tiles);
     int rc = c->gpack.ensure(count);
     if (rc) return rc;
@@ -1057,7 +1119,7 @@ int sdm_solve(sdm_ctx* c, int level, int reg_type, float reg_param, int regulari
     if ((rc = c->Rt[level].ensure((size_t)Mp * c->ldf))) return rc;
     {
         Timer t(c, SDM_T_REG);
-        if (reg_type == SDM_REG_MATRIX_NORM) sdm_launch_fro2_upper(c->G.p, ncols, F, c->fro.p, c->stream);
+        if (reg_type == SDM_REG_MATRIX_NORM && !c->g_scattered) sdm_launch_fro2_upper(c->G.p, ncols, F, c->fro.p, c->stream);      // (reduce-scattered: the ranks' shares were summed with the exchange)
         sdm_launch_add_diag(c->G.p, ncols, F, c->fro.p + F, reg_type, reg_param,
                             (int)(n_train_global > 0 ? n_train_global : c->N), regularise_last_row,
                             c->lambda_dev.p, c->stream);
@@ -1067,6 +1129,8 @@ int sdm_solve(sdm_ctx* c, int level, int reg_type, float reg_param, int regulari
         // factor + forward substitution (the back substitution is part of the same launcher)
         SolveShard shard{};
         const bool sharded = c->shard_world >= 1 && (c->shard_comm || c->shard_bcast);
+        if (c->g_scattered && !(sharded && c->shard_world == c->world_size))
+            return fail(SDM_ERR_INVALID, "sdm_solve: the Gram matrix was reduce-scattered over the ranks; the factorisation must be sharded over the same ranks");
         if (sharded) {
             if ((rc = c->shard_stage.ensure(sdm_solve_shard_stage_tiles(ncols, c->shard_world) * 128 * 128))) return rc;
             shard.rank = c->shard_rank; shard.world = c->shard_world; shard.stage = c->shard_stage.p; shard.self = c;

@@ -175,7 +175,12 @@ void sdm_launch_gram_bf16x3(const float* A, long long lda, int N, int ncols, voi
 // upper Gram tiles + RHS tile columns <-> one contiguous exchange buffer of sdm_packed_tiles_count() floats
 size_t sdm_packed_tiles_count(int F, int rhs_tiles);
 void sdm_launch_tiles_pack(float* G, long long ldg, int F, int rhs_tiles, float* P, int unpack, hipStream_t stream);
-void sdm_launch_fro2_upper(const float* G, long long ldg, int F, double* out, hipStream_t stream);
+void sdm_launch_fro2_upper(const float* G, long long ldg, int F, double* part_and_out, hipStream_t stream, int own_rank = 0, int own_world = 1);
+// reduce-scatter exchange of the Gram matrix (tiles grouped by owner, sdm_solve.hip)
+size_t sdm_owned_chunk_tiles(int F, int rhs_tiles, int W);
+void sdm_launch_tiles_pack_owned(float* G, long long ldg, int F, int rhs_tiles, int W, int me, float* P, int unpack, hipStream_t stream);
+void sdm_launch_diag_owned(float* G, long long ldg, int F, int W, int me, float* d, int scatter, hipStream_t stream);
+void sdm_launch_small_exchange_pack(const double* fro2, float* d_tail, int unpack, double* fro2_out, hipStream_t stream);
 void sdm_launch_add_diag(float* G, long long ldg, int F, const double* fro2, int reg_type, float param,
                          int n_train, int regularise_last_row, float* lambda_out, hipStream_t stream);
 

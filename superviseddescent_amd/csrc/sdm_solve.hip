@@ -391,12 +391,14 @@ syrk_tn_thin_kernel(const float* __restrict__ A, long long lda, int rows, float*
 }
 
 // ---- Frobenius norm of the symmetric matrix stored as its upper triangle ------------------------------
-__global__ void fro2_rows_kernel(const float* __restrict__ G, long long ldg, int F, double* __restrict__ part)
+__global__ void fro2_rows_kernel(const float* __restrict__ G, long long ldg, int F, double* __restrict__ part, int own_rank, int own_world)
 {
+    // own_world > 1: only the tile columns this rank owns (its share of a reduce-scattered matrix; the shares are summed by the caller)
     __shared__ double red[256];
     const int i = blockIdx.x;
     double s = 0.0;
     for (int j = i + threadIdx.x; j < F; j += 256) {
+        if (own_world > 1 && (j / TILE) % own_world != own_rank) continue;
         const double v = G[(long long)i * ldg + j];
         s += (j == i ? 1.0 : 2.0) * v * v;
     }
@@ -1037,6 +1039,50 @@ __global__ __launch_bounds__(256) void tiles_gather_kernel(float* G, long long l
     }
 }
 
+
+// ---- reduce-scatter exchange: the same tiles grouped by OWNER (tile column j belongs to rank j % W, as in the sharded factorisation):
+// chunk r = the upper tiles of rank r's factor columns, column by column (rows 0 .. j), then its right-hand-side columns (rows
+// 0 .. T - 1); all chunks padded to the largest.  After a reduce-scatter of the W chunks rank r holds the SUM of chunk r: exactly the
+// tiles its share of the factorisation reads, half the bytes of the all-reduce on the ring.
+__host__ __device__ inline long long owned_tiles_before(int c, int r, int W, int T)
+{
+    // tiles of rank r's owned columns number 0 .. c - 1 (column number c' is tile column r + W c')
+    const int nf = r < T ? (T - r + W - 1) / W : 0;           // owned factor columns
+    const int cf = c < nf ? c : nf;
+    return (long long)cf * (r + 1) + (long long)W * cf * (cf - 1) / 2 + (long long)(c - cf) * T;
+}
+
+__global__ __launch_bounds__(256) void tiles_pack_owned_kernel(float* G, long long ldg, int T, int TR, int W, float* P, long long chunk_tiles,
+                                                               int unpack, int only_rank)
+{
+    // grid (owned column number, tile row, rank): pack fills all W chunks, unpack reads the one chunk a rank received
+    const int c = blockIdx.x, ti = blockIdx.y, r = unpack ? only_rank : (int)blockIdx.z;
+    const int tj = r + W * c;
+    if (tj >= T + TR || (tj < T && ti > tj)) return;
+    const long long tile = (unpack ? 0 : (long long)r * chunk_tiles) + owned_tiles_before(c, r, W, T) + ti;
+    float4* p = (float4*)(P + tile * TILE * TILE);
+    for (int e = threadIdx.x; e < TILE * TILE / 4; e += 256) {
+        const int rr = e / (TILE / 4), c4 = e % (TILE / 4);
+        float4* g = (float4*)(G + (long long)(ti * TILE + rr) * ldg + (long long)tj * TILE) + c4;
+        if (unpack) *g = p[e]; else p[e] = *g;
+    }
+}
+
+// diagonal of the owned tile columns (zero elsewhere) -> d[0 .. F - 1]; and back: every rank writes the summed diagonal into its matrix
+__global__ __launch_bounds__(256) void diag_owned_kernel(float* G, long long ldg, int F, int W, int me, float* d, int scatter)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= F) return;
+    float* g = G + (long long)i * ldg + i;
+    if (scatter) *g = d[i];
+    else d[i] = (i / TILE) % W == me ? *g : 0.0f;
+}
+
+__global__ void small_exchange_pack_kernel(const double* fro2, float* d_tail, int unpack, double* fro2_out)
+{
+    if (unpack) *fro2_out = (double)*d_tail; else *d_tail = (float)*fro2;
+}
+
 size_t sdm_packed_tiles_count(int F, int rhs_tiles)
 {
     const size_t T = (size_t)(F + TILE - 1) / TILE;
@@ -1049,10 +1095,43 @@ void sdm_launch_tiles_pack(float* G, long long ldg, int F, int rhs_tiles, float*
     hipLaunchKernelGGL(tiles_pack_kernel, dim3(T + rhs_tiles, T), dim3(256), 0, stream, G, ldg, T, rhs_tiles, P, unpack);
 }
 
-void sdm_launch_fro2_upper(const float* G, long long ldg, int F, double* part_and_out, hipStream_t stream)
+
+size_t sdm_owned_chunk_tiles(int F, int rhs_tiles, int W)
+{
+    // tiles of the largest per-rank chunk
+    const int T = (F + TILE - 1) / TILE;
+    long long most = 0;
+    for (int r = 0; r < W; ++r) {
+        const int ncol = r < T + rhs_tiles ? (T + rhs_tiles - r + W - 1) / W : 0;
+        const long long n = owned_tiles_before(ncol, r, W, T);
+        if (n > most) most = n;
+    }
+    return (size_t)most;
+}
+
+void sdm_launch_tiles_pack_owned(float* G, long long ldg, int F, int rhs_tiles, int W, int me, float* P, int unpack, hipStream_t stream)
+{
+    const int T = (F + TILE - 1) / TILE;
+    const long long chunk = (long long)sdm_owned_chunk_tiles(F, rhs_tiles, W);
+    const int ncol = (T + rhs_tiles + W - 1) / W;
+    if (!unpack) (void)hipMemsetAsync(P, 0, (size_t)W * chunk * TILE * TILE * sizeof(float), stream);      // (the padding of the shorter chunks is summed too)
+    hipLaunchKernelGGL(tiles_pack_owned_kernel, dim3(ncol, T, unpack ? 1 : W), dim3(256), 0, stream, G, ldg, T, rhs_tiles, W, P, chunk, unpack, me);
+}
+
+void sdm_launch_diag_owned(float* G, long long ldg, int F, int W, int me, float* d, int scatter, hipStream_t stream)
+{
+    hipLaunchKernelGGL(diag_owned_kernel, dim3((F + 255) / 256), dim3(256), 0, stream, G, ldg, F, W, me, d, scatter);
+}
+
+void sdm_launch_small_exchange_pack(const double* fro2, float* d_tail, int unpack, double* fro2_out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(small_exchange_pack_kernel, dim3(1), dim3(1), 0, stream, fro2, d_tail, unpack, fro2_out);
+}
+
+void sdm_launch_fro2_upper(const float* G, long long ldg, int F, double* part_and_out, hipStream_t stream, int own_rank, int own_world)
 {
     // part_and_out: [F + 1] doubles; result in part_and_out[F]
-    hipLaunchKernelGGL(fro2_rows_kernel, dim3(F), dim3(256), 0, stream, G, ldg, F, part_and_out);
+    hipLaunchKernelGGL(fro2_rows_kernel, dim3(F), dim3(256), 0, stream, G, ldg, F, part_and_out, own_rank, own_world);
     hipLaunchKernelGGL(fro2_final_kernel, dim3(1), dim3(256), 0, stream, part_and_out, F, part_and_out + F);
 }
 

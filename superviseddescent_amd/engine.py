@@ -313,6 +313,30 @@ class Context:
         """The same through RCCL called by the library on its own stream; ``comm`` = ncclComm_t (None uninstalls)."""
         check(self._lib.sdm_set_solve_sharding_rccl(self._h, comm, rank, world_size, bcast_fn, allgather_fn))
 
+    def set_reduce_scatter(self, fn: Optional[Callable[[int, int, int, int], int]]):
+        """Reduce-scatter form of the Gram exchange (include/sdm.h: sdm_set_reduce_scatter), taken by ``allreduce_gram_rhs`` when the
+        solve is sharded over the same ranks: ``fn(send_ptr, recv_ptr, count_f32_per_rank, hip_stream) -> 0`` leaves the sum over
+        the ranks of this rank's chunk at ``recv_ptr``.  ``None`` restores the all-reduce."""
+        if fn is None:
+            check(self._lib.sdm_set_reduce_scatter(self._h, _lib.ALLGATHER_FN(), None))
+            self._keep_reduce_scatter = None
+            return
+
+        def tramp(send, recv, count, stream, _user):
+            try:
+                return int(fn(send, recv, count, stream) or 0)
+            except Exception:  # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = _lib.ALLGATHER_FN(tramp)
+        check(self._lib.sdm_set_reduce_scatter(self._h, cb, None))
+        self._keep_reduce_scatter = cb
+
+    def set_reduce_scatter_rccl(self, enable: bool, reduce_scatter_fn: Optional[int] = None):
+        """The same through ``ncclReduceScatter`` on the communicator of ``set_allreduce_rccl``."""
+        check(self._lib.sdm_set_reduce_scatter_rccl(self._h, int(bool(enable)), reduce_scatter_fn))
+
     def solve(self, level: int, reg_type: int, reg_param: float, regularise_last_row: bool,
               n_train_global: int = 0, fetch: bool = True):
         lam = ctypes.c_float(0.0)
@@ -562,9 +586,11 @@ class SupervisedDescentOptimiser:
     def train(self, parameters, initialisations, templates, projection: HogTransform,
               on_training_epoch_callback: Optional[Callable[[np.ndarray], None]] = None,
               allreduce=None, world_size: int = 1, n_train_global: int = 0, rank: Optional[int] = None,
-              solve_collectives=None):
+              solve_collectives=None, reduce_scatter=None):
         """``rank`` + ``solve_collectives = (bcast, allgather)`` (parallel.make_torch_solve_collectives) additionally shard the
-        factorisation of the summed system over the ranks (Context.set_solve_sharding); without them every rank solves it."""
+        factorisation of the summed system over the ranks (Context.set_solve_sharding); without them every rank solves it.
+        ``reduce_scatter`` (parallel.make_torch_reduce_scatter) then replaces the all-reduce of the whole Gram matrix by a
+        reduce-scatter of the owned tile columns + a small all-reduce (Context.set_reduce_scatter)."""
         x0 = np.asarray(initialisations, np.float32)
         self._bind(projection, x0.shape[0])
         c = self.ctx
@@ -577,6 +603,8 @@ class SupervisedDescentOptimiser:
                 c.set_solve_sharding(rank, world_size, *solve_collectives)
             else:
                 c.set_solve_sharding(0, 0, None, None)
+        if hasattr(c, "set_reduce_scatter"):
+            c.set_reduce_scatter(reduce_scatter if (solve_collectives is not None and rank is not None) else None)
         n_glob = n_train_global or c.N
         for level, reg in enumerate(self.regressors):
             c.hog_features(level)                                            # superviseddescent.hpp:173-189

@@ -68,6 +68,10 @@ struct DataParallel {
     sdm_allgather_fn allgather = nullptr;
     void* rccl_broadcast = nullptr;
     void* rccl_allgather = nullptr;
+    // reduce-scatter form of the Gram exchange on top of the sharded factorisation (sdm.h: sdm_set_reduce_scatter*)
+    sdm_reduce_scatter_fn reduce_scatter = nullptr;
+    bool rccl_reduce_scatter = false;
+    void* rccl_reduce_scatter_fn = nullptr;
 };
 inline DataParallel& data_parallel()
 {
@@ -99,6 +103,13 @@ inline void set_solve_sharding_rccl(int rank, void* nccl_broadcast_fn = nullptr,
     DataParallel& dp = data_parallel();
     dp.rank = rank; dp.rccl_broadcast = nccl_broadcast_fn; dp.rccl_allgather = nccl_allgather_fn;
 }
+// with the sharded factorisation: ship every rank the sum of its own tile columns instead of all-reducing the whole matrix
+inline void set_reduce_scatter(sdm_reduce_scatter_fn fn) { data_parallel().reduce_scatter = fn; }
+inline void set_reduce_scatter_rccl(void* nccl_reduce_scatter_fn = nullptr)
+{
+    DataParallel& dp = data_parallel();
+    dp.rccl_reduce_scatter = true; dp.rccl_reduce_scatter_fn = nccl_reduce_scatter_fn;
+}
 inline void clear_data_parallel() { data_parallel() = DataParallel(); }
 // applied by the batched backend to the context it trains on
 inline void install_data_parallel(sdm_ctx* c)
@@ -113,6 +124,10 @@ inline void install_data_parallel(sdm_ctx* c)
               "sdm_set_solve_sharding_rccl");
     else
         check(sdm_set_solve_sharding(c, 0, 0, nullptr, nullptr, nullptr), "sdm_set_solve_sharding");
+    if (dp.rank >= 0 && dp.rccl_comm && dp.rccl_reduce_scatter)
+        check(sdm_set_reduce_scatter_rccl(c, 1, dp.rccl_reduce_scatter_fn), "sdm_set_reduce_scatter_rccl");
+    else
+        check(sdm_set_reduce_scatter(c, dp.rank >= 0 ? dp.reduce_scatter : nullptr, dp.user), "sdm_set_reduce_scatter");
 }
 
 // one lazily created handle per thread for the stand-alone solver calls

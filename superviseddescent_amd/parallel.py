@@ -83,6 +83,25 @@ def make_torch_solve_collectives(device_index: int):
     return bcast, allgather
 
 
+def make_torch_reduce_scatter(device_index: int):
+    """Callback for ``Context.set_reduce_scatter``: ``world`` chunks of ``count`` floats at ``send``; the sum over the ranks of
+    this rank's chunk arrives at ``recv`` (``torch.distributed.reduce_scatter_tensor``, nccl = RCCL), on the engine's stream."""
+    import torch
+    import torch.distributed as dist
+
+    dev = torch.device("cuda", device_index)
+
+    def reduce_scatter(send: int, recv: int, count: int, stream: int) -> int:
+        ctx = torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=dev)) if stream else torch.cuda.stream(None)
+        with ctx:
+            dist.reduce_scatter_tensor(torch.as_tensor(_DeviceSpan(recv, count), device=dev),
+                                       torch.as_tensor(_DeviceSpan(send, count * dist.get_world_size()), device=dev),
+                                       op=dist.ReduceOp.SUM)
+        return 0
+
+    return reduce_scatter
+
+
 def make_host_allreduce() -> Callable[[np.ndarray], None]:
     """All-reduce for host buffers (gloo): used by the CPU tests of the data-parallel logic."""
     import torch

@@ -26,7 +26,7 @@ def main():
     reg = lambda: Regulariser(Regulariser.RegularisationType.MatrixNorm, 1.5, False)
     stream = torch.cuda.current_stream().cuda_stream
 
-    def train(allreduce, rows, shard=False):
+    def train(allreduce, rows, shard=False, scatter=False):
         sdo = SupervisedDescentOptimiser([LinearRegressor(reg()) for _ in params], device=local, stream=stream)
         hog = HogTransform(images, params, ids, ibug.RIGHT_EYE_IDS, ibug.LEFT_EYE_IDS, idx[rows])
         calls, shard_calls = [], []
@@ -39,7 +39,8 @@ def main():
             b, g = parallel.make_torch_solve_collectives(local)
             coll = (lambda *a: (shard_calls.append("b"), b(*a))[1], lambda *a: (shard_calls.append("g"), g(*a))[1])
         x = sdo.train(xs[rows], x0[rows], None, hog, allreduce=fn, world_size=world, n_train_global=xs.shape[0],
-                      rank=rank if shard else None, solve_collectives=coll)
+                      rank=rank if shard else None, solve_collectives=coll,
+                      reduce_scatter=parallel.make_torch_reduce_scatter(local) if scatter else None)
         return [r.x.copy() for r in sdo.regressors], x, (shard_calls if shard else calls)
 
     R_dist, x_dist, calls = train(parallel.make_torch_allreduce(local), slice(ra, rb))
@@ -52,6 +53,11 @@ def main():
     for a, b in zip(R_shard, R_dist):
         assert np.array_equal(a, b), float(np.abs(a - b).max())
     assert np.array_equal(x_shard, x_dist)
+    # ... and with the Gram exchange as a reduce-scatter of the owned tile columns (dist.reduce_scatter_tensor) + the small all-reduce
+    R_rs, x_rs, _ = train(parallel.make_torch_allreduce(local), slice(ra, rb), shard=True, scatter=True)
+    for a, b in zip(R_rs, R_dist):
+        assert float(np.linalg.norm((a - b).astype(np.float64))) <= 2e-5 * float(np.linalg.norm(b.astype(np.float64)))
+    assert float(np.linalg.norm((x_rs - x_dist).astype(np.float64))) <= 1e-5 * float(np.linalg.norm(x_dist.astype(np.float64)))
     if world == 1:
         R_solo, x_solo, _ = train(None, slice(0, xs.shape[0]))
         for a, b in zip(R_dist, R_solo):

@@ -199,7 +199,37 @@ def test_native_rccl_allreduce_world_of_one(built):
             assert np.array_equal(R.view(np.uint32), ref_regs[level][0].view(np.uint32)) and lam == ref_regs[level][1]
             ctx.apply(level)
         assert np.array_equal(ctx.get_x().view(np.uint32), ref_x.view(np.uint32))
+    # the reduce-scatter form of the exchange (sdm_set_reduce_scatter_rccl): ncclReduceScatter of the owner-ordered tiles + the small
+    # ncclAllReduce, both issued by the library; with one rank the sums are identities (MatrixNorm: lambda from the exchanged norm)
+    _lib.check(_lib.lib().sdm_set_allreduce_rccl(ctx._h, comm, fn, 1))
+    for rs_fn in (ctypes.cast(rccl.ncclReduceScatter, ctypes.c_void_p), None):
+        ctx.set_reduce_scatter_rccl(True, rs_fn)
+        for mn in (False, True):
+            r_type, r_par = (1, 1.5) if mn else (reg[0], reg[1])
+            ctx.set_x(x0)
+            ctx.hog_features(0); ctx.gram_rhs(0)
+            ctx.set_solve_sharding_rccl(None)
+            ctx.set_reduce_scatter_rccl(False)
+            _lib.check(_lib.lib().sdm_set_allreduce_rccl(ctx._h, None, None, 1))
+            R_plain, lam_plain = ctx.solve(0, r_type, r_par, reg[2], n_train_global=0)      # no exchange at all
+            _lib.check(_lib.lib().sdm_set_allreduce_rccl(ctx._h, comm, fn, 1))
+            ctx.set_solve_sharding_rccl(comm, 0, 1, None, None)
+            ctx.set_reduce_scatter_rccl(True, rs_fn)
+            n_before = ctx.get_timing()["allreduce"][1]
+            ctx.gram_rhs(0); ctx.allreduce_gram_rhs()
+            R, lam = ctx.solve(0, r_type, r_par, reg[2], n_train_global=0)
+            assert ctx.get_timing()["allreduce"][1] == n_before + 1
+            assert lam == pytest.approx(lam_plain, rel=1e-6)
+            if not mn:
+                assert np.array_equal(R.view(np.uint32), R_plain.view(np.uint32))
+            else:
+                assert np.linalg.norm((R - R_plain).astype(np.float64)) <= 1e-5 * np.linalg.norm(R_plain.astype(np.float64))
+    # a reduce-scattered matrix cannot be solved replicated: the call says so instead of factoring partial sums
+    ctx.gram_rhs(0); ctx.allreduce_gram_rhs()
     ctx.set_solve_sharding_rccl(None)
+    with pytest.raises(_lib.SdmError):
+        ctx.solve(0, reg[0], reg[1], reg[2], n_train_global=0)
+    ctx.set_reduce_scatter_rccl(False)
     ctx.close()
     ctx_probe.close()
     assert rccl.ncclCommDestroy(comm) == 0
