@@ -52,6 +52,24 @@ def gram_report(exec_flops, useful_flops, ms):
                     "matrix-core kernel it replaces: 2.4e-7 ... 3.5e-7)"}
 
 
+def apply_report(flops_per_launch, feature_bytes_per_launch, ms):
+    """The regressor apply (LDS-staged kernel) forms every f32 product from three float16 piece products on the 16-bit matrix cores
+    (csrc/sdm_apply.hip: the features are split in the kernel, the regressor when it is loaded).  `achieved` = f32-equivalent
+    TFLOP/s, `peak` / `frac` = against the f32 matrix-core peak the reference's f32 GEMM would be priced on (the north-star's
+    'MFMA utilisation'); `hbm` = the feature matrix read once per launch against the HBM peak -- the bound that is left."""
+    if ms <= 0:
+        return None
+    tf = flops_per_launch / (ms * 1e-3) / 1e12
+    gbs = feature_bytes_per_launch / (ms * 1e-3) / 1e9
+    return {"kernel": "apply_tiled_f16_kernel+apply_reduce_kernel", "bound": "hbm", "achieved": tf, "peak": MFMA_F32_PEAK_TF,
+            "unit": "TFLOP/s (f32-equivalent)", "frac": tf / MFMA_F32_PEAK_TF, "frac_of_f16_peak_over_3": tf / (MFMA_F16_PEAK_TF / 3.0),
+            "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_launch": feature_bytes_per_launch},
+            "avg_launch_ms": ms,
+            "note": "f32 operands as two float16 pieces, three piece products per product, float32 accumulation (SDM_APPLY_F32=1: the "
+                    "f32 matrix-core kernel of rounds 1-2: 0.044 ms = 71 TF at RCR-22, 0.544 ms = 111 TF at RCR-68)"}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -323,8 +341,7 @@ def main():
             "ms_per_step": dt68 / steps68 * 1e3, "scaling": "weak",
             "hog": {"bound": "hbm", "achieved": gbs68, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs68 / HBM_PEAK_GBS,
                     "avg_launch_ms": hog68_ms, "algorithmic_bytes_per_launch": hog_bytes68 / n_levels},
-            "apply_gemm": {"kernel": "apply_partial_kernel+apply_reduce_kernel", "bound": "mfma", "achieved": tf68, "peak": MFMA_F32_PEAK_TF,
-                           "unit": "TFLOP/s", "frac": tf68 / MFMA_F32_PEAK_TF, "avg_launch_ms": app68_ms},
+            "apply_gemm": apply_report(2.0 * nb68 * F68 * M68, 4.0 * nb68 * F68, app68_ms),
         }
 
     if rank != 0:
@@ -408,15 +425,8 @@ def main():
             "avg_launch_ms": hog_avg_ms,
             "launches": hog_n,
         },
-        "apply_gemm": {
-            "kernel": "apply_tiled_kernel+apply_reduce_kernel",
-            "bound": "mfma",
-            "achieved": apply_tf,
-            "peak": MFMA_F32_PEAK_TF,
-            "unit": "TFLOP/s",
-            "frac": apply_tf / MFMA_F32_PEAK_TF,
-            "avg_launch_ms": app_ms / max(app_n, 1),
-        },
+        "apply_gemm": apply_report(apply_flops / n_levels, sum(4.0 * args.batch * ctx.feature_dim(l) for l in range(n_levels)) / n_levels,
+                                   app_ms / max(app_n, 1)),
         "train": {
             "metric": "train sec/cascade (RCR-22, MatrixNorm 1.5, bias unregularised)",
             "rows_total": int(n_train_global),

@@ -232,6 +232,155 @@ apply_tiled_kernel(const float* __restrict__ feat, long long ldf, int N, int ksl
         }
 }
 
+// ---- the LDS-staged kernel on the 16-bit matrix cores (round 3) -----------------------------------------------------------
+// At RCR-68 the f32 matrix-core kernel above is bound by its matrix instructions (111 TF of 157), at RCR-22 the matrix work
+// (22 us) and the feature read from HBM (144 MB) co-limit.  As in the Gram kernel (sdm_gram_bf16.hip) every f32 operand is two
+// float16 pieces and a product three piece products with float32 accumulation -- 3/16 of the matrix time of one f32 product:
+//   * features: split IN the kernel, on the fragments (a lane of v_mfma_f32_16x16x32_f16 holds 8 consecutive k of one row = two
+//     16-byte chunks of the staged slab): v 2^12 = h1 + h2, h1 = v with the low 13 mantissa bits cleared (11 significant bits:
+//     exact in float16), h2 = float16(v - h1) (the residual has <= 13 bits; 11 kept).  Three vector instructions per element.
+//     HOG features are below 0.43 (x 2^12 < 2^11): no overflow; below 6 x 10^-5 / 2^12 a piece becomes subnormal and the error is
+//     absolute, 2^-24 / 2^12 of the feature scale.
+//   * regressor: split once when it is loaded / solved (apply_planes_kernel) with one power-of-two scale per OUTPUT COLUMN from the
+//     column's largest entry (entries keep 22 bits down to 2^-29 of it), stored as planes [piece][K / 8][Mp][8] so that a lane's 8 consecutive k of one output column are 16 contiguous bytes.
+// Same staging (LDS-direct, source-side swizzle, double buffered), same split-K / partial layout / reduction as the f32 kernel.
+typedef _Float16 af16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned au32x4 __attribute__((ext_vector_type(4)));
+
+__device__ inline int apply_f16_exponent(unsigned maxbits)
+{
+    const float b = __builtin_bit_cast(float, maxbits);
+    if (!(b > 0.0f) || !(b < 3.0e38f)) return 14;                                  // (scale 1)
+    return (int)((maxbits >> 23) & 0xff) - 127;                                    // floor(log2 b): |entries| < 2^(e + 1)
+}
+
+__device__ inline void apply_split8(const f32x4 v0, const f32x4 v1, af16x8& hi, af16x8& lo)
+{
+    au32x4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a = (j < 2 ? v0[2 * j] : v1[2 * j - 4]) * 4096.0f, b = (j < 2 ? v0[2 * j + 1] : v1[2 * j - 3]) * 4096.0f;
+        const float ah = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a) & 0xffffe000u);
+        const float bh = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, b) & 0xffffe000u);
+        h[j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ah, bh));              // (exact: 11 significant bits)
+        l[j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a - ah, b - bh));
+    }
+    hi = __builtin_bit_cast(af16x8, h);
+    lo = __builtin_bit_cast(af16x8, l);
+}
+
+template <int NT, int BM>
+__global__ void __launch_bounds__(BM * 4)
+apply_tiled_f16_kernel(const float* __restrict__ feat, long long ldf, int N, int kslabs, const f32x4* __restrict__ Rp, int KG,
+                       const unsigned* __restrict__ rmax, float* __restrict__ partial, int splits)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [2 buffers][BM feature rows | regressor planes][AT_BK floats]
+    constexpr int ROWS = BM + NT * 16;                            // (the planes of a slab take as many bytes as NT*16 f32 rows)
+    constexpr int RPP = BM / 4;
+    constexpr int MP = NT * 16;
+    constexpr int BU = 2 * 8 * MP;                                // 16-byte units of the regressor planes per slab: [piece][8 k-groups][MP]
+    constexpr int BPASS = (BU + BM * 4 - 1) / (BM * 4);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int row0 = blockIdx.x * BM;
+    const int split = blockIdx.y;
+    const int s0 = (int)(((long long)kslabs * split) / splits), s1 = (int)(((long long)kslabs * (split + 1)) / splits);
+    const int srow = t >> 4, spos = t & 15;
+    const int schunk = spos ^ (srow & 15);
+    const float* ap[BM / RPP];
+#pragma unroll
+    for (int p = 0; p < BM / RPP; ++p) {
+        int row = row0 + srow + RPP * p;
+        if (row > N - 1) row = N - 1;                            // clamp: duplicates are never stored
+        ap[p] = feat + (long long)row * ldf + 4 * schunk;
+    }
+    // regressor planes: unit u = t + BM*4 c of the slab = (piece u / (8 MP), k-group, column); a piece's units of a slab are contiguous
+    const f32x4* bsrc[BPASS];
+#pragma unroll
+    for (int c = 0; c < BPASS; ++c) {
+        int u = t + BM * 4 * c;
+        if (u > BU - 1) u = BU - 1;
+        bsrc[c] = Rp + (size_t)(u / (8 * MP)) * KG * MP + (u % (8 * MP));
+    }
+    auto issue = [&](int s, int buf) {
+        float* base = lds + (size_t)buf * ROWS * AT_BK;
+        const long long k0 = (long long)s * AT_BK;
+#pragma unroll
+        for (int p = 0; p < BM / RPP; ++p)
+            glds16(ap[p] + k0, base + (4 * wave + RPP * p) * AT_BK);
+#pragma unroll
+        for (int c = 0; c < BPASS; ++c)
+            if (64 * wave + BM * 4 * c < BU) glds16((const float*)(bsrc[c] + (size_t)s * 8 * MP), base + BM * AT_BK + 4 * (64 * wave + BM * 4 * c));
+    };
+    f32x4 acc[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (s0 < s1) issue(s0, 0);
+    for (int s = s0; s < s1; ++s) {
+        __syncthreads();                 // slab s has landed (the barrier drains the LDS-direct loads); the other buffer is free
+        if (s + 1 < s1) issue(s + 1, (s - s0 + 1) & 1);
+        const float* a = lds + (size_t)((s - s0) & 1) * ROWS * AT_BK + (16 * wave + li) * AT_BK;
+        const f32x4* b = (const f32x4*)(lds + (size_t)((s - s0) & 1) * ROWS * AT_BK + BM * AT_BK);
+#pragma unroll
+        for (int h = 0; h < AT_BK / 32; ++h) {
+            const int c0 = 2 * (lq + 4 * h);                      // this lane's 8 consecutive k: chunks c0, c0 + 1 of its row
+            const f32x4 v0 = *(const f32x4*)(a + 4 * (c0 ^ li));
+            const f32x4 v1 = *(const f32x4*)(a + 4 * ((c0 + 1) ^ li));
+            af16x8 ah, al;
+            apply_split8(v0, v1, ah, al);
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+                const af16x8 bh = __builtin_bit_cast(af16x8, b[(0 * 8 + 4 * h + lq) * MP + 16 * c + li]);
+                const af16x8 bl = __builtin_bit_cast(af16x8, b[(1 * 8 + 4 * h + lq) * MP + 16 * c + li]);
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[c], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        const float unscale = __builtin_ldexpf(1.0f, -12 + (apply_f16_exponent(rmax[16 * c + li]) - 14));      // (this lane's column)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = row0 + 16 * wave + lq * 4 + e;
+            if (row < N) partial[((long long)split * N + row) * MP + 16 * c + li] = acc[c][e] * unscale;
+        }
+    }
+}
+
+// regressor operand Rt[Mp][ldr] (K contiguous, zero padded) -> planes [piece][ldr / 8][Mp][8] float16, scaled by 2^(14 - e(max |R|))
+__global__ void __launch_bounds__(256) apply_absmax_kernel(const float* __restrict__ Rt, long long ldr, unsigned* __restrict__ out)
+{
+    // one workgroup per output column (= row of Rt): the largest |entry| of the column
+    __shared__ float part[4];
+    const float* row = Rt + (long long)blockIdx.x * ldr;
+    float v = 0.0f;
+    for (long long i = threadIdx.x; i < ldr; i += 256) v = __builtin_fmaxf(v, __builtin_fabsf(row[i]));
+    for (int o = 32; o; o >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = __builtin_bit_cast(unsigned, __builtin_fmaxf(__builtin_fmaxf(part[0], part[1]), __builtin_fmaxf(part[2], part[3])));
+}
+
+__global__ void __launch_bounds__(256) apply_planes_kernel(const float* __restrict__ Rt, long long ldr, int Mp, int KG, af16x8* __restrict__ planes,
+                                                           const unsigned* __restrict__ rmax)
+{
+    const long long u = (long long)blockIdx.x * 256 + threadIdx.x;      // (k-group, column)
+    if (u >= (long long)KG * Mp) return;
+    const int kg = (int)(u / Mp), col = (int)(u % Mp);
+    const float scale = __builtin_ldexpf(1.0f, 14 - apply_f16_exponent(rmax[col]));      // one power of two per output column
+    const float* src = Rt + (long long)col * ldr + 8 * kg;
+    af16x8 p1, p2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = src[j] * scale;
+        const _Float16 h1 = (_Float16)v;
+        p1[j] = h1; p2[j] = (_Float16)(v - (float)h1);
+    }
+    planes[u] = p1; planes[(size_t)KG * Mp + u] = p2;
+}
+
 __global__ void apply_reduce_kernel(const float* __restrict__ partial, int splits, int N, int Mp, int M,
                                     const float* __restrict__ x_in, float* __restrict__ x_out, int L,
                                     EyeIdxDev eyes)
@@ -463,9 +612,19 @@ static void launch_partial(const float* feat, long long ldf, int N, int kgroups,
                        kgroups, Rt, ldr, partial, splits);
 }
 
+size_t sdm_apply_planes_bytes(long long ldr, int M) { return (size_t)2 * (size_t)(ldr / 8) * (size_t)(((M + 15) / 16) * 16) * 16; }
+
+void sdm_launch_apply_planes(const float* Rt, long long ldr, int M, void* planes, unsigned* rmax, hipStream_t stream)
+{
+    // planes: sdm_apply_planes_bytes(ldr, M); rmax: Mp words (receive the bits of the columns' max |R|)
+    const int Mp = ((M + 15) / 16) * 16, KG = (int)(ldr / 8);
+    hipLaunchKernelGGL(apply_absmax_kernel, dim3(Mp), dim3(256), 0, stream, Rt, ldr, rmax);
+    hipLaunchKernelGGL(apply_planes_kernel, dim3((unsigned)(((long long)KG * Mp + 255) / 256)), dim3(256), 0, stream, Rt, ldr, Mp, KG, (af16x8*)planes, rmax);
+}
+
 void sdm_launch_apply(const float* feat, long long ldf, int N, int F, const float* Rt, long long ldr,
                       int M, const float* x_in, float* x_out, int L, const EyeIdxDev& eyes,
-                      float* partial, int splits, hipStream_t stream)
+                      float* partial, int splits, hipStream_t stream, const void* planes, const unsigned* rmax)
 {
     if (N <= 0) return;
     const int kgroups = (F + 15) / 16;   // feat/Rt are zero padded to a multiple of 16 columns
@@ -482,6 +641,23 @@ void sdm_launch_apply(const float* feat, long long ldf, int N, int F, const floa
             ATATTR(1); ATATTR(2); ATATTR(3); ATATTR(4, 128); ATATTR(5, 128); ATATTR(6, 128); ATATTR(7, 128); ATATTR(8, 128); ATATTR(9, 128);
 #undef ATATTR
         }
+        static const bool f32_only = getenv("SDM_APPLY_F32") && getenv("SDM_APPLY_F32")[0] == '1';      // (A/B: the f32 matrix-core kernel)
+        if (planes && rmax && !f32_only) {
+            static unsigned long long attr16 = 0;
+            if (sdm_first_use_on_device(attr16)) {
+#define AFATTR(...) SDM_SET_ATTR((const void*)apply_tiled_f16_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+                AFATTR(1, 64); AFATTR(2, 64); AFATTR(3, 64); AFATTR(4, 128); AFATTR(5, 128); AFATTR(6, 128); AFATTR(7, 128); AFATTR(8, 128); AFATTR(9, 128);
+#undef AFATTR
+            }
+#define AFL(...) hipLaunchKernelGGL((apply_tiled_f16_kernel<__VA_ARGS__>), grid, dim3(bm * 4), lds, stream, feat, ldf, N, kslabs, \
+                                    (const f32x4*)planes, (int)(ldr / 8), rmax, partial, splits)
+            switch (NT) {
+                case 1: AFL(1, 64); break; case 2: AFL(2, 64); break; case 3: AFL(3, 64); break;
+                case 4: AFL(4, 128); break; case 5: AFL(5, 128); break; case 6: AFL(6, 128); break;
+                case 7: AFL(7, 128); break; case 8: AFL(8, 128); break; default: AFL(9, 128); break;
+            }
+#undef AFL
+        } else {
 #define ATL(...) hipLaunchKernelGGL((apply_tiled_kernel<__VA_ARGS__>), grid, dim3(bm * 4), lds, stream, feat, ldf, N, kslabs, Rt, ldr, partial, splits)
         switch (NT) {
             case 1: ATL(1); break; case 2: ATL(2); break; case 3: ATL(3); break;
@@ -489,6 +665,7 @@ void sdm_launch_apply(const float* feat, long long ldf, int N, int F, const floa
             case 7: ATL(7, 128); break; case 8: ATL(8, 128); break; default: ATL(9, 128); break;
         }
 #undef ATL
+        }
     } else
     switch (NT) {
         case 1: launch_partial<2, 1>(feat, ldf, N, kgroups, Rt, ldr, partial, splits, stream); break;

@@ -119,6 +119,8 @@ struct sdm_ctx {
 
     // regressors, transposed + padded: [Mp][ldf]
     std::vector<DevBuf<float>> Rt;
+    std::vector<DevBuf<unsigned char>> Rp;   // the same regressors as two float16 planes (the 16-bit matrix-core apply, sdm_apply.hip)
+    DevBuf<unsigned> Rmax;                   // per level and output column: bits of max |R| (the planes' power-of-two scales)
     std::vector<bool> have_R;
 
     // normal equations
@@ -304,6 +306,16 @@ int do_hog(sdm_ctx* c, int level)
     return SDM_OK;
 }
 
+// the level's regressor operand as float16 planes (after every write of Rt[level])
+int build_apply_planes(sdm_ctx* c, int level)
+{
+    int rc;
+    if ((rc = c->Rp[level].ensure(sdm_apply_planes_bytes(c->ldf, c->M))) || (rc = c->Rmax.ensure(c->levels.size() * (size_t)Mp_of(c->M)))) return rc;
+    sdm_launch_apply_planes(c->Rt[level].p, c->ldf, c->M, c->Rp[level].p, c->Rmax.p + (size_t)level * Mp_of(c->M), c->stream);
+    HIP_TRY(hipGetLastError());
+    return SDM_OK;
+}
+
 int do_apply(sdm_ctx* c, int level)
 {
     if (c->feat_level != level) return fail(SDM_ERR_INVALID, "sdm_apply: features of this level not extracted");
@@ -315,7 +327,8 @@ int do_apply(sdm_ctx* c, int level)
     {
         Timer t(c, SDM_T_APPLY);
         sdm_launch_apply(c->feat.p, c->ldf, c->N, F, c->Rt[level].p, c->ldf, c->M, c->x[c->cur].p,
-                         c->x[c->cur ^ 1].p, c->L, c->eyes, c->partial.p, splits, c->stream);
+                         c->x[c->cur ^ 1].p, c->L, c->eyes, c->partial.p, splits, c->stream,
+                         c->Rp[level].p, c->Rp[level].p ? c->Rmax.p + (size_t)level * Mp_of(c->M) : nullptr);
     }
     HIP_TRY(hipGetLastError());
     c->cur ^= 1;
@@ -388,6 +401,8 @@ void sdm_destroy(sdm_ctx* c)
     c->img_stride.release(); c->img_idx.release(); c->x[0].release(); c->x[1].release();
     c->xstar.release(); c->tmpl.release(); c->feat.release(); c->patch_idx.release(); c->status.release();
     c->partial.release(); c->shard_stage.release(); c->G.release(); c->gpack.release(); c->fro.release(); c->Rsol.release(); c->winv.release(); c->gram_planes.release(); c->gram_flag.release(); c->upd_planes.release(); c->upd_maxdiag.release(); c->lambda_dev.release();
+    for (auto& r : c->Rp) r.release();
+    c->Rmax.release();
     for (auto& r : c->Rt) r.release();
     for (auto& q : c->plans) { q.lane_tab.release(); q.wb.release(); q.pass_info.release(); }
     if (c->own_stream) e = hipStreamDestroy(c->stream);
@@ -550,6 +565,8 @@ int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int*
     c->ldf = (long long)round_up(c->Fmax, 128) + 128 * c->rhs_tiles;
     for (auto& r : c->Rt) r.release();
     c->Rt.assign(n_levels, DevBuf<float>());
+    for (auto& r : c->Rp) r.release();
+    c->Rp.assign(n_levels, DevBuf<unsigned char>());
     c->have_R.assign(n_levels, false);
     c->feat.release(); c->feat_level = -1;
     c->N = 0; c->have_targets = false; c->g_level = -1;
@@ -840,6 +857,7 @@ int sdm_set_regressor(sdm_ctx* c, int level, const float* R)
     for (int k = 0; k < F; ++k)
         for (int j = 0; j < M; ++j) t[(size_t)j * c->ldf + k] = R[(size_t)k * M + j];
     HIP_TRY(hipMemcpyAsync(c->Rt[level].p, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if ((rc = build_apply_planes(c, level))) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_R[level] = true;
     return SDM_OK;
@@ -1151,6 +1169,7 @@ int sdm_solve(sdm_ctx* c, int level, int reg_type, float reg_param, int regulari
     ScopedBuf<float> rc_dev;
     if (R_host && (rc = rc_dev.ensure((size_t)F * M))) return rc;
     sdm_launch_pack_regressor(c->Rsol.p, F, M, Mp, c->Rt[level].p, c->ldf, R_host ? rc_dev.p : nullptr, c->stream);
+    if ((rc = build_apply_planes(c, level))) return rc;
     HIP_TRY(hipGetLastError());
     if (R_host) HIP_TRY(hipMemcpyAsync(R_host, rc_dev.p, (size_t)F * M * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     if (lambda_out) HIP_TRY(hipMemcpyAsync(lambda_out, c->lambda_dev.p, sizeof(float), hipMemcpyDeviceToHost, c->stream));

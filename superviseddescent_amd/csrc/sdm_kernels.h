@@ -133,7 +133,10 @@ void sdm_launch_gradient_table(const HogLevelDev& lv, float* g_out, int* bin_out
 int sdm_apply_splits(int N, int F, int M);
 void sdm_launch_apply(const float* feat, long long ldf, int N, int F, const float* Rt, long long ldr,
                       int M, const float* x_in, float* x_out, int L, const EyeIdxDev& eyes,
-                      float* partial, int splits, hipStream_t stream);
+                      float* partial, int splits, hipStream_t stream, const void* planes = nullptr, const unsigned* rmax = nullptr);
+// the regressor as two float16 planes for the 16-bit matrix-core apply (sdm_apply.hip): planes = sdm_apply_planes_bytes(ldr, M) bytes
+size_t sdm_apply_planes_bytes(long long ldr, int M);
+void sdm_launch_apply_planes(const float* Rt, long long ldr, int M, void* planes, unsigned* rmax, hipStream_t stream);
 
 // Rsol [Fp][Mp] -> Rt [Mp][ldf] (zero padded) and, if Rc != null, the compact [F][M] copy
 void sdm_launch_pack_regressor(const float* Rsol, int F, int M, int Mp, float* Rt, long long ldf, float* Rc, hipStream_t stream);

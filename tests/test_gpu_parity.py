@@ -272,6 +272,38 @@ def test_apply_update(gpu_ctx, faces, n):
     assert rel_l2(x1, ref) < 1e-6
 
 
+def test_apply_on_the_16_bit_matrix_cores_keeps_float32_accuracy_per_column(gpu_ctx, faces):
+    """Round 3: on batches >= 2 048 rows the apply forms every product from float16 pieces (features split in the kernel, regressor
+    when it is loaded, one power-of-two scale per OUTPUT COLUMN; csrc/sdm_apply.hip).  Columns of very different magnitude (10^-6 ...
+    10^3) and a heavy bias row must each come out as a float32 GEMM would deliver them: every column within 2e-6 of a float64
+    product, relative to the column's own norm."""
+    images, _, _, _, x0 = faces
+    n = 2304
+    gpu_ctx.set_model_geometry(len(IDS), RE, LE, SHIPPED)
+    gpu_ctx.upload_images(images)
+    idx = (np.arange(n) % x0.shape[0]).astype(np.int32)
+    x = (x0[idx] + (np.arange(n)[:, None] // x0.shape[0]).astype(np.float32) * 0.29).astype(np.float32)
+    gpu_ctx.set_sample_image_index(idx)
+    gpu_ctx.set_x(x)
+    feat = gpu_ctx.hog_features(0, fetch=True)
+    rng = np.random.default_rng(5)
+    R = rng.standard_normal((feat.shape[1], 44)) * (10.0 ** rng.uniform(-6, 3, size=44))[None, :]
+    R[-1] *= 300.0                                                              # the bias row
+    R = R.astype(np.float32)
+    gpu_ctx.set_regressor(0, R)
+    gpu_ctx.apply(0)
+    x1 = gpu_ctx.get_x().astype(np.float64)
+    norm = orc.InterEyeDistanceNormalisation(RE, LE)(x).astype(np.float64)
+    u_gpu = (x.astype(np.float64) - x1) * norm                                 # the update the kernel applied (x is O(100): float32 rounding of x - u shows for the small columns)
+    u = feat.astype(np.float64) @ R.astype(np.float64)
+    big = np.abs(u).max(axis=0) > 1e-2                                          # columns whose update survives the float32 subtraction from x
+    err = np.linalg.norm(u_gpu[:, big] - u[:, big], axis=0) / np.linalg.norm(u[:, big], axis=0)
+    print("apply, float16 pieces: per-column relative error max %.2e (columns with a visible update: %d of 44)" % (err.max(), int(big.sum())))
+    assert big.sum() >= 10 and err.max() < 2e-5
+    ref = (x - (u * (1.0 / norm)).astype(np.float32)).astype(np.float32)
+    assert rel_l2(gpu_ctx.get_x(), ref) < 1e-6
+
+
 @pytest.mark.parametrize("L,n", [(25, 2100), (33, 2049), (40, 2100), (47, 2303), (55, 2100), (61, 2048), (68, 2100), (68, 8192)])
 def test_apply_wide_outputs_on_large_batches(faces, L, n):
     """Round 3: outputs of 4 ... 9 column tiles (2L = 50 ... 136) on batches >= 2 048 rows run on the LDS-staged GEMM with 128-row
