@@ -1151,7 +1151,7 @@ int sdm_solve(sdm_ctx* c, int level, int reg_type, float reg_param, int regulari
             return fail(SDM_ERR_INVALID, "sdm_solve: the Gram matrix was reduce-scattered over the ranks; the factorisation must be sharded over the same ranks");
         if (sharded) {
             if ((rc = c->shard_stage.ensure(sdm_solve_shard_stage_tiles(ncols, c->shard_world) * 128 * 128))) return rc;
-            shard.rank = c->shard_rank; shard.world = c->shard_world; shard.stage = c->shard_stage.p; shard.self = c;
+            shard.rank = c->shard_rank; shard.world = c->shard_world; shard.stage = c->shard_stage.p; shard.stage_floats = c->shard_stage.cap; shard.self = c;
             shard.bcast = shard_bcast_thunk; shard.allgather = shard_allgather_thunk;
             static const int emulate = getenv("SDM_SOLVE_SHARD_EMULATE") ? atoi(getenv("SDM_SOLVE_SHARD_EMULATE")) : 0;
             shard.emulate_chain = emulate;

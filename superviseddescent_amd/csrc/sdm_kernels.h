@@ -230,6 +230,7 @@ void sdm_launch_update_f16(const void* planes, int rows, int wcols, int wcols_fa
 struct SolveShard {
     int rank, world;
     float* stage;
+    size_t stage_floats;          // capacity of `stage` (the sharded back substitution's all-gather needs (world + 1) * Fp * 16 * ceil(nrhs / 16 / world))
     void* self;
     int (*bcast)(void* self, float* buf, size_t count_f32, int root, hipStream_t stream);
     int (*allgather)(void* self, const float* send, float* recv, size_t count_f32_per_rank, hipStream_t stream);

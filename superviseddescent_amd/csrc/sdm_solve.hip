@@ -1083,6 +1083,17 @@ __global__ void small_exchange_pack_kernel(const double* fro2, float* d_tail, in
     if (unpack) *fro2_out = (double)*d_tail; else *d_tail = (float)*fro2;
 }
 
+// columns [c0, c0 + nc) of the row-major solution R[rows][ldr] <-> a dense rows x nc block (the all-gather of the sharded back
+// substitution); columns beyond c_end are zero in the block / skipped on the way back
+__global__ __launch_bounds__(256) void cols_gather_kernel(float* R, long long ldr, int rows, int c0, int nc, int c_end, float* block, int unpack)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)rows * nc) return;
+    const int r = (int)(t / nc), c = (int)(t - (long long)r * nc);
+    if (unpack) { if (c0 + c < c_end) R[(long long)r * ldr + c0 + c] = block[t]; }
+    else block[t] = c0 + c < c_end ? R[(long long)r * ldr + c0 + c] : 0.0f;
+}
+
 size_t sdm_packed_tiles_count(int F, int rhs_tiles)
 {
     const size_t T = (size_t)(F + TILE - 1) / TILE;
@@ -1252,14 +1263,31 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
         }
     }
     if (tail_pending) (void)hipStreamWaitEvent(stream, aux->tail_done, 0);
-    const int nj = nrhs / 16;   // nrhs is a multiple of 16, <= 144
+    int nj = nrhs / 16;   // nrhs is a multiple of 16, <= 144 (sharded: narrowed to this rank's column tiles below)
     static const bool bs_steps = getenv("SDM_BACKSOLVE_STEPS") && getenv("SDM_BACKSOLVE_STEPS")[0] == '1';   // (A/B: the round-2 launch per step)
     if (!bs_steps) {
         // one persistent launch: Tf workgroups x chunks of <= 5 column tiles; flags (one int per tile row and chunk) behind the
         // inverses in `work`, cleared on the stream
-        const int nchunks = (nj + 4) / 5, NJ = (nj + nchunks - 1) / nchunks;
+        // Sharded: the right-hand-side columns are independent, so rank r substitutes the column tiles r per ... (r + 1) per - 1 only
+        // (the same instructions per column as the replicated launch: bit-identical) and one all-gather of the column blocks gives
+        // every rank the whole solution.  At W = 8 and 136 right-hand sides a rank substitutes 32 columns instead of 144.
+        int bs_lo = 0, bs_n = nj, bs_per = nj;
+        const size_t Fp_rows = (size_t)Tf * TILE;
+        if (shard && W > 1) {
+            bs_per = (nj + W - 1) / W;
+            if ((size_t)(W + 1) * Fp_rows * 16 * bs_per <= shard->stage_floats) {
+                bs_lo = me * bs_per < nj ? me * bs_per : nj;
+                bs_n = bs_lo + bs_per <= nj ? bs_per : nj - bs_lo;
+            } else
+                bs_per = nj;                               // (staging too small for the exchange: replicated)
+        }
+        const bool bs_sharded = bs_per != nj;
+        const int nj_full = nj;
+        nj = bs_n;
+        const int rhs_shift = 16 * bs_lo;
+        const int nchunks = nj > 0 ? (nj + 4) / 5 : 0, NJ = nchunks ? (nj + nchunks - 1) / nchunks : 1;
         int* flags = (int*)(work + (size_t)Tf * TILE * TILE);
-        (void)hipMemsetAsync(flags, 0, (size_t)nchunks * Tf * sizeof(int), stream);
+        if (nchunks) (void)hipMemsetAsync(flags, 0, (size_t)nchunks * Tf * sizeof(int), stream);
         static unsigned long long attr_bsp = 0;
         if (sdm_first_use_on_device(attr_bsp)) {
 #define BSPATTR(NJv) SDM_SET_ATTR((const void*)backsolve_persistent_kernel<NJv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
@@ -1267,10 +1295,25 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
 #undef BSPATTR
         }
 #define BSP(NJv) hipLaunchKernelGGL(backsolve_persistent_kernel<NJv>, dim3(Tf, nchunks), dim3(BSP_WAVES * 64),                         \
-                                    ((size_t)TILE * (TILE + 4) + (size_t)TILE * NJv * 16) * sizeof(float), stream, G, ldg, Tf, rhs0, nrhs, \
-                                    work, R_out, ldr, flags, status)
-        switch (NJ) { case 1: BSP(1); break; case 2: BSP(2); break; case 3: BSP(3); break; case 4: BSP(4); break; default: BSP(5); break; }
+                                    ((size_t)TILE * (TILE + 4) + (size_t)TILE * NJv * 16) * sizeof(float), stream, G, ldg, Tf, rhs0 + rhs_shift, \
+                                    16 * nj < nrhs - rhs_shift ? 16 * nj : nrhs - rhs_shift, work, R_out + rhs_shift, ldr, flags, status)
+        if (nchunks)
+            switch (NJ) { case 1: BSP(1); break; case 2: BSP(2); break; case 3: BSP(3); break; case 4: BSP(4); break; default: BSP(5); break; }
 #undef BSP
+        if (bs_sharded) {
+            const int nc = 16 * bs_per;
+            const size_t per_rank = Fp_rows * nc;
+            float* send = shard->stage;
+            float* recv = shard->stage + per_rank;
+            const unsigned gb = (unsigned)((per_rank + 255) / 256);
+            hipLaunchKernelGGL(cols_gather_kernel, dim3(gb), dim3(256), 0, stream, R_out, ldr, (int)Fp_rows, 16 * bs_lo, nc, 16 * nj_full, send, 0);
+            const int rc = shard->allgather(shard->self, send, recv, per_rank, stream);
+            if (rc) return rc;
+            for (int r = 0; r < W; ++r)
+                if (r != me && r * bs_per < nj_full)
+                    hipLaunchKernelGGL(cols_gather_kernel, dim3(gb), dim3(256), 0, stream, R_out, ldr, (int)Fp_rows, 16 * r * bs_per, nc, 16 * nj_full,
+                                       recv + (size_t)r * per_rank, 1);
+        }
         return 0;
     }
     for (int k = Tf - 1; k >= 0; --k) {

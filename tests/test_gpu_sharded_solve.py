@@ -142,12 +142,16 @@ def test_sharded_factorisation_is_bit_identical(built, case):
             R, lam = out[rank]
             assert lam == lam1
             assert np.array_equal(R.view(np.uint32), R1.view(np.uint32)), (case, world, rank)
-            # one broadcast per 128-column step, one all-gather per group of 4 steps that has columns to its right
+            # one broadcast per 128-column step, one all-gather per group of 4 steps that has columns to its right, and -- with
+            # more than one rank -- one all-gather of the back substitution's column blocks (round 3: every rank substitutes
+            # its share of the right-hand-side column tiles only)
             assert calls[rank]["bcast"] == Tf
-            assert calls[rank]["allgather"] == -(-Tf // 4)
+            assert calls[rank]["allgather"] == -(-Tf // 4) + (1 if world > 1 else 0)
             # a step ships at most 4 tiles, the gathers ship each rank's share of the panel rows (padded to the largest share)
+            # and of the solution (a block of 16 * ceil(column tiles / world) columns)
             assert calls[rank]["bcast_floats"] <= 4 * Tf * 128 * 128
-            assert calls[rank]["allgather_floats"] <= (T * (T + 1) // 2 // world + 4 * T) * 128 * 128
+            nj = -(-(2 * len(ids)) // 16)
+            assert calls[rank]["allgather_floats"] <= (T * (T + 1) // 2 // world + 4 * T) * 128 * 128 + Tf * 128 * 16 * -(-nj // world)
 
 
 def test_sharded_failure_is_seen_by_every_rank(built):
@@ -276,7 +280,7 @@ def test_bench_train_path_two_ranks_at_the_shipped_size(built, world):
     assert rel < 1e-4
     for rank in range(world):
         assert group.calls[rank]["allreduce"] == len(params)
-        assert group.calls[rank]["bcast"] == 69 * len(params) and group.calls[rank]["allgather"] == 18 * len(params)
+        assert group.calls[rank]["bcast"] == 69 * len(params) and group.calls[rank]["allgather"] == (18 + 1) * len(params)      # (+ the solution's column blocks)
 
 
 def _reduce_scatter_of(group, rank):
