@@ -1052,7 +1052,7 @@ hog_fast_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float* 
 #endif             /* plan: among equally dense group sizes prefer one with at least two passes per wave (measured: the smaller group wins, 1.54 -> 1.50 ms) */
 #endif
 #ifndef HP_ABL
-#define HP_ABL 0                    /* experiments: 1 no folds, 2 no finish, 3 no column read-modify-write, 4 no image loads, 5 no gradient */
+#define HP_ABL 0                    /* experiments: 1 no folds, 2 no finish, 3 no column read-modify-write, 4 no image loads, 5 no gradient, 6 folds without their matrix instructions */
 #endif
 #define HP_ROWS_BYTES(O) ((size_t)2 * (O) * HP_ST * 8)
 #define HP_HIST_BYTES(O, CC) ((size_t)2 * (O) * (CC) * 4)
@@ -1424,6 +1424,11 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
                 if (kp < 6 || kp < nkp) {      // (a 55-column pass leaves the last 8 lanes without a column: 14 products instead of 16)
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
+                        if (HP_ABL == 6) {      // (timing experiment: the fold's LDS traffic without its matrix instructions)
+                            fa0[mt][0] += a0v[mt][kp % 3] * wq[(2 * kp) >> 2][(2 * kp) & 3];
+                            fa1[mt][0] += a1v[mt][kp % 3] * wq[(2 * kp + 1) >> 2][(2 * kp + 1) & 3];
+                            continue;
+                        }
                         fa0[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v[mt][kp % 3], wq[(2 * kp) >> 2][(2 * kp) & 3], fa0[mt], 0, 0, 0);
                         fa1[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v[mt][kp % 3], wq[(2 * kp + 1) >> 2][(2 * kp + 1) & 3], fa1[mt], 0, 0, 0);
                     }
