@@ -580,7 +580,13 @@ static bool apply_use_tiled(int N, int M)
     const int nt = (M + 15) / 16;
     return !force_partial && nt <= 9 && N >= 2048;
 }
-static int apply_bm(int M) { return (M + 15) / 16 <= 3 ? AT_BM : 128; }
+static int apply_bm(int M)
+{
+    static const int forced = getenv("SDM_APPLY_BM") ? atoi(getenv("SDM_APPLY_BM")) : 0;      // (A/B: 64 or 128 rows per workgroup)
+    if (forced == 64 && (M + 15) / 16 <= 3) return 64;
+    if (forced == 128) return 128;
+    return (M + 15) / 16 <= 3 ? AT_BM : 128;
+}
 
 int sdm_apply_splits(int N, int F, int M)
 {
@@ -589,6 +595,8 @@ int sdm_apply_splits(int N, int F, int M)
         const int row_blocks = (N + bm - 1) / bm, kslabs = (F + AT_BK - 1) / AT_BK;
         int splits = ((bm == 128 ? 256 : 512) + row_blocks - 1) / row_blocks;     // two 61 KB workgroups per CU (64 rows), one of 90 - 139 KB (128 rows)
         if (splits > kslabs / 4) splits = kslabs / 4;
+        static const int forced_splits = getenv("SDM_APPLY_SPLITS") ? atoi(getenv("SDM_APPLY_SPLITS")) : 0;      // (A/B)
+        if (forced_splits > 0) splits = forced_splits;
         return splits < 1 ? 1 : (splits > 64 ? 64 : splits);
     }
     // enough workgroups to cover 256 CUs a few times over, but at least 4 k-groups per wave
@@ -646,13 +654,15 @@ void sdm_launch_apply(const float* feat, long long ldf, int N, int F, const floa
             static unsigned long long attr16 = 0;
             if (sdm_first_use_on_device(attr16)) {
 #define AFATTR(...) SDM_SET_ATTR((const void*)apply_tiled_f16_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-                AFATTR(1, 64); AFATTR(2, 64); AFATTR(3, 64); AFATTR(4, 128); AFATTR(5, 128); AFATTR(6, 128); AFATTR(7, 128); AFATTR(8, 128); AFATTR(9, 128);
+                AFATTR(1, 64); AFATTR(2, 64); AFATTR(3, 64); AFATTR(1, 128); AFATTR(2, 128); AFATTR(3, 128); AFATTR(4, 128); AFATTR(5, 128); AFATTR(6, 128); AFATTR(7, 128); AFATTR(8, 128); AFATTR(9, 128);
 #undef AFATTR
             }
 #define AFL(...) hipLaunchKernelGGL((apply_tiled_f16_kernel<__VA_ARGS__>), grid, dim3(bm * 4), lds, stream, feat, ldf, N, kslabs, \
                                     (const f32x4*)planes, (int)(ldr / 8), rmax, partial, splits)
             switch (NT) {
-                case 1: AFL(1, 64); break; case 2: AFL(2, 64); break; case 3: AFL(3, 64); break;
+                case 1: if (bm == 128) AFL(1, 128); else AFL(1, 64); break;
+                case 2: if (bm == 128) AFL(2, 128); else AFL(2, 64); break;
+                case 3: if (bm == 128) AFL(3, 128); else AFL(3, 64); break;
                 case 4: AFL(4, 128); break; case 5: AFL(5, 128); break; case 6: AFL(6, 128); break;
                 case 7: AFL(7, 128); break; case 8: AFL(8, 128); break; default: AFL(9, 128); break;
             }
