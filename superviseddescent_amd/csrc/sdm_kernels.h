@@ -240,7 +240,7 @@ struct SolveShard {
 };
 inline size_t sdm_solve_shard_stage_tiles(int ncols, int world) { return (size_t)(world + 1) * 4 * (size_t)(ncols / 128 / world + 1); }
 // returns 0, or the non-zero result of a failed collective
-inline size_t sdm_backsolve_flag_floats(int Fp) { return (size_t)2 * (size_t)(Fp / 128) + 64; }      // (<= 144 right-hand sides: <= 2 chunks)
+inline size_t sdm_backsolve_flag_floats(int Fp) { return (size_t)9 * (size_t)(Fp / 128) + 64; }      // (<= 144 right-hand sides = 9 column tiles: <= 9 chunks)
 int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs, float* R_out,
                               long long ldr, float* work, int* status, hipStream_t stream, const SolveAux* aux = nullptr,
                               const SolveShard* shard = nullptr);

@@ -1285,7 +1285,9 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
         const int nj_full = nj;
         nj = bs_n;
         const int rhs_shift = 16 * bs_lo;
-        const int nchunks = nj > 0 ? (nj + 4) / 5 : 0, NJ = nchunks ? (nj + nchunks - 1) / nchunks : 1;
+        static const int max_nj = getenv("SDM_BACKSOLVE_MAX_NJ") ? atoi(getenv("SDM_BACKSOLVE_MAX_NJ")) : 5;      // column tiles per workgroup (1 ... 5)
+        const int cap = max_nj < 1 ? 1 : (max_nj > 5 ? 5 : max_nj);
+        const int nchunks = nj > 0 ? (nj + cap - 1) / cap : 0, NJ = nchunks ? (nj + nchunks - 1) / nchunks : 1;
         int* flags = (int*)(work + (size_t)Tf * TILE * TILE);
         if (nchunks) (void)hipMemsetAsync(flags, 0, (size_t)nchunks * Tf * sizeof(int), stream);
         static unsigned long long attr_bsp = 0;
