@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3   # f32-input MFMA dense peak
+PREROLL_STEPS = 40         # untimed steps before the warm-up steps (GPU clocks back up after the host-side set-up)
 MFMA_F16_PEAK_TF = 2500.0  # f16 / bf16-input MFMA dense peak (the Gram launch: four float16 piece products per f32 product)
 
 
@@ -266,6 +267,11 @@ def main():
     x_final = ctx.get_x()
     apply_flops = sum(2.0 * args.batch * ctx.feature_dim(l) * M for l in range(n_levels))
 
+    # clock pre-roll: the host-side preparation above leaves the GPU idle for a few hundred milliseconds and its clocks drop; the W
+    # warm-up steps of a short run (7 ms at W = 5) do not bring them back (measured: 1.443 ms per step at W = 5 / K = 20 against
+    # 1.419-1.422 at W = 40 or K = 200).  PREROLL untimed steps of the same work run before the W warm-up steps; reported in `config`.
+    for _ in range(PREROLL_STEPS):
+        step()
     for _ in range(args.warmup):
         step()
     ctx.enable_timing(True)
@@ -407,6 +413,7 @@ def main():
             "batch_per_gpu": args.batch,
             "levels": n_levels,
             "sharding": "faces sharded by rank, no collective on the detect path",
+            "preroll_steps": PREROLL_STEPS,      # untimed, before the `warmup` steps: GPU clocks back up after the host-side set-up
         },
         "roofline": {
             "kernel": hog_kernel,
