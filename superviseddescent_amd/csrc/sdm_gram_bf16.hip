@@ -527,11 +527,13 @@ static const std::vector<int>& gram_tile_order_w(int T)
     std::vector<int>& o = cache[T];
     if (!o.empty()) return o;
     const int TI = (T + 1) / 2;
+    static const int BH = getenv("SDM_GRAM_BLOCK_H") ? atoi(getenv("SDM_GRAM_BLOCK_H")) : 4;      // (A/B of the block shape)
+    static const int BW = getenv("SDM_GRAM_BLOCK_W") ? atoi(getenv("SDM_GRAM_BLOCK_W")) : 8;
     std::vector<int> seq;
-    for (int bi = 0; bi * 4 < TI; ++bi)
-        for (int bj = 0; bj * 8 < T; ++bj)
-            for (int I = bi * 4; I < (bi + 1) * 4 && I < TI; ++I)
-                for (int j = bj * 8; j < (bj + 1) * 8 && j < T; ++j)
+    for (int bi = 0; bi * BH < TI; ++bi)
+        for (int bj = 0; bj * BW < T; ++bj)
+            for (int I = bi * BH; I < (bi + 1) * BH && I < TI; ++I)
+                for (int j = bj * BW; j < (bj + 1) * BW && j < T; ++j)
                     if (j >= 2 * I) seq.push_back(I | (j << 16));
     const int nt = (int)seq.size(), chunk = (nt + 7) / 8;
     o.assign((size_t)8 * chunk, -1);
