@@ -43,8 +43,8 @@ def test_trained_level_satisfies_the_normal_equations_at_100k_rows(built):
     p, ld, n = ctx.features_device_ptr()
     dev = torch.device("cuda", 0)
     A = torch.as_tensor(parallel._DeviceSpan(p, n * ld), device=dev).view(n, ld)[:, :F]
-    ied = np.linalg.norm(x0[:, RE].mean(1, keepdims=True) * 0 + np.stack([x0[:, RE].mean(1) - x0[:, LE].mean(1),
-                                                                       x0[:, [r + len(IDS) for r in RE]].mean(1) - x0[:, [l + len(IDS) for l in LE]].mean(1)], 1), axis=1)
+    L = len(IDS)
+    ied = np.hypot(x0[:, RE].mean(1) - x0[:, LE].mean(1), x0[:, [r + L for r in RE]].mean(1) - x0[:, [l + L for l in LE]].mean(1))   # helpers.hpp:136-160
     b = ((x0 - x_star).astype(np.float64) / ied[:, None].astype(np.float64))   # superviseddescent.hpp:199-205 with model.hpp:94-98
     G = torch.zeros((F, F), dtype=torch.float64, device=dev)
     rhs = torch.zeros((F, b.shape[1]), dtype=torch.float64, device=dev)
