@@ -19,8 +19,13 @@ IDS = ibug.RCR22_IDS
 RE, LE = ibug.eye_indices(IDS)
 
 
-def test_trained_level_satisfies_the_normal_equations_at_100k_rows(built):
+@pytest.mark.parametrize("model", ["rcr22", "rcr68"])
+def test_trained_level_satisfies_the_normal_equations_at_100k_rows(built, model):
+    """rcr22: the bench's `train` leg (F = 8 801, M = 44); rcr68: BASELINE config 5 (F = 27 201, M = 136: two right-hand-side tile
+    columns, 213 factor tiles, float16 trailing updates) -- there the float64 solve is skipped (the residual says the same)."""
     import torch
+    IDS = ibug.RCR22_IDS if model == "rcr22" else ibug.IBUG68_IDS
+    RE, LE = ibug.eye_indices(IDS)
     n_img, per = 2000, 50                                                    # 100 000 rows (bench.py: 10 000 images x 10)
     images, boxes, gt = synth.make_faces(n_img, seed=9100, chunk=32, workers=8)
     x_star, x0, idx = synth.make_samples(boxes, gt, IDS, n_perturb=per - 1, seed=9101)
@@ -38,7 +43,7 @@ def test_trained_level_satisfies_the_normal_equations_at_100k_rows(built):
     assert ctx.gram_fallbacks() == 0                                          # the float16-piece Gram kernel, no range fallback
     R, lam = ctx.solve(0, 1, 1.5, False, n_train_global=N)                    # MatrixNorm 1.5, bias row unregularised (rcr-train.cpp:440-443)
     F = R.shape[0]
-    assert F == 8801 and np.isfinite(R).all() and lam > 0
+    assert F == (8801 if model == "rcr22" else 27201) and np.isfinite(R).all() and lam > 0
     # float64 normal equations from what the engine holds: features (zero-copy view of its HBM buffer), targets b = (x0 - x*) .* norm
     p, ld, n = ctx.features_device_ptr()
     dev = torch.device("cuda", 0)
@@ -61,20 +66,20 @@ def test_trained_level_satisfies_the_normal_equations_at_100k_rows(built):
     Rt = torch.from_numpy(R.astype(np.float64)).to(dev)
     res = G @ Rt + d[:, None] * Rt - rhs
     rel = float(torch.linalg.norm(res) / torch.linalg.norm(rhs))
-    # and the distance to the float64 solution of the same system
-    want = torch.linalg.solve(G + torch.diag(d), rhs)
-    err = float(torch.linalg.norm(Rt - want) / torch.linalg.norm(want))
-    print("100 000 rows x %d features: normal-equation residual %.2e of ||A^T b||, regressor %.2e from the float64 solution" % (F, rel, err))
-    # predictions: the update the regressor produces on these rows against the float64 regressor's
-    up = A[:20000].double() @ Rt
-    up64 = A[:20000].double() @ want
-    pred = float(torch.linalg.norm(up - up64) / torch.linalg.norm(up64))
-    print("   update of 20 000 rows against the float64 regressor's: %.2e" % pred)
-    # measured 2.0e-5 / 9.0e-3 / see the print: the regressor itself is ill-determined along the weakly regularised directions of a
-    # float32 Gram matrix (cond ~ ||G|| / lambda), which is why parity is asserted on landmarks and residuals, not on R
-    assert rel < 1e-4
-    assert err < 5e-2
-    assert pred < 1e-4
+    print("100 000 rows x %d features: normal-equation residual %.2e of ||A^T b||" % (F, rel))
+    assert rel < 1e-4              # (measured 2.0e-5 at F = 8 801)
+    if model == "rcr22":
+        # the distance to the float64 solution of the same system, and of the updates it produces
+        want = torch.linalg.solve(G + torch.diag(d), rhs)
+        err = float(torch.linalg.norm(Rt - want) / torch.linalg.norm(want))
+        up = A[:20000].double() @ Rt
+        up64 = A[:20000].double() @ want
+        pred = float(torch.linalg.norm(up - up64) / torch.linalg.norm(up64))
+        print("   regressor %.2e from the float64 solution, update of 20 000 rows %.2e" % (err, pred))
+        # measured 9.0e-3 / 7.0e-5: the regressor itself is ill-determined along the weakly regularised directions of a float32 Gram
+        # matrix (cond ~ ||G|| / lambda), which is why parity is asserted on landmarks and residuals, not on R
+        assert err < 5e-2
+        assert pred < 1e-4
     ctx.close()
 
 
