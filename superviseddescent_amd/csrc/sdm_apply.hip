@@ -694,6 +694,15 @@ void sdm_launch_apply(const float* feat, long long ldf, int N, int F, const floa
                        partial, splits, N, NT * 16, M, x_in, x_out, L, eyes);
 }
 
+void sdm_launch_apply_reduce(const float* partial, int splits, int N, int M, const float* x_in, float* x_out, int L,
+                             const EyeIdxDev& eyes, hipStream_t stream)
+{
+    const long long total = (long long)N * M;
+    if (total <= 0) return;
+    hipLaunchKernelGGL(apply_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                       partial, splits, N, ((M + 15) / 16) * 16, M, x_in, x_out, L, eyes);
+}
+
 void sdm_launch_targets(const float* x, const float* xstar, int N, int L, const EyeIdxDev& eyes,
                         float* feat, long long ldf, int bcol0, hipStream_t stream)
 {

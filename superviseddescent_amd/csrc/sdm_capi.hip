@@ -83,8 +83,15 @@ struct sdm_ctx {
     std::vector<int> fast_kernel;   // per level: fused S<=64 kernel usable
     std::vector<int> fast_bins;     // per level: un-normalised arg-max verified on all 511x511 gradients
     // per level: lane-packed launch plan (sdm_hog_fast.hip::hog_packed_kernel), device tables owned here
-    struct Plan { bool ok = false; HogPlanDev dev{}; DevBuf<unsigned> lane_tab; DevBuf<float> wb; DevBuf<int> pass_info; };
+    struct Plan { bool ok = false; HogPlanDev dev{}; DevBuf<unsigned> lane_tab; DevBuf<float> wb; DevBuf<int> pass_info; DevBuf<int> cut; };
     std::vector<Plan> plans;
+    // round 4: the packed launch stops at the raw cell histograms (cells[N][L][2][2O][C*C]); sdm_desc.hip normalises them into the
+    // feature rows, or -- sdm_detect_batch -- multiplies the descriptors by the regressor without writing the feature matrix
+    DevBuf<float> cells;
+    // The feature ROWS (training, sdm_hog_features) still come from the launch that normalises inside the pixel kernel: writing the
+    // rows is HBM-bound on its own (55 us per 4 096 x 22 patches) and hides behind the pixel work there; measured 5 % slower split.
+    bool split_store = false;       // SDM_HOG_SPLIT_STORE=1: feature rows through cells + sdm_desc.hip's store form (A/B, tests)
+    bool fuse_apply = true;         // SDM_DETECT_UNFUSED=1: sdm_detect_batch through the feature matrix + apply GEMM (A/B)
     bool packing = true;            // sdm_debug_set_hog_packing / SDM_HOG_NO_PACK=1: run the one-patch-per-wave kernel instead
     int hog_mode = SDM_HOG_COLUMNS;
     int Fmax = 0;
@@ -120,6 +127,7 @@ struct sdm_ctx {
     // regressors, transposed + padded: [Mp][ldf]
     std::vector<DevBuf<float>> Rt;
     std::vector<DevBuf<unsigned char>> Rp;   // the same regressors as two float16 planes (the 16-bit matrix-core apply, sdm_apply.hip)
+    std::vector<DevBuf<unsigned char>> Rd;   // ... and per landmark in matrix-core fragment order (the fused descriptor + apply launch, sdm_desc.hip)
     DevBuf<unsigned> Rmax;                   // per level and output column: bits of max |R| (the planes' power-of-two scales)
     std::vector<bool> have_R;
 
@@ -268,13 +276,36 @@ int check_sample_index(const sdm_ctx* c)
     return SDM_OK;
 }
 
-int do_hog(sdm_ctx* c, int level)
+// the default mode's lane-packed launch is usable for this level
+bool packed_ok(const sdm_ctx* c, int level)
+{
+    return c->fast_kernel[level] && !c->narrow_images && c->packing && c->hog_mode == SDM_HOG_COLUMNS &&
+           c->fast_bins[level] == 2 && c->plans[level].ok;
+}
+bool split_ok(const sdm_ctx* c, int level) { return packed_ok(c, level) && sdm_desc_supported(c->levels[level]); }
+
+int hog_checks(sdm_ctx* c, int level)
 {
     if (!c->img_base) return fail(SDM_ERR_INVALID, "no images set");
     if (c->N <= 0) return fail(SDM_ERR_INVALID, "no samples set (sdm_set_x)");
     if (c->levels[level].fixed_h == 0 && (c->eyes.nre <= 0 || c->eyes.nle <= 0))
         return fail(SDM_ERR_INVALID, "HOG features need eye landmark indices (IED-adaptive patch size)");
-    { const int rci = check_sample_index(c); if (rci) return rci; }
+    return check_sample_index(c);
+}
+
+// pixel kernel of the split launch: images -> raw cell histograms of every (sample, landmark)
+int launch_cells(sdm_ctx* c, int level)
+{
+    int rc = c->cells.ensure(sdm_cells_floats(c->levels[level], c->N, c->L));
+    if (rc) return rc;
+    sdm_launch_hog_cells(image_set(c), c->idx_identity ? nullptr : c->img_idx.p, c->x[c->cur].p, c->N, c->L, c->eyes,
+                         c->levels[level], c->plans[level].dev, c->cells.p, c->patch_idx.p, c->status.p, c->stream);
+    return SDM_OK;
+}
+
+int do_hog(sdm_ctx* c, int level)
+{
+    { const int rci = hog_checks(c, level); if (rci) return rci; }
     if (c->feat_level >= 0 && level_F(c, c->feat_level) != level_F(c, level)) {
         // a different level geometry leaves stale columns beyond its own F: clear the rows once
         HIP_TRY(hipMemsetAsync(c->feat.p, 0, (size_t)c->N * c->ldf * sizeof(float), c->stream));
@@ -282,8 +313,11 @@ int do_hog(sdm_ctx* c, int level)
     }
     {
         Timer t(c, SDM_T_HOG);
-        if (c->fast_kernel[level] && !c->narrow_images && c->packing && c->hog_mode == SDM_HOG_COLUMNS &&
-            c->fast_bins[level] == 2 && c->plans[level].ok)
+        if (c->split_store && split_ok(c, level)) {
+            const int rcc = launch_cells(c, level);
+            if (rcc) return rcc;
+            sdm_launch_desc_store(c->levels[level], c->cells.p, c->plans[level].cut.p, c->N, c->L, c->feat.p, c->ldf, c->stream);
+        } else if (packed_ok(c, level))
             sdm_launch_hog_packed(image_set(c), c->idx_identity ? nullptr : c->img_idx.p, c->x[c->cur].p, c->N, c->L,
                                   c->eyes, c->levels[level], c->plans[level].dev, c->feat.p, c->ldf, c->patch_idx.p,
                                   c->status.p, c->stream);
@@ -312,6 +346,11 @@ int build_apply_planes(sdm_ctx* c, int level)
     int rc;
     if ((rc = c->Rp[level].ensure(sdm_apply_planes_bytes(c->ldf, c->M))) || (rc = c->Rmax.ensure(c->levels.size() * (size_t)Mp_of(c->M)))) return rc;
     sdm_launch_apply_planes(c->Rt[level].p, c->ldf, c->M, c->Rp[level].p, c->Rmax.p + (size_t)level * Mp_of(c->M), c->stream);
+    if (c->plans[level].ok && sdm_desc_supported(c->levels[level])) {      // the same pieces per landmark, in fragment order (fused detect)
+        if ((rc = c->Rd[level].ensure(sdm_desc_planes_bytes(c->levels[level], c->L, c->M)))) return rc;
+        sdm_launch_desc_planes(c->levels[level], c->Rt[level].p, c->ldf, c->L, c->M, c->Rmax.p + (size_t)level * Mp_of(c->M),
+                               c->Rd[level].p, c->stream);
+    }
     HIP_TRY(hipGetLastError());
     return SDM_OK;
 }
@@ -332,6 +371,44 @@ int do_apply(sdm_ctx* c, int level)
     }
     HIP_TRY(hipGetLastError());
     c->cur ^= 1;
+    return SDM_OK;
+}
+
+// one cascade level of sdm_detect_batch without the feature matrix: cells -> (descriptors x regressor slices) -> landmark update
+bool fused_ok(const sdm_ctx* c, int level)
+{
+    return c->fuse_apply && split_ok(c, level) && c->have_R[level] && c->Rd[level].p && c->Rp[level].p && c->tmpl_N == 0;
+}
+// sdm_detect_batch with every level fused: cells -> (descriptors x regressor slices) -> landmark update; the feature matrix is not
+// written.  (Measured and dropped: the batch as two blocks of rows on two queues, so that the short descriptor / update launches of
+// one block overlap the pixel kernel of the other -- 1.352 against 1.354 ms: the pixel kernel's workgroups hold every register
+// and LDS slot of a CU, the 51 KB descriptor workgroups of the other queue are admitted only when it drains.)
+int detect_fused(sdm_ctx* c)
+{
+    const int nl = (int)c->levels.size();
+    for (int l = 0; l < nl; ++l) { const int rci = hog_checks(c, l); if (rci) return rci; }
+    const int Mp = Mp_of(c->M);
+    int rc;
+    size_t cells_max = 0;
+    for (int l = 0; l < nl; ++l) { const size_t n = sdm_cells_floats(c->levels[l], c->N, c->L); if (n > cells_max) cells_max = n; }
+    if ((rc = c->cells.ensure(cells_max)) || (rc = c->partial.ensure((size_t)c->L * c->N * Mp))) return rc;
+    for (int l = 0; l < nl; ++l) {
+        const HogLevelDev& lv = c->levels[l];
+        {
+            Timer t(c, SDM_T_HOG);
+            sdm_launch_hog_cells(image_set(c), c->idx_identity ? nullptr : c->img_idx.p, c->x[c->cur].p, c->N, c->L, c->eyes, lv,
+                                 c->plans[l].dev, c->cells.p, c->patch_idx.p, c->status.p, c->stream);
+        }
+        {
+            Timer t(c, SDM_T_APPLY);
+            sdm_launch_desc_apply(lv, c->cells.p, c->plans[l].cut.p, c->N, c->L, c->M, c->Rd[l].p, c->Rmax.p + (size_t)l * Mp,
+                                  c->Rt[l].p, c->ldf, c->partial.p, c->stream);
+            sdm_launch_apply_reduce(c->partial.p, c->L, c->N, c->M, c->x[c->cur].p, c->x[c->cur ^ 1].p, c->L, c->eyes, c->stream);
+        }
+        HIP_TRY(hipGetLastError());
+        c->cur ^= 1;
+    }
+    c->feat_level = -1;          // (the feature rows were not produced)
     return SDM_OK;
 }
 
@@ -382,6 +459,8 @@ sdm_ctx* sdm_create(int device)
     }
     if (c->status.ensure(1, true, c->stream) || c->lambda_dev.ensure(1, true, c->stream)) { delete c; return nullptr; }
     { const char* np = getenv("SDM_HOG_NO_PACK"); c->packing = !(np && np[0] == '1'); }
+    { const char* np = getenv("SDM_HOG_SPLIT_STORE"); c->split_store = np && np[0] == '1'; }
+    { const char* np = getenv("SDM_DETECT_UNFUSED"); c->fuse_apply = !(np && np[0] == '1'); }
     return c;
 }
 
@@ -402,9 +481,11 @@ void sdm_destroy(sdm_ctx* c)
     c->xstar.release(); c->tmpl.release(); c->feat.release(); c->patch_idx.release(); c->status.release();
     c->partial.release(); c->shard_stage.release(); c->G.release(); c->gpack.release(); c->fro.release(); c->Rsol.release(); c->winv.release(); c->gram_planes.release(); c->gram_flag.release(); c->upd_planes.release(); c->upd_maxdiag.release(); c->lambda_dev.release();
     for (auto& r : c->Rp) r.release();
+    for (auto& r : c->Rd) r.release();
+    c->cells.release();
     c->Rmax.release();
     for (auto& r : c->Rt) r.release();
-    for (auto& q : c->plans) { q.lane_tab.release(); q.wb.release(); q.pass_info.release(); }
+    for (auto& q : c->plans) { q.lane_tab.release(); q.wb.release(); q.pass_info.release(); q.cut.release(); }
     if (c->own_stream) e = hipStreamDestroy(c->stream);
     delete c;
 }
@@ -511,17 +592,20 @@ int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int*
             for (int q = 0; q < l && verdict < 0; ++q)
                 if (n_levels_dev[q].O == lv.O) { verdict = n_fast_bins[q]; raw_ok = n_raw_sqrt[q]; }
             if (verdict < 0) {
-                int mism[3] = {1, 1, 1};
+                int mism[4] = {1, 1, 1, 1};
                 ScopedBuf<int> dm;
-                int rcv = dm.ensure(3, true, c->stream);
+                int rcv = dm.ensure(4, true, c->stream);
                 if (rcv) return rcv;
                 sdm_launch_verify_fast_bins(lv, dm.p, c->stream);
-                HIP_TRY(hipMemcpyAsync(mism, dm.p, 3 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipMemcpyAsync(mism, dm.p, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
                 HIP_TRY(hipStreamSynchronize(c->stream));
                 dm.release();
                 // 2 = sector count, 1 = un-normalised arg-max, 0 = reference arithmetic
                 verdict = mism[1] == 0 ? 2 : (mism[0] == 0 ? 1 : 0);
-                raw_ok = mism[2] == 0 ? 1 : 0;      // the packed kernel may take v_sqrt_f32 as it comes (else it repairs the ulp)
+                // the packed kernel's fast instances: v_sqrt_f32 as it comes AND (4 orientations) the octant code on rotated
+                // coordinates -- both verified on all 511^2 gradients on THIS device, else the instance with the repaired root and
+                // the sector count runs
+                raw_ok = (mism[2] == 0 && (lv.O != 4 || mism[3] == 0)) ? 1 : 0;
             }
             n_fast_bins.push_back(verdict);
             n_raw_sqrt.push_back(raw_ok);
@@ -536,7 +620,7 @@ int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int*
     // early returns leaked them), the context's previous tables after the swap at the commit
     struct PlanGuard {
         std::vector<sdm_ctx::Plan>& v;
-        ~PlanGuard() { for (auto& q : v) { q.lane_tab.release(); q.wb.release(); q.pass_info.release(); } }
+        ~PlanGuard() { for (auto& q : v) { q.lane_tab.release(); q.wb.release(); q.pass_info.release(); q.cut.release(); } }
     } plan_guard{n_plans};
     for (int l = 0; l < n_levels; ++l) {
         HogPlanHost hp;
@@ -544,8 +628,9 @@ int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int*
         sdm_ctx::Plan& pl = n_plans[l];
         int rcp;
         if ((rcp = pl.lane_tab.ensure(hp.lane_tab.size())) || (rcp = pl.wb.ensure(hp.wb.size())) ||
-            (rcp = pl.pass_info.ensure(hp.pass_info.size())))
+            (rcp = pl.pass_info.ensure(hp.pass_info.size())) || (rcp = pl.cut.ensure(hp.cut.size())))
             return rcp;
+        HIP_TRY(hipMemcpyAsync(pl.cut.p, hp.cut.data(), hp.cut.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(pl.lane_tab.p, hp.lane_tab.data(), hp.lane_tab.size() * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(pl.wb.p, hp.wb.data(), hp.wb.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(pl.pass_info.p, hp.pass_info.data(), hp.pass_info.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
@@ -567,6 +652,9 @@ int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int*
     c->Rt.assign(n_levels, DevBuf<float>());
     for (auto& r : c->Rp) r.release();
     c->Rp.assign(n_levels, DevBuf<unsigned char>());
+    for (auto& r : c->Rd) r.release();
+    c->Rd.assign(n_levels, DevBuf<unsigned char>());
+    c->cells.release();
     c->have_R.assign(n_levels, false);
     c->feat.release(); c->feat_level = -1;
     c->N = 0; c->have_targets = false; c->g_level = -1;
@@ -888,10 +976,14 @@ int sdm_detect_batch(sdm_ctx* c, float* x_host)
     HIP_TRY(hipSetDevice(c->device));
     c->chain_timers = true; c->ev_fresh = false;
     int rc = SDM_OK;
-    for (int l = 0; l < (int)c->levels.size() && !rc; ++l) {
-        rc = do_hog(c, l);
-        if (!rc) rc = do_apply(c, l);
-    }
+    bool all_fused = true;
+    for (int l = 0; l < (int)c->levels.size(); ++l) all_fused = all_fused && fused_ok(c, l);
+    if (all_fused) rc = detect_fused(c);
+    else
+        for (int l = 0; l < (int)c->levels.size() && !rc; ++l) {
+            rc = do_hog(c, l);
+            if (!rc) rc = do_apply(c, l);
+        }
     c->chain_timers = false; c->ev_fresh = false;
     if (rc) return rc;
     if (x_host) return sdm_get_x(c, x_host);

@@ -201,6 +201,23 @@ __device__ inline void bin_sector4_bits(float gx, float gy, const HogLevelDev& l
     b2 = (s && !A) != Y;
 }
 
+// Round 4: the same eight sectors on coordinates rotated by -22.5 degrees, where the sector boundaries are the two axes and the
+// two diagonals: octant code = 4 [x' < 0] + 2 [y' < 0] + [|x'| < |y'|] -- three sign tests, no scalar boolean chain (the three
+// bits above cost five scalar instructions per pixel row, and every scalar instruction takes an issue slot beside the vector
+// ones).  The code is NOT the bin: bin j lives in column-sum row HP_ROW_OF_BIN(j), and the band folds read their matrix-core
+// rows through that permutation, so the histograms come out in bin order.  Used only when verify_fast_bins_kernel found the
+// code's bin equal to the reference's on all 511 x 511 gradients (counter 3).
+#define HP_ROT_C 0.92387953251128674f      /* cos(pi / 8) */
+#define HP_ROT_S 0.38268343236508977f      /* sin(pi / 8) */
+#define HP_ROW_OF_BIN(j) ((0x37645102u >> (4 * (j))) & 7u)      /* bins 0..7 -> rows 2 0 1 5 4 6 7 3 */
+__device__ inline int bin_rot4_row(float gx, float gy)
+{
+    typedef float v2 __attribute__((ext_vector_type(2)));
+    const v2 r = __builtin_elementwise_fma((v2){gy, gy}, (v2){HP_ROT_S, HP_ROT_C}, (v2){gx, gx} * (v2){HP_ROT_C, -HP_ROT_S});
+    const float w = __builtin_fabsf(r.x) - __builtin_fabsf(r.y);
+    return (r.x < 0.0f ? 4 : 0) + (r.y < 0.0f ? 2 : 0) + (w < 0.0f ? 1 : 0);
+}
+
 // per-wave LDS layout.  Region A lives for the whole patch, region B is first the rolling private
 // accumulators of the row loop and afterwards the scratch of the normalisation phase.
 struct FastLds {
@@ -1211,8 +1228,19 @@ __host__ __device__ constexpr int packed_band_of(int d, int cell)
 // the S rows -- no per-row scalar loads of the band index, no band compare / branch, no loop counter.  CELL == 0: any cell size
 // (the round-2 form of the loop).  RAW: the gradient magnitude is v_sqrt_f32 as the hardware returns it (chosen per level at
 // sdm_set_model_geometry, only if the exhaustive check found it exact or one ulp low on all 511^2 gradients).
-template <int TO, int TC, int CELL, bool RAW>
-__global__ void __launch_bounds__(HP_WAVES * 64, HP_MINW)
+// CELLS: the launch stops at the raw cell histograms (round 4): every band fold stores its cells straight to HBM,
+// cells[sample][landmark][part][C*C][2O] (a lane stores its four bins of one cell with one 16-byte store; part 0: the pass that sees the patch's first column, part 1: the second pass of a
+// patch cut by a pass boundary -- the consumer adds the two), there are no histogram slots in LDS and no normalisation phase in
+// this kernel: sdm_desc.hip normalises (hog.c:857-1062) with a lane per cell and either writes the feature rows or multiplies
+// the descriptors by the regressor while they are still on the chip.  `feat` is then the cells buffer, `ldf` unused.
+#ifndef HP_PAIRFOLD
+#define HP_PAIRFOLD 1               /* CELLS, 4 orientations: the last two bands of a pass in one set of matrix-core products */
+#endif
+#ifndef HP_MINW_CELLS
+#define HP_MINW_CELLS 6             /* the CELLS form needs 5.1 KB of LDS per wave: seven waves per SIMD fit if the registers do (<= 72) */
+#endif
+template <int TO, int TC, int CELL, bool RAW, bool CELLS = false>
+__global__ void __launch_bounds__(HP_WAVES * 64, CELLS ? HP_MINW_CELLS : HP_MINW)
 hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float* __restrict__ x, int N, int L,
                   EyeIdxDev eyes, HogLevelDev lv, HogPlanDev plan, float* __restrict__ feat, long long ldf,
                   int* __restrict__ idx_out, int* __restrict__ status)
@@ -1240,8 +1268,9 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
     constexpr int SC = TC * CELL;                 // (0 for the generic instance)
     const int S = CELL > 0 ? SC : lv.S;
 
-    const int nslots = plan.hist_slots;                                               // 2, or 3 for ROIs under 22 columns
+    const int nslots = CELLS ? 0 : plan.hist_slots;                                   // 2, or 3 for ROIs under 22 columns; none when the cells go to HBM
     constexpr bool SPEC = CELL > 0;
+    constexpr bool ROTB = RAW && TO == 4;          // octant code on rotated coordinates (bin_rot4_row); the folds read rows HP_ROW_OF_BIN(bin)
     unsigned char* lds = smem + (size_t)wave * packed_lds_bytes(C, O, S, nslots, SPEC);
     float* colrows = (float*)lds;                                                    // [2O][ST][2 band slots]
     i32x4* rowtab = (i32x4*)(lds + al16(HP_ROWS_BYTES(O)));                          // [S (+ 2)] {row offset 0, row offset 1, weight 0 << 12, weight 1 << 12}
@@ -1358,12 +1387,17 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
         const int sg = li < C ? 0 : (li < 2 * C ? 1 : (li < 3 * C ? 2 : 3));
         const int seg_slot = sg == 0 ? pinfo[0] : (sg == 1 ? pinfo[1] : (sg == 2 ? pinfo[2] : -1));
         const bool recv = seg_slot >= 0;                                   // (rows 16 mt + 4 lq + e >= 2O are skipped at the store)
-        float* hrecv = hist + (seg_slot >= 0 ? hist_slot(seg_slot) : 0) * HSTR + (4 * lq) * CC + (li - sg * C);
         const int done = pinfo[3];
         const int nkp = (done >> 16) & 0xff;          // k-step pairs (8 lanes each) that hold columns in this pass
         // the first pass that touches a patch STORES its cells, a later one (the patch was cut) adds to them: the histogram
         // slots need no clearing, and the uncut patches no read-modify-write
         const bool first_seen = sg < 3 && ((done >> (24 + sg)) & 1);
+        float* hrecv;
+        if (CELLS)      // HBM: cells[sample][landmark][part][cell][bin]; part 1 = the second pass of a cut patch.  A lane holds four
+                        // consecutive bins of one cell: one 16-byte store per fold
+            hrecv = feat + ((((long long)s * L + lm0 + (seg_slot >= 0 ? seg_slot : 0)) * 2 + (first_seen ? 0 : 1)) * CC + (li - sg * C)) * (2 * O) + 4 * lq;
+        else
+            hrecv = hist + (seg_slot >= 0 ? hist_slot(seg_slot) : 0) * HSTR + (4 * lq) * CC + (li - sg * C);
 
         // ---- row loop ----------------------------------------------------------------------------------------------------------
         // the image loads of row y: the two source rows' byte offsets come from the row table (one broadcast 8-byte LDS read)
@@ -1396,7 +1430,10 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
         float pend_g = 0.0f;
         int prev_by = -1;
         // fold band b (slot b & 1): hist[patch of n][bin][b][cell of n] += sum_x col[bin][x] W[x][n], clear the slot
-        auto fold_band = [&](const int b) __attribute__((always_inline)) {
+        // `pair` (CELLS, 4 orientations; round 4): bands b and b + 1 in ONE set of products -- the 8 bin rows of band b's slot are the
+        // matrix-core rows 0..7, the 8 of band b + 1's slot the rows 8..15 (idle until now) -- used for the last two bands of a pass,
+        // which are complete at the same pixel row: four fold events per pass instead of five.
+        auto fold_band = [&](const int b, const bool pair = false) __attribute__((always_inline)) {
             if (HP_ABL == 1) return;
             const int sl = b & 1;
             wave_sync();
@@ -1405,7 +1442,10 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 fa0[mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; fa1[mt] = fa0[mt];
-                ap[mt] = colrows + ((16 * mt + li < 2 * O ? 16 * mt + li : 2 * O - 1) * ST + lq) * 2 + sl;
+                int bin_i = 16 * mt + li < 2 * O ? 16 * mt + li : 2 * O - 1;
+                int sl_i = sl;
+                if (pair) { bin_i = li & 7; sl_i = (li >> 3) ? (sl ^ 1) : sl; }
+                ap[mt] = colrows + ((ROTB ? (int)HP_ROW_OF_BIN(bin_i) : bin_i) * ST + lq) * 2 + sl_i;
             }
             // the operand reads run two k-step pairs ahead of the products (the scheduling barriers keep that order: with the
             // reads serialised behind the products every fold cost eight LDS round trips)
@@ -1435,11 +1475,32 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // every lane clears the slot of its own pixel column (the LDS unit executes this wave's accesses in order)
-            float* cz = (float*)cbase0 + sl;
+            // every lane clears the slot(s) of its own pixel column (the LDS unit executes this wave's accesses in order)
+            if (pair) {
 #pragma unroll
-            for (int k = 0; k < 2 * O; ++k) cz[k * ST * 2] = 0.0f;
-            if (recv) {
+                for (int k = 0; k < 2 * O; ++k) *(f32x2*)((float*)cbase0 + k * ST * 2) = (f32x2){0.0f, 0.0f};
+            } else {
+                float* cz = (float*)cbase0 + sl;
+#pragma unroll
+                for (int k = 0; k < 2 * O; ++k) cz[k * ST * 2] = 0.0f;
+            }
+            if (CELLS) {
+                if (recv) {
+                    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(8)));
+                    if (pair) {      // rows 4 lq .. 4 lq + 3: bins 4 (lq & 1) .. of band b + (lq >> 1)
+                        float* hf = hrecv + ((b + (lq >> 1)) * C) * (2 * O) - 4 * lq + 4 * (lq & 1);
+                        *(f32x4u*)hf = fa0[0] + fa1[0];
+                    } else {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            float* hf = hrecv + b * C * (2 * O) + 16 * mt;
+                            const int left = 2 * O - (16 * mt + 4 * lq);      // bins from this lane's first one to the last
+                            if (left >= 4) *(f32x4u*)hf = fa0[mt] + fa1[mt];
+                            else if (left >= 2) *(f32x2*)hf = (f32x2){fa0[mt][0] + fa1[mt][0], fa0[mt][1] + fa1[mt][1]};
+                        }
+                    }
+                }
+            } else if (recv) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     float* hf = hrecv + b * C + 16 * mt * CC;
@@ -1474,7 +1535,11 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
                 const float gm = (HP_RAWSQRT && RAW) ? __builtin_amdgcn_sqrtf(g2) : sqrt_int_up(g2);
                 bool b0 = false, b1 = false, b2 = false;
                 int bin_any = 0;
-                if constexpr (TO == 4) bin_sector4_bits(gx, gy, lv, b0, b1, b2);
+                if constexpr (ROTB) {
+                    typedef float v2 __attribute__((ext_vector_type(2)));
+                    const v2 rr = __builtin_elementwise_fma((v2){gy, gy}, (v2){HP_ROT_S, HP_ROT_C}, (v2){gx, gx} * (v2){HP_ROT_C, -HP_ROT_S});
+                    b0 = (__builtin_fabsf(rr.x) - __builtin_fabsf(rr.y)) < 0.0f; b1 = rr.y < 0.0f; b2 = rr.x < 0.0f;      // row = b0 + 2 b1 + 4 b2
+                } else if constexpr (TO == 4) bin_sector4_bits(gx, gy, lv, b0, b1, b2);
                 else bin_sector<TO>(gx, gy, lv, TO, bin_any);      // (a zero gradient lands in bin 0 with magnitude 0)
                 if (HP_ABL == 3) { f32x2 dz = __builtin_elementwise_fma(pend_v, (f32x2){pend_g, pend_g}, qv); asm volatile("" :: "v"(dz), "v"(pend_p)); }
                 else if (HP_PKFMA) *pend_p = __builtin_elementwise_fma(pend_v, (f32x2){pend_g, pend_g}, qv);
@@ -1514,26 +1579,31 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
         }
         if (HP_PKFMA) *pend_p = __builtin_elementwise_fma(pend_v, (f32x2){pend_g, pend_g}, *pend_p);
         else *pend_p += pend_v;
-        if (prev_by >= 0) fold_band(prev_by);
-        if (prev_by + 1 <= C - 1) fold_band(prev_by + 1);
+        if (CELLS && TO == 4 && HP_PAIRFOLD && prev_by >= 0 && prev_by + 1 <= C - 1) fold_band(prev_by, true);
+        else {
+            if (prev_by >= 0) fold_band(prev_by);
+            if (prev_by + 1 <= C - 1) fold_band(prev_by + 1);
+        }
         wave_sync();
 
         // ---- patches whose last column was in this pass: normalise, store, free the histogram slot -----------------------------
         const int dfirst = done & 0xff, dcount = (done >> 8) & 0xff;
         for (int j = 0; j < dcount; ++j) {
             const int ps = dfirst + j, lmp = lm0 + ps;
-            float* hp = hist + hist_slot(ps) * HSTR;
-            if (HP_ABL != 2) hog_finish_direct<TO, TC>(hp, scratch, out_row + (long long)lmp * lv.P, lv, lane);
-            if (HP_OVERLAY)      // the scratch sat on the column rows, which the next pass expects to be zero
-                for (int i = lane; i < (int)(packed_scratch_bytes(C, O) / 16); i += 64) ((f32x4*)scratch)[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            if (!CELLS) {
+                float* hp = hist + hist_slot(ps) * HSTR;
+                if (HP_ABL != 2) hog_finish_direct<TO, TC>(hp, scratch, out_row + (long long)lmp * lv.P, lv, lane);
+                if (HP_OVERLAY)      // the scratch sat on the column rows, which the next pass expects to be zero
+                    for (int i = lane; i < (int)(packed_scratch_bytes(C, O) / 16); i += 64) ((f32x4*)scratch)[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            }
             if (idx_row && lane == 0) {
                 if (lmp == 0) idx_row[0] = h;
                 idx_row[1 + lmp] = __float2int_rn(xr[lmp]);
                 idx_row[1 + L + lmp] = __float2int_rn(xr[lmp + L]);
             }
             // bias, adaptive_vlhog.hpp:182-183 (the non-adaptive example transform has none)
-            if (lmp == L - 1 && lv.fixed_h == 0 && lane == 0) out_row[(long long)L * lv.P] = 1.0f;
-            wave_sync();
+            if (!CELLS && lmp == L - 1 && lv.fixed_h == 0 && lane == 0) out_row[(long long)L * lv.P] = 1.0f;
+            if (!CELLS) wave_sync();
         }
     }
 }
@@ -1566,6 +1636,13 @@ __global__ void verify_fast_bins_kernel(HogLevelDev lv, int* __restrict__ mismat
     // the packed kernel's raw v_sqrt_f32: acceptable only if it is the correctly rounded root or exactly one ulp below it
     const int raw = __builtin_bit_cast(int, __builtin_amdgcn_sqrtf(g2));
     if (!(raw == want || raw == want - 1)) atomicAdd(mismatches + 2, 1);
+    // the packed kernel's octant code on rotated coordinates (4 orientations): its bin must be the reference's
+    if (lv.O == 4) {
+        const int row = bin_rot4_row(gx, gy);
+        int jb = -1;
+        for (int j = 0; j < 8; ++j) if ((int)HP_ROW_OF_BIN(j) == row) jb = j;
+        if (!((a == jb) || (a == -1 && g == 0.0f))) atomicAdd(mismatches + 3, 1);
+    }
 }
 
 }  // namespace
@@ -1638,6 +1715,20 @@ bool sdm_hog_plan_build(const HogLevelDev& lv, int L, HogPlanHost& out)
     out.Pt = out.Gt ? plan_pack(S, out.Gt, tail_p) : 0;
     const int NP = out.P + out.Pt;
     out.hist_slots = 2;
+    // landmarks whose patch is cut by a pass boundary (its cells are the sum of two partial folds)
+    out.cut.assign((size_t)L, 0);
+    for (int pt = 0; pt < NP; ++pt) {
+        const std::vector<PlanLane>& pl = pt < out.P ? main_p[pt] : tail_p[pt - out.P];
+        for (size_t xl = 0; xl < pl.size(); ++xl) {
+            const bool starts_here = pl[xl].col == 0;
+            if (xl == 0 || pl[xl].slot != pl[xl - 1].slot) {      // first lane of a segment
+                if (!starts_here) {                                 // the patch began in the previous pass: cut
+                    if (pt < out.P) { for (int g = 0; g < out.n_main; ++g) out.cut[(size_t)g * out.G + pl[xl].slot] = 1; }
+                    else out.cut[(size_t)out.n_main * out.G + pl[xl].slot] = 1;
+                }
+            }
+        }
+    }
     out.lane_tab.assign((size_t)NP * 64, 0u);
     out.wb.assign((size_t)NP * 64 * 16, 0.0f);
     out.pass_info.assign((size_t)NP * 4, -1);
@@ -1676,24 +1767,25 @@ bool sdm_hog_plan_build(const HogLevelDev& lv, int L, HogPlanHost& out)
     return true;
 }
 
-void sdm_launch_hog_packed(const ImageSetDev& imgs, const int* img_idx, const float* x, int N, int L,
-                           const EyeIdxDev& eyes, const HogLevelDev& lv, const HogPlanDev& plan, float* feat, long long ldf,
-                           int* idx_out, int* status, hipStream_t stream)
+template <bool CELLS>
+static void launch_hog_packed(const ImageSetDev& imgs, const int* img_idx, const float* x, int N, int L,
+                              const EyeIdxDev& eyes, const HogLevelDev& lv, const HogPlanDev& plan, float* feat, long long ldf,
+                              int* idx_out, int* status, hipStream_t stream)
 {
     const int gpf = plan.n_main + (plan.Gt > 0 ? 1 : 0);
     const long long total = (long long)N * gpf;
     if (total <= 0) return;
     const unsigned grid = (unsigned)((total + HP_WAVES - 1) / HP_WAVES);
 #define HP_LAUNCH_O(TO, CELL, RAW)                                                                                              \
-    hipLaunchKernelGGL((hog_packed_kernel<TO, 5, CELL, RAW>), dim3(grid), dim3(HP_WAVES * 64),                                     \
-                       packed_wg_lds_bytes(5, TO, lv.S, plan.hist_slots, CELL > 0), stream, imgs, img_idx, x, N, L,               \
+    hipLaunchKernelGGL((hog_packed_kernel<TO, 5, CELL, RAW, CELLS>), dim3(grid), dim3(HP_WAVES * 64),                              \
+                       packed_wg_lds_bytes(5, TO, lv.S, CELLS ? 0 : plan.hist_slots, CELL > 0), stream, imgs, img_idx, x, N, L,  \
                        eyes, lv, plan, feat, ldf, idx_out, status)
 #define HP_LAUNCH(CELL, RAW) HP_LAUNCH_O(4, CELL, RAW)
     if (lv.O == 9) {      // "31-bin" HOG (9 orientations, hog.c:212-215): 18 bin rows = two matrix-core row tiles per band fold
         static unsigned long long attr9 = 0;
         if (sdm_first_use_on_device(attr9)) {
-            SDM_SET_ATTR((const void*)hog_packed_kernel<9, 5, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            SDM_SET_ATTR((const void*)hog_packed_kernel<9, 5, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            SDM_SET_ATTR((const void*)hog_packed_kernel<9, 5, 0, true, CELLS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            SDM_SET_ATTR((const void*)hog_packed_kernel<9, 5, 0, false, CELLS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         }
         if (plan.raw_sqrt) HP_LAUNCH_O(9, 0, true); else HP_LAUNCH_O(9, 0, false);
         return;
@@ -1712,6 +1804,21 @@ void sdm_launch_hog_packed(const ImageSetDev& imgs, const int* img_idx, const fl
     }
 #undef HP_LAUNCH
 #undef HP_LAUNCH_O
+}
+
+void sdm_launch_hog_packed(const ImageSetDev& imgs, const int* img_idx, const float* x, int N, int L,
+                           const EyeIdxDev& eyes, const HogLevelDev& lv, const HogPlanDev& plan, float* feat, long long ldf,
+                           int* idx_out, int* status, hipStream_t stream)
+{
+    launch_hog_packed<false>(imgs, img_idx, x, N, L, eyes, lv, plan, feat, ldf, idx_out, status, stream);
+}
+
+// the same launch stopping at the raw cell histograms: cells[N][L][2 parts][2O][C*C] floats (see hog_packed_kernel, CELLS)
+void sdm_launch_hog_cells(const ImageSetDev& imgs, const int* img_idx, const float* x, int N, int L,
+                          const EyeIdxDev& eyes, const HogLevelDev& lv, const HogPlanDev& plan, float* cells,
+                          int* idx_out, int* status, hipStream_t stream)
+{
+    launch_hog_packed<true>(imgs, img_idx, x, N, L, eyes, lv, plan, cells, 0, idx_out, status, stream);
 }
 
 bool sdm_hog_fast_supported(const HogLevelDev& lv)

@@ -107,6 +107,7 @@ struct HogPlanHost {
     std::vector<unsigned> lane_tab;
     std::vector<float> wb;
     std::vector<int> pass_info;
+    std::vector<int> cut;      // [L] 1: the landmark's patch is cut by a pass boundary (its raw cells arrive in two parts)
 };
 // false when the level has no packed instance (then sdm_launch_hog_fast runs it)
 bool sdm_hog_plan_build(const HogLevelDev& lv, int L, HogPlanHost& out);
@@ -114,6 +115,27 @@ bool sdm_hog_plan_build(const HogLevelDev& lv, int L, HogPlanHost& out);
 void sdm_launch_hog_packed(const ImageSetDev& imgs, const int* img_idx, const float* x, int N, int L,
                            const EyeIdxDev& eyes, const HogLevelDev& lv, const HogPlanDev& plan, float* feat, long long ldf,
                            int* idx_out, int* status, hipStream_t stream);
+
+// The packed launch stopping at the raw cell histograms (round 4): cells[N][L][2 parts][2O][C*C] f32; part 1 is written only
+// for landmarks with plan cut[l] = 1 (patch cut by a pass boundary); sdm_desc.hip turns them into descriptors.
+void sdm_launch_hog_cells(const ImageSetDev& imgs, const int* img_idx, const float* x, int N, int L,
+                          const EyeIdxDev& eyes, const HogLevelDev& lv, const HogPlanDev& plan, float* cells,
+                          int* idx_out, int* status, hipStream_t stream);
+
+// ---- raw cells -> descriptors (sdm_desc.hip) ----
+bool sdm_desc_supported(const HogLevelDev& lv);
+size_t sdm_cells_floats(const HogLevelDev& lv, int N, int L);
+// store mode: feat[n][l * P + ...] (+ bias) from the cells, hog_finish_direct's arithmetic with one lane per cell
+void sdm_launch_desc_store(const HogLevelDev& lv, const float* cells, const int* cut, int N, int L, float* feat, long long ldf, hipStream_t stream);
+// detect: descriptors x the landmark's slice of the regressor on the 16-bit matrix cores, partial[L][N][Mp]; the regressor as
+// float16 planes in fragment order (sdm_desc_planes_bytes; scales = the apply planes' rmax words), Rt for the bias row
+size_t sdm_desc_planes_bytes(const HogLevelDev& lv, int L, int M);
+void sdm_launch_desc_planes(const HogLevelDev& lv, const float* Rt, long long ldr, int L, int M, const unsigned* rmax, void* planes, hipStream_t stream);
+void sdm_launch_desc_apply(const HogLevelDev& lv, const float* cells, const int* cut, int N, int L, int M, const void* planes,
+                           const unsigned* rmax, const float* Rt, long long ldr, float* partial, hipStream_t stream);
+// x_out = x_in - (sum over `splits` of partial[split][N][Mp]) * IED(x_in)   (the split-K reduction of sdm_launch_apply on its own)
+void sdm_launch_apply_reduce(const float* partial, int splits, int N, int M, const float* x_in, float* x_out, int L,
+                             const EyeIdxDev& eyes, hipStream_t stream);
 
 void sdm_launch_hog_fast_profile(const ImageSetDev& imgs, const int* img_idx, const float* x, int N, int L,
                                  const EyeIdxDev& eyes, const HogLevelDev& lv, float* feat, long long ldf,
