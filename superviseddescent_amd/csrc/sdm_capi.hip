@@ -83,7 +83,7 @@ struct sdm_ctx {
     std::vector<int> fast_kernel;   // per level: fused S<=64 kernel usable
     std::vector<int> fast_bins;     // per level: un-normalised arg-max verified on all 511x511 gradients
     // per level: lane-packed launch plan (sdm_hog_fast.hip::hog_packed_kernel), device tables owned here
-    struct Plan { bool ok = false; HogPlanDev dev{}; DevBuf<unsigned> lane_tab; DevBuf<float> wb; DevBuf<int> pass_info; DevBuf<int> cut; };
+    struct Plan { bool ok = false; HogPlanDev dev{}; DevBuf<unsigned> lane_tab; DevBuf<float> wb; DevBuf<int> pass_info; DevBuf<int> cut; DevBuf<int> taps; };
     std::vector<Plan> plans;
     // round 4: the packed launch stops at the raw cell histograms (cells[N][L][2][2O][C*C]); sdm_desc.hip normalises them into the
     // feature rows, or -- sdm_detect_batch -- multiplies the descriptors by the regressor without writing the feature matrix
@@ -183,6 +183,22 @@ struct sdm_ctx {
 namespace {
 
 int Mp_of(int M) { return round_up(M, 16); }
+
+// the kernels' per-coordinate arithmetic (hog.c:697-704), IEEE on the host: {weight of band slot 0, of band slot 1, cell index, upper weight}
+void fill_row_tab(HogLevelDev& lv)
+{
+    for (int d = 0; d < 64 && d < lv.S; ++d) {
+        const float hx = (float)((d + 0.5) / (double)lv.cell - 0.5);
+        int b = (int)hx;
+        if (!(hx >= 0.0f || (float)b == hx)) b -= 1;                        // vl_floor_f
+        const float w2 = hx - (float)b, w1 = (float)(1.0 - w2);
+        const float wlo = b >= 0 ? w1 : 0.0f, whi = b + 1 <= lv.C - 1 ? w2 : 0.0f;   // the cell rows -1 and C do not exist
+        lv.row_tab[d][0] = (b & 1) ? whi : wlo;                              // band b lives in slot b & 1
+        lv.row_tab[d][1] = (b & 1) ? wlo : whi;
+        memcpy(&lv.row_tab[d][2], &b, sizeof(int));
+        lv.row_tab[d][3] = w2;
+    }
+}
 
 struct Timer {
     sdm_ctx* c; int slot; hipEvent_t a = nullptr, b = nullptr; bool a_shared = false;
@@ -485,7 +501,7 @@ void sdm_destroy(sdm_ctx* c)
     c->cells.release();
     c->Rmax.release();
     for (auto& r : c->Rt) r.release();
-    for (auto& q : c->plans) { q.lane_tab.release(); q.wb.release(); q.pass_info.release(); q.cut.release(); }
+    for (auto& q : c->plans) { q.lane_tab.release(); q.wb.release(); q.pass_info.release(); q.cut.release(); q.taps.release(); }
     if (c->own_stream) e = hipStreamDestroy(c->stream);
     delete c;
 }
@@ -570,17 +586,7 @@ int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int*
         }
         lv.n_sector = lv.O / 2;
         for (int j = 0; j < lv.n_sector; ++j) lv.sector_t[j] = (float)tan((2 * j + 1) * 3.141592653589793 / (2.0 * lv.O));
-        for (int d = 0; d < 64 && d < lv.S; ++d) {      // the kernel's per-coordinate arithmetic (hog.c:697-704), IEEE on the host
-            const float hx = (float)((d + 0.5) / (double)lv.cell - 0.5);
-            int b = (int)hx;
-            if (!(hx >= 0.0f || (float)b == hx)) b -= 1;                        // vl_floor_f
-            const float w2 = hx - (float)b, w1 = (float)(1.0 - w2);
-            const float wlo = b >= 0 ? w1 : 0.0f, whi = b + 1 <= lv.C - 1 ? w2 : 0.0f;   // the cell rows -1 and C do not exist
-            lv.row_tab[d][0] = (b & 1) ? whi : wlo;                              // band b lives in slot b & 1
-            lv.row_tab[d][1] = (b & 1) ? wlo : whi;
-            memcpy(&lv.row_tab[d][2], &b, sizeof(int));
-            lv.row_tab[d][3] = w2;
-        }
+        fill_row_tab(lv);
         for (int hh = 1; hh < SDM_SCALE_TAB; ++hh) lv.scale_tab[hh] = 1.0 / ((double)lv.S / (double)(2 * hh));
         lv.scale_tab[0] = 1.0 / ((double)lv.S / 1.0);      // an empty patch (h <= 0) is given a 1-pixel source
         if (sdm_hog_lds_bytes(lv, 4) > 160 * 1024) return fail(SDM_ERR_INVALID, "HOG geometry exceeds the LDS budget");
@@ -620,7 +626,7 @@ int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int*
     // early returns leaked them), the context's previous tables after the swap at the commit
     struct PlanGuard {
         std::vector<sdm_ctx::Plan>& v;
-        ~PlanGuard() { for (auto& q : v) { q.lane_tab.release(); q.wb.release(); q.pass_info.release(); q.cut.release(); } }
+        ~PlanGuard() { for (auto& q : v) { q.lane_tab.release(); q.wb.release(); q.pass_info.release(); q.cut.release(); q.taps.release(); } }
     } plan_guard{n_plans};
     for (int l = 0; l < n_levels; ++l) {
         HogPlanHost hp;
@@ -631,13 +637,15 @@ int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int*
             (rcp = pl.pass_info.ensure(hp.pass_info.size())) || (rcp = pl.cut.ensure(hp.cut.size())))
             return rcp;
         HIP_TRY(hipMemcpyAsync(pl.cut.p, hp.cut.data(), hp.cut.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        if ((rcp = pl.taps.ensure((size_t)SDM_SCALE_TAB * 64 * 8))) return rcp;
+        sdm_launch_taps_table(n_levels_dev[l], pl.taps.p, c->stream);
         HIP_TRY(hipMemcpyAsync(pl.lane_tab.p, hp.lane_tab.data(), hp.lane_tab.size() * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(pl.wb.p, hp.wb.data(), hp.wb.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(pl.pass_info.p, hp.pass_info.data(), hp.pass_info.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));      // (the host vectors go out of scope)
         pl.dev.G = hp.G; pl.dev.P = hp.P; pl.dev.n_main = hp.n_main; pl.dev.Gt = hp.Gt; pl.dev.Pt = hp.Pt; pl.dev.hist_slots = hp.hist_slots;
         pl.dev.raw_sqrt = n_raw_sqrt[l];
-        pl.dev.lane_tab = pl.lane_tab.p; pl.dev.wb = pl.wb.p; pl.dev.pass_info = pl.pass_info.p;
+        pl.dev.lane_tab = pl.lane_tab.p; pl.dev.wb = pl.wb.p; pl.dev.pass_info = pl.pass_info.p; pl.dev.taps = pl.taps.p;
         pl.ok = true;
     }
     // ---- commit ----
@@ -1421,14 +1429,7 @@ int sdm_debug_hog_plan(int num_cells, int cell_size, int num_bins, int num_landm
     HogLevelDev lv;
     memset(&lv, 0, sizeof(lv));
     lv.variant = SDM_VARIANT_UOCTTI; lv.C = num_cells; lv.cell = cell_size; lv.O = num_bins; lv.S = num_cells * cell_size;
-    for (int d = 0; d < 64 && d < lv.S; ++d) {      // as sdm_set_model_geometry
-        const float hx = (float)((d + 0.5) / (double)lv.cell - 0.5);
-        int b = (int)hx;
-        if (!(hx >= 0.0f || (float)b == hx)) b -= 1;
-        const float w2 = hx - (float)b;
-        memcpy(&lv.row_tab[d][2], &b, sizeof(int));
-        lv.row_tab[d][3] = w2;
-    }
+    fill_row_tab(lv);      // as sdm_set_model_geometry
     HogPlanHost hp;
     if (!info5) return fail(SDM_ERR_INVALID, "bad arguments");
     if (!sdm_hog_plan_build(lv, num_landmarks, hp)) { info5[0] = 0; return SDM_OK; }

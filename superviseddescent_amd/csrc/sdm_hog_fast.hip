@@ -215,7 +215,10 @@ __device__ inline int bin_rot4_row(float gx, float gy)
     typedef float v2 __attribute__((ext_vector_type(2)));
     const v2 r = __builtin_elementwise_fma((v2){gy, gy}, (v2){HP_ROT_S, HP_ROT_C}, (v2){gx, gx} * (v2){HP_ROT_C, -HP_ROT_S});
     const float w = __builtin_fabsf(r.x) - __builtin_fabsf(r.y);
-    return (r.x < 0.0f ? 4 : 0) + (r.y < 0.0f ? 2 : 0) + (w < 0.0f ? 1 : 0);
+    // the kernel takes the SIGN BITS (a -0.0f would count as negative): checked here in that form
+    // (scalar copies first: __builtin_bit_cast applied to the vector ELEMENT r.y reads element 0 with this compiler)
+    const float rx1 = r.x, ry1 = r.y;
+    return (int)((((__builtin_bit_cast(unsigned, rx1) >> 31) << 1 | (__builtin_bit_cast(unsigned, ry1) >> 31)) << 1) | (__builtin_bit_cast(unsigned, w) >> 31));
 }
 
 // per-wave LDS layout.  Region A lives for the whole patch, region B is first the rolling private
@@ -1069,7 +1072,7 @@ hog_fast_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float* 
 #endif             /* plan: among equally dense group sizes prefer one with at least two passes per wave (measured: the smaller group wins, 1.54 -> 1.50 ms) */
 #endif
 #ifndef HP_ABL
-#define HP_ABL 0                    /* experiments: 1 no folds, 2 no finish, 3 no column read-modify-write, 4 no image loads, 5 no gradient, 6 folds without their matrix instructions */
+#define HP_ABL 0                    /* experiments: 1 no folds, 2 no finish, 3 no column read-modify-write, 4 no image loads, 5 no gradient, 6 folds without their matrix instructions, 7 no per-row LDS table reads, 8 no resize arithmetic, 9 no binning, 10 no square root */
 #endif
 #define HP_ROWS_BYTES(O) ((size_t)2 * (O) * HP_ST * 8)
 #define HP_HIST_BYTES(O, CC) ((size_t)2 * (O) * (CC) * 4)
@@ -1085,7 +1088,34 @@ __host__ __device__ inline size_t packed_scratch_bytes(int C, int O = 4)
 // (the finish scratch overlays the column rows, which are all zero between two passes)
 // (the generic instance issues its image loads two rows ahead without looking: entries S and S + 1 repeat the last row; the
 //  instances specialised on the cell size know at compile time where the ROI ends and keep S entries)
-__host__ __device__ inline size_t packed_rowtab_bytes(int S, bool spec = false) { return (size_t)(S + (spec ? 0 : 2)) * 16; }
+// Round 4: the per-row entries no longer live in LDS at all (HP_ROWREG).  The ablation profiles/r04_hog_ablations.txt priced the two
+// broadcast LDS reads per pixel row (this table + the band-slot weights) at 23 % of the kernel -- more than all of the resize
+// arithmetic (4 %): every one is a dependent round trip through a queue that 24 waves keep ~60 % busy.  Lane d still holds the
+// taps of coordinate d in registers, so row y's entry is four v_readlane (scalar operands of the address adds and of the two
+// vertical multiplies), and the specialised instances take the band-slot weights as compile-time constants (PackedWs).
+#ifndef HP_ROWREG
+#define HP_ROWREG 0      /* measured: 1.188 against 1.147 ms (sum of the four levels) -- the four v_readlane per row cost more than the two LDS reads */
+#endif
+__host__ __device__ inline size_t packed_rowtab_bytes(int S, bool spec = false) { return HP_ROWREG ? 0 : (size_t)(S + (spec ? 0 : 2)) * 16; }
+// band-slot weights {slot 0, slot 1} of resized-ROI row d, evaluated at compile time with the host's expressions
+// (sdm_set_model_geometry's lv.row_tab, hog.c:697-704); sdm_hog_plan_build compares the two bit for bit before a specialised
+// instance may be chosen
+template <int CELL, int TC>
+struct PackedWs {
+    float w[64][2];
+    constexpr PackedWs() : w{}
+    {
+        for (int d = 0; d < 64 && d < CELL * TC; ++d) {
+            const float hx = (float)((d + 0.5) / (double)CELL - 0.5);
+            int b = (int)hx;
+            if (!(hx >= 0.0f || (float)b == hx)) b -= 1;
+            const float w2 = hx - (float)b, w1 = (float)(1.0 - w2);
+            const float wlo = b >= 0 ? w1 : 0.0f, whi = b + 1 <= TC - 1 ? w2 : 0.0f;
+            w[d][0] = (b & 1) ? whi : wlo;
+            w[d][1] = (b & 1) ? wlo : whi;
+        }
+    }
+};
 __host__ __device__ inline size_t packed_lds_bytes(int C, int O, int S, int hist_slots, bool spec = false)
 {
     return al16(HP_ROWS_BYTES(O)) + packed_rowtab_bytes(S, spec) + hist_slots * al16(HP_HIST_BYTES(O, C * C)) + (HP_OVERLAY ? 0 : packed_scratch_bytes(C, O));
@@ -1094,7 +1124,7 @@ __host__ __device__ inline size_t packed_lds_bytes(int C, int O, int S, int hist
 // workgroup behind the waves' regions, read per row with a broadcast 8-byte LDS read straight into the register pair the
 // packed multiply-add takes (scalar loads of them cannot stay in SGPRs over an unrolled ROI: the compiler spilled them to
 // vector lanes and paid two v_readlane per row)
-__host__ __device__ inline size_t packed_wstab_bytes(int S) { return al16((size_t)S * 8); }
+__host__ __device__ inline size_t packed_wstab_bytes(int S) { return HP_ROWREG ? 0 : al16((size_t)S * 8); }
 __host__ __device__ inline size_t packed_wg_lds_bytes(int C, int O, int S, int hist_slots, bool spec)
 {
     return packed_lds_bytes(C, O, S, hist_slots, spec) * HP_WAVES + (spec ? packed_wstab_bytes(S) : 0);
@@ -1233,6 +1263,9 @@ __host__ __device__ constexpr int packed_band_of(int d, int cell)
 // patch cut by a pass boundary -- the consumer adds the two), there are no histogram slots in LDS and no normalisation phase in
 // this kernel: sdm_desc.hip normalises (hog.c:857-1062) with a lane per cell and either writes the feature rows or multiplies
 // the descriptors by the regressor while they are still on the chip.  `feat` is then the cells buffer, `ldf` unused.
+#ifndef HP_SIGNBITS
+#define HP_SIGNBITS 1               /* octant code from the sign bits of x', y', |x'| - |y'| (0: compares + selects) */
+#endif
 #ifndef HP_PAIRFOLD
 #define HP_PAIRFOLD 1               /* CELLS, 4 orientations: the last two bands of a pass in one set of matrix-core products */
 #endif
@@ -1291,7 +1324,6 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
     if (empty && lane == 0) atomicOr(status, SDM_DEV_ERR_EMPTY_PATCH);
     const int sw = empty ? 1 : 2 * h;
     const bool area2 = (sw == 2 * S);
-    const double scale = resize_scale(lv, h, sw);
     const uint8_t* img = imgs.base + imgs.offset[im];
     const int iw = imgs.w[im], ih = imgs.h[im], istride = imgs.stride[im];
     const __amdgpu_buffer_rsrc_t img_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)img, 0, ih * istride, 0x00020000);
@@ -1300,7 +1332,13 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
     int tab_s, tab_w;                 // unclamped source index floor((d + 0.5) scale - 0.5), 11-bit weights c0 | c1 << 16
     i32x4 row_ent;                    // vertical taps of row d as the row loop wants them: byte offsets of the two source rows
                                       // RELATIVE to the patch origin (rows clipped to the patch), the two weights << 12
-    {
+    if (CELLS && plan.taps && h < SDM_SCALE_TAB) {      // the level's table of taps by half-width (taps_table_kernel): two 16-byte loads
+        const i32x4* e = (const i32x4*)(plan.taps + ((size_t)(h > 0 ? h : 0) * 64 + lane) * 8);
+        const i32x4 e0 = e[0], e1 = e[1];
+        tab_s = e0.x; tab_w = e0.y;
+        row_ent = (i32x4){e0.z * istride, e0.w * istride, e1.x, e1.y};
+    } else {
+        const double scale = resize_scale(lv, h, sw);
         const ResizeTaps tp = resize_taps(lane < S ? lane : S - 1, scale, sw, area2);
         tab_s = tp.s0;
         tab_w = (tp.c0 & 0xffff) | (tp.c1 << 16);
@@ -1318,7 +1356,9 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
     wave_sync();
     // the per-row table: every lane reads entry y with ONE broadcast LDS read per row (no v_readlane, no scalar decoding);
     // entries S and S + 1 (the row loop issues its loads two rows ahead) repeat the last row
-    if (SPEC) {
+    if (HP_ROWREG) {
+        // (nothing in LDS: row y's entry is read out of lane min(y, S - 1) of row_ent with v_readlane)
+    } else if (SPEC) {
         // specialised layout: entry e = {offsets of row e + 2, weights of row e}: the row loop wants exactly that pair at row e, in
         // ONE 16-byte broadcast read; the offsets of rows 0 and 1 (issued before the loop) sit in the last two entries
         if (lane < S) {
@@ -1329,8 +1369,8 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
     } else if (lane < S + 2) rowtab[lane] = row_ent;
     // (every wave of the workgroup writes the same values; a wave's own LDS accesses execute in order, so it reads what it -- or
     //  a neighbour, identically -- wrote: no workgroup barrier)
-    if (SPEC && lane < S) wstab[lane] = (f32x2){lv.row_tab[lane][0], lv.row_tab[lane][1]};
-    if (!SPEC && S + 2 > 64 && lane < S + 2 - 64) {
+    if (!HP_ROWREG && SPEC && lane < S) wstab[lane] = (f32x2){lv.row_tab[lane][0], lv.row_tab[lane][1]};
+    if (!HP_ROWREG && !SPEC && S + 2 > 64 && lane < S + 2 - 64) {
         i32x4 last;
 #pragma unroll
         for (int k = 0; k < 4; ++k) last[k] = __builtin_amdgcn_readlane(row_ent[k], 63);
@@ -1401,18 +1441,32 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
 
         // ---- row loop ----------------------------------------------------------------------------------------------------------
         // the image loads of row y: the two source rows' byte offsets come from the row table (one broadcast 8-byte LDS read)
+        const i32x2 abl_rr = HP_ROWREG ? (i32x2){0, 0} : *(const i32x2*)&rowtab[0], abl_bb = HP_ROWREG ? (i32x2){1 << 22, 1 << 22} : *((const i32x2*)&rowtab[0] + 1);
+        const f32x2 abl_ws = (!HP_ROWREG && SPEC) ? wstab[0] : (f32x2){0.5f, 0.5f};
         auto issue_row = [&](int y, unsigned short& q0, unsigned short& q1) {
-            const i32x2 rr = *(const i32x2*)&rowtab[SPEC ? (y >= 2 ? y - 2 : y + S - 2) : y];
+            i32x2 rr;
+            if (HP_ABL == 7 || HP_ABL == 11) rr = abl_rr;
+            else if (HP_ROWREG) {      // byte offsets of row y's two source rows: scalar operands of the two address adds
+                const int yl = y < S ? y : S - 1;      // (generic instance: the two loads issued past the last row repeat it)
+                rr = (i32x2){__builtin_amdgcn_readlane(row_ent.x, yl), __builtin_amdgcn_readlane(row_ent.y, yl)};
+            } else rr = *(const i32x2*)&rowtab[SPEC ? (y >= 2 ? y - 2 : y + S - 2) : y];
             if (HP_ABL == 4) { q0 = (unsigned short)(vb + rr.x); q1 = (unsigned short)(vb + rr.y); return; }
+            // (the row offset stays in the VECTOR offset: the hardware range check that yields the black canvas covers voffset only)
             q0 = __builtin_amdgcn_raw_buffer_load_b16(img_rsrc, vb + rr.x, 0, 0);
             q1 = __builtin_amdgcn_raw_buffer_load_b16(img_rsrc, vb + rr.y, 0, 0);
         };
         auto horizontal = [&](unsigned short q0, unsigned short q1, int& H0, int& H1) {
+            if (HP_ABL == 8) { H0 = q0; H1 = q1; return; }
             H0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, spread_bytes(q0, spread_sel)), wpk2, 0u, false);
             H1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, spread_bytes(q1, spread_sel)), wpk2, 0u, false);
         };
         auto vertical = [&](int H0, int H1, int y) -> float {
-            const i32x2 bb = *((const i32x2*)&rowtab[y] + 1);      // the row's two weights << 12
+            if (HP_ABL == 8) return (float)(H0 + H1);
+            if (HP_ROWREG && HP_ABL != 7) {      // the row's two weights << 12 as scalar operands
+                const unsigned b0 = (unsigned)__builtin_amdgcn_readlane(row_ent.z, y), b1 = (unsigned)__builtin_amdgcn_readlane(row_ent.w, y);
+                return (float)(int)((mul_hi_u24(b0, (unsigned)H0 & ~15u) + mul_hi_u24(b1, (unsigned)H1 & ~15u) + 2u) >> 2);
+            }
+            const i32x2 bb = (HP_ABL == 7 || HP_ABL == 12) ? abl_bb : *((const i32x2*)&rowtab[y] + 1);      // the row's two weights << 12
             const int out = (int)((mul_hi_u24_vv((unsigned)bb.x, (unsigned)H0 & ~15u) + mul_hi_u24_vv((unsigned)bb.y, (unsigned)H1 & ~15u) + 2u) >> 2);
             return (float)out;
         };
@@ -1532,13 +1586,20 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
                 const float gx = from_right(rm1) - from_left(rm1);
                 const float gy = r0 - rm2;
                 const float g2 = gx * gx + gy * gy;
-                const float gm = (HP_RAWSQRT && RAW) ? __builtin_amdgcn_sqrtf(g2) : sqrt_int_up(g2);
+                const float gm = HP_ABL == 10 ? g2 : ((HP_RAWSQRT && RAW) ? __builtin_amdgcn_sqrtf(g2) : sqrt_int_up(g2));
                 bool b0 = false, b1 = false, b2 = false;
                 int bin_any = 0;
+                unsigned rot_ux = 0, rot_uy = 0, rot_uw = 0;
                 if constexpr (ROTB) {
                     typedef float v2 __attribute__((ext_vector_type(2)));
                     const v2 rr = __builtin_elementwise_fma((v2){gy, gy}, (v2){HP_ROT_S, HP_ROT_C}, (v2){gx, gx} * (v2){HP_ROT_C, -HP_ROT_S});
-                    b0 = (__builtin_fabsf(rr.x) - __builtin_fabsf(rr.y)) < 0.0f; b1 = rr.y < 0.0f; b2 = rr.x < 0.0f;      // row = b0 + 2 b1 + 4 b2
+                    const float rw = __builtin_fabsf(rr.x) - __builtin_fabsf(rr.y);
+                    b0 = rw < 0.0f; b1 = rr.y < 0.0f; b2 = rr.x < 0.0f;      // row = b0 + 2 b1 + 4 b2
+                    // (sign bits: -0.0f would differ from "< 0", but x', y' and |x'| - |y'| are never zero for a non-zero integer
+                    //  gradient, and a zero gradient adds 0 to whichever row it lands in -- verify_fast_bins_kernel checks the bits)
+                    // (scalar copies first: __builtin_bit_cast applied to the vector ELEMENT rr.y reads element 0 with this compiler)
+                    const float rx1 = rr.x, ry1 = rr.y;
+                    rot_ux = __builtin_bit_cast(unsigned, rx1); rot_uy = __builtin_bit_cast(unsigned, ry1); rot_uw = __builtin_bit_cast(unsigned, rw);
                 } else if constexpr (TO == 4) bin_sector4_bits(gx, gy, lv, b0, b1, b2);
                 else bin_sector<TO>(gx, gy, lv, TO, bin_any);      // (a zero gradient lands in bin 0 with magnitude 0)
                 if (HP_ABL == 3) { f32x2 dz = __builtin_elementwise_fma(pend_v, (f32x2){pend_g, pend_g}, qv); asm volatile("" :: "v"(dz), "v"(pend_p)); }
@@ -1546,7 +1607,9 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
                 else *pend_p = qv + pend_v;
                 const float* rt = lv.row_tab[yy];
                 f32x2 wsv;
-                if (SPEC) wsv = wstab[yy];
+                if (HP_ABL == 7 || HP_ABL == 12) wsv = abl_ws;
+                else if (SPEC && HP_ROWREG) { constexpr PackedWs<(CELL > 0 ? CELL : 1), TC> WS{}; wsv = (f32x2){WS.w[yy][0], WS.w[yy][1]}; }
+                else if (SPEC) wsv = wstab[yy];
                 else wsv = (f32x2){rt[0], rt[1]};
                 const float ws0 = wsv.x, ws1 = wsv.y;
                 // (specialised instance: yy and with it the band are constants after unrolling; prev_by folds away)
@@ -1555,7 +1618,12 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
                     if (prev_by >= 0) fold_band(prev_by);
                     prev_by = cby;
                 }
-                if constexpr (TO == 4)
+                if constexpr (HP_ABL == 9) pend_p = (lds_f32x2*)(size_t)cadr0;
+                else if constexpr (ROTB && HP_SIGNBITS) {
+                    // the octant code straight from the three sign bits (shifts and shift-ors instead of three compares and three selects)
+                    const unsigned code = ((((rot_ux >> 31) << 1) | (rot_uy >> 31)) << 1) | (rot_uw >> 31);
+                    pend_p = (lds_f32x2*)(size_t)(cadr0 + code * bin_stride);
+                } else if constexpr (TO == 4)
                     pend_p = (lds_f32x2*)(size_t)((b0 ? cadr1 : cadr0) + ((b1 ? 2u * bin_stride : 0u) + (b2 ? 4u * bin_stride : 0u)));
                 else
                     pend_p = (lds_f32x2*)(size_t)(cadr0 + (unsigned)bin_any * bin_stride);
@@ -1606,6 +1674,24 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
             if (!CELLS) wave_sync();
         }
     }
+}
+
+// cv::resize's taps depend on the level and on the patch half-width h only: one table per level, [h < SDM_SCALE_TAB][64 coordinates]
+// x {s0, c0 | c1 << 16, sy0, sy1, b0 << 12, b1 << 12, 0, 0}, built once per geometry by the device function the kernels used to call
+// per wave (so the bits are the ones they computed).  Round 4: ~80 vector instructions (double-precision coordinate arithmetic,
+// conversions, clamps) per wave leave the pixel kernel's set-up -- a third of its instructions outside the row loop at the small levels.
+__global__ void taps_table_kernel(HogLevelDev lv, int* __restrict__ table)
+{
+    const int h = blockIdx.x, d = threadIdx.x;
+    const int S = lv.S;
+    const bool empty = h <= 0;
+    const int sw = empty ? 1 : 2 * h;
+    const bool area2 = (sw == 2 * S);
+    const double scale = resize_scale(lv, h, sw);
+    const ResizeTaps tp = resize_taps(d < S ? d : S - 1, scale, sw, area2);
+    i32x4* e = (i32x4*)(table + ((size_t)h * 64 + d) * 8);
+    e[0] = (i32x4){tp.s0, (tp.c0 & 0xffff) | (tp.c1 << 16), tp.sy0, tp.sy1};
+    e[1] = (i32x4){tp.b0 << 12, tp.b1 << 12, 0, 0};
 }
 
 // count the (gx, gy) pairs for which the un-normalised arg-max disagrees with the reference arithmetic
@@ -1697,6 +1783,16 @@ bool sdm_hog_plan_build(const HogLevelDev& lv, int L, HogPlanHost& out)
     for (int d = 0; d < S; ++d) {      // the specialised instances compute the band of a row in integers: must equal the table
         int b; memcpy(&b, &lv.row_tab[d][2], sizeof(int));
         if (b != packed_band_of(d, lv.cell)) return false;
+    }
+    // ... and take the band-slot weights as compile-time constants: must equal the table bit for bit
+    {
+        bool same = true;
+        auto cmp = [&](const float (*w)[2]) { for (int d = 0; d < S; ++d) if (memcmp(&w[d][0], &lv.row_tab[d][0], 4) || memcmp(&w[d][1], &lv.row_tab[d][1], 4)) same = false; };
+        if (lv.cell == 11) { static const PackedWs<11, 5> W; cmp(W.w); }
+        else if (lv.cell == 10) { static const PackedWs<10, 5> W; cmp(W.w); }
+        else if (lv.cell == 8) { static const PackedWs<8, 5> W; cmp(W.w); }
+        else if (lv.cell == 6) { static const PackedWs<6, 5> W; cmp(W.w); }
+        if (!same) return false;
     }
     std::vector<std::vector<PlanLane>> tmp;
     // group size: fewest passes per sample; among equals at least two passes per wave (the per-group set-up is then shared),
@@ -1836,6 +1932,11 @@ static bool hog_fast_pair(const HogLevelDev& lv, int fast_bins, bool columns = f
     if (two > 160 * 1024) return false;
     const size_t wg_one = (160 * 1024) / one, wg_two = (160 * 1024) / two;
     return 2 * wg_two >= wg_one;
+}
+
+void sdm_launch_taps_table(const HogLevelDev& lv, int* table, hipStream_t stream)
+{
+    hipLaunchKernelGGL(taps_table_kernel, dim3(SDM_SCALE_TAB), dim3(64), 0, stream, lv, table);
 }
 
 void sdm_launch_verify_fast_bins(const HogLevelDev& lv, int* mismatches_dev, hipStream_t stream)

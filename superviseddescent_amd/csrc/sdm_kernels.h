@@ -76,6 +76,8 @@ bool sdm_hog_fast_supported(const HogLevelDev& lv);
 // mismatches_dev[0]: un-normalised arg-max (+ lean sqrt), mismatches_dev[1]: sector method (+ lean sqrt),
 // mismatches_dev[2]: gradients whose raw v_sqrt_f32 is neither the correctly rounded root nor one ulp below it
 void sdm_launch_verify_fast_bins(const HogLevelDev& lv, int* mismatches_dev, hipStream_t stream);
+// table[SDM_SCALE_TAB][64][8] ints: the level's cv::resize taps for every patch half-width below SDM_SCALE_TAB
+void sdm_launch_taps_table(const HogLevelDev& lv, int* table, hipStream_t stream);
 void sdm_launch_hog_fast(const ImageSetDev& imgs, const int* img_idx, const float* x, int N, int L,
                          const EyeIdxDev& eyes, const HogLevelDev& lv, float* feat, long long ldf, int* idx_out,
                          int* status, int acc_mode, int fast_bins, hipStream_t stream);
@@ -99,6 +101,7 @@ struct HogPlanDev {
     const unsigned* lane_tab;
     const float* wb;
     const int* pass_info;
+    const int* taps;           // [SDM_SCALE_TAB half-widths][64 coordinates][8] cv::resize taps of the level (sdm_launch_taps_table); null = computed per wave
 };
 #ifdef __cplusplus
 #include <vector>
