@@ -54,21 +54,41 @@ def gram_report(exec_flops, useful_flops, ms):
 
 
 def apply_report(flops_per_launch, feature_bytes_per_launch, ms):
-    """The regressor apply (LDS-staged kernel) forms every f32 product from three float16 piece products on the 16-bit matrix cores
-    (csrc/sdm_apply.hip: the features are split in the kernel, the regressor when it is loaded).  `achieved` = f32-equivalent
-    TFLOP/s, `peak` / `frac` = against the f32 matrix-core peak the reference's f32 GEMM would be priced on (the north-star's
-    'MFMA utilisation'); `hbm` = the feature matrix read once per launch against the HBM peak -- the bound that is left."""
+    """The UNFUSED regressor apply (LDS-staged GEMM over the feature matrix, csrc/sdm_apply.hip; training's update step and
+    SDM_DETECT_UNFUSED=1): every f32 product = three float16 piece products on the 16-bit matrix cores.  One fraction per pipe the
+    kernel runs on: `mfma_f16` = executed piece flops / f16 peak, `hbm` = the feature matrix read once."""
     if ms <= 0:
         return None
     tf = flops_per_launch / (ms * 1e-3) / 1e12
     gbs = feature_bytes_per_launch / (ms * 1e-3) / 1e9
-    return {"kernel": "apply_tiled_f16_kernel+apply_reduce_kernel", "bound": "hbm", "achieved": tf, "peak": MFMA_F32_PEAK_TF,
-            "unit": "TFLOP/s (f32-equivalent)", "frac": tf / MFMA_F32_PEAK_TF, "frac_of_f16_peak_over_3": tf / (MFMA_F16_PEAK_TF / 3.0),
-            "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                    "algorithmic_bytes_per_launch": feature_bytes_per_launch},
-            "avg_launch_ms": ms,
-            "note": "f32 operands as two float16 pieces, three piece products per product, float32 accumulation (SDM_APPLY_F32=1: the "
-                    "f32 matrix-core kernel of rounds 1-2: 0.044 ms = 71 TF at RCR-22, 0.544 ms = 111 TF at RCR-68)"}
+    return {"kernel": "apply_tiled_f16_kernel+apply_reduce_kernel", "bound": "hbm", "unit": "GB/s", "achieved": gbs, "peak": HBM_PEAK_GBS,
+            "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": feature_bytes_per_launch,
+            "mfma_f16": {"achieved": 3.0 * tf, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s (float16 piece products executed)",
+                         "frac": 3.0 * tf / MFMA_F16_PEAK_TF},
+            "f32_equivalent_tflops": tf, "avg_launch_ms": ms}
+
+
+def fused_apply_report(n_faces, L, P, M, cut_frac, ms):
+    """The fused descriptor + apply launch of detect (csrc/sdm_desc.hip: desc_kernel<FUSED> + apply_reduce_kernel): reads the raw
+    cells, normalises them, multiplies [faces x P] by the landmark's [P x 2L] regressor slice on the 16-bit matrix cores (three
+    float16 piece products per product) and writes partial[L][faces][2L]; the N x F feature matrix is never written.
+    `hbm`: cells read (+ the second part of patches cut by a pass boundary) + partial written and read back by the reduction.
+    `mfma_f16`: executed piece flops (K padded to 32, 2L to 16) against the f16 peak -- the launch is bound by neither: its
+    workgroups are latency chains (cells load -> ~270 vector instructions per patch pair -> barrier -> fragment loads -> 39 matrix
+    instructions), three resident per CU."""
+    if ms <= 0:
+        return None
+    Mp, KP = (M + 15) // 16 * 16, (P + 31) // 32 * 32
+    cells = n_faces * L * 2 * 8 * 25 * 4.0 / 2 * (1.0 + cut_frac)      # 800 B per part
+    partial = 2.0 * L * n_faces * Mp * 4.0
+    gbs = (cells + partial) / (ms * 1e-3) / 1e9
+    tf_exec = 3.0 * 2.0 * n_faces * L * KP * Mp / (ms * 1e-3) / 1e12
+    return {"kernel": "desc_kernel<FUSED>+apply_reduce_kernel", "bound": "latency", "avg_stage_ms": ms,
+            "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "bytes_per_launch": cells + partial},
+            "mfma_f16": {"achieved": tf_exec, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s (float16 piece products executed)",
+                         "frac": tf_exec / MFMA_F16_PEAK_TF},
+            "f32_equivalent_tflops": 2.0 * n_faces * (L * P + 1) * M / (ms * 1e-3) / 1e12,
+            "feature_matrix_bytes_not_written": n_faces * (L * P + 1) * 4.0}
 
 
 def parse():
@@ -258,14 +278,45 @@ def main():
     #      L*(2h)^2 ROI bytes + F*4 feature bytes written + 2L*4 landmark bytes read ------------------------
     ctx.enable_timing(False)
     ctx.set_x_device(d_x0.data_ptr(), args.batch)
-    hog_bytes = 0
+    hog_bytes = 0          # SURVEY.md 8d per level: patch bytes + feature row written + landmarks read (the unfused launch)
+    patch_bytes = 0        # ... the patch bytes alone
     for l in range(n_levels):
         ctx.hog_features(l)
         h = ctx.patch_indices()[:, 0].astype(np.int64)
+        patch_bytes += int((L * (2 * h) ** 2).sum())
         hog_bytes += int((L * (2 * h) ** 2).sum()) + args.batch * (ctx.feature_dim(l) * 4 + M * 4)
         ctx.apply(l)
     x_final = ctx.get_x()
     apply_flops = sum(2.0 * args.batch * ctx.feature_dim(l) * M for l in range(n_levels))
+    # sdm_detect_batch is fused (the descriptors are multiplied by the regressor on the chip): SURVEY 8d -- "if HOG is fused with the
+    # apply GEMM, the feature write term drops out and is reported as such".  Algorithmic bytes of a level = patch bytes + the
+    # landmark rows read and written.
+    fused_bytes = patch_bytes + n_levels * args.batch * 2 * M * 4
+    from superviseddescent_amd.engine import hog_plan
+
+    def cut_fraction(cell, nl=L):      # share of the landmarks whose patch is cut by a pass boundary of the packed launch (two parts of cells)
+        pl = hog_plan(5, cell, 4, nl)
+        if pl is None:
+            return 0.0
+        def cuts(passes):
+            seen = {}
+            for pt in passes:
+                for d in pl["lane_tab"][pt]:
+                    if (int(d) >> 17) & 1:
+                        seen.setdefault(int(d) & 0xff, set()).add(pt)
+            return sum(1 for v in seen.values() if len(v) > 1)
+        return (pl["n_main"] * cuts(range(pl["P"])) + cuts(range(pl["P"], pl["P"] + pl["Pt"]))) / float(nl)
+    cut_frac = float(np.mean([cut_fraction(p.cell_size) for p in params]))
+
+    # ---- the driver's view without the pre-roll: W warm-up steps straight after the host-side set-up, then K timed steps ------
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt_no_preroll = time.perf_counter() - t0
 
     # clock pre-roll: the host-side preparation above leaves the GPU idle for a few hundred milliseconds and its clocks drop; the W
     # warm-up steps of a short run (7 ms at W = 5) do not bring them back (measured: 1.443 ms per step at W = 5 / K = 20 against
@@ -294,6 +345,54 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # ---- input-inclusive rate: every batch's 256 x 256 images cross PCIe (pinned host memory -> HBM) and
+    # the uploads are double buffered against the cascade of the previous batch: two contexts, two streams, two device buffers --
+    # context A uploads + detects batch i while context B uploads batch i + 1.  The headline `value` stays the resident-input rate.
+    e2e = None
+    if rank == 0:
+        try:
+            h_images = torch.from_numpy(images[:args.batch]).pin_memory()
+            h_x0 = torch.from_numpy(x0).pin_memory()
+            streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+            bufs = [torch.empty_like(d_images[:args.batch]), torch.empty_like(d_images[:args.batch])]
+            dx = [torch.empty_like(d_x0), torch.empty_like(d_x0)]
+            ctxs = []
+            for k in range(2):
+                c2 = Context(local_rank, stream=streams[k].cuda_stream)
+                c2.set_model_geometry(L, re, le, params)
+                c2.set_images_device(bufs[k].data_ptr(), args.batch, 256, 256, 256)
+                c2.set_sample_image_index(None)
+                for l in range(n_levels):
+                    c2.set_regressor(l, regressors[l])
+                ctxs.append(c2)
+
+            def e2e_step(i):
+                k = i & 1
+                with torch.cuda.stream(streams[k]):
+                    bufs[k].copy_(h_images, non_blocking=True)
+                    dx[k].copy_(h_x0, non_blocking=True)
+                    ctxs[k].set_x_device(dx[k].data_ptr(), args.batch)
+                    ctxs[k].detect_batch(fetch=False)
+            n_e2e = max(4, min(args.steps, 24))
+            for i in range(4):
+                e2e_step(i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n_e2e):
+                e2e_step(i)
+            torch.cuda.synchronize()
+            dt_e2e = time.perf_counter() - t0
+            e2e = {"value": args.batch * n_e2e / dt_e2e, "unit": "faces/s", "ms_per_step": dt_e2e / n_e2e * 1e3, "steps": n_e2e,
+                   "h2d_bytes_per_step": int(h_images.numel() + h_x0.numel() * 4),
+                   "h2d_gb_per_s": (h_images.numel() + h_x0.numel() * 4) * n_e2e / dt_e2e / 1e9,
+                   "note": "pinned host images -> HBM per batch, double buffered over two contexts / streams; bound by the host link "
+                           "(PCIe Gen5 x16, 63 GB/s spec), not by the cascade"}
+            for c2 in ctxs:
+                c2.close()
+            del bufs, dx, h_images
+        except Exception as exc:      # (reported, never fatal for the headline)
+            e2e = {"error": repr(exc)}
+
     # ---- BASELINE config 4: RCR-68 detect on this rank's shard (65 536 faces over 8 GPUs = 8 192 per GPU), the cascade just
     # trained, inputs resident; same timing discipline as the headline (barrier + synchronize, max over ranks) ------------------
     if rcr68 is not None:
@@ -305,12 +404,13 @@ def main():
         ctx68.set_templates(None)
         ctx68.enable_timing(False)
         ctx68.set_x_device(d_x068.data_ptr(), nb68)
-        hog_bytes68 = 0
+        hog_bytes68 = 0      # 2L = 136 > 64: this cascade runs through the feature matrix (csrc/sdm_capi.hip fused_ok): SURVEY 8d's full byte count
         for l in range(n_levels):
             ctx68.hog_features(l)
             h = ctx68.patch_indices()[:, 0].astype(np.int64)
             hog_bytes68 += int((L68 * (2 * h) ** 2).sum()) + nb68 * (ctx68.feature_dim(l) * 4 + M68 * 4)
             ctx68.apply(l)
+        x68_stepwise = ctx68.get_x()
         steps68 = max(3, min(args.steps, 20))
 
         def step68():
@@ -348,7 +448,10 @@ def main():
             "hog": {"bound": "hbm", "achieved": gbs68, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs68 / HBM_PEAK_GBS,
                     "avg_launch_ms": hog68_ms, "algorithmic_bytes_per_launch": hog_bytes68 / n_levels},
             "apply_gemm": apply_report(2.0 * nb68 * F68 * M68, 4.0 * nb68 * F68, app68_ms),
+            "path": "feature matrix + apply GEMM (the fused descriptor + apply launch serves 2L <= 64: at 2L = 136 its workgroups re-read "
+                    "230 KB of regressor per 32 faces from L2 -- measured 0.53 against 0.25 ms per level)",
         }
+        x68_fused = ctx68.get_x()      # (the last timed step's landmarks)
 
     if rank != 0:
         if use_dist:
@@ -360,9 +463,8 @@ def main():
     hog_ms, hog_n = timing["hog"]
     app_ms, app_n = timing["apply"]
     hog_avg_ms = hog_ms / max(hog_n, 1)
-    bytes_per_launch = hog_bytes / n_levels
+    bytes_per_launch = fused_bytes / n_levels          # patch bytes + landmark rows: the feature write dropped out (fused)
     achieved_gbs = bytes_per_launch / (hog_avg_ms * 1e-3) / 1e9 if hog_avg_ms > 0 else 0.0
-    apply_tf = apply_flops / n_levels / (app_ms / max(app_n, 1) * 1e-3) / 1e12 if app_ms > 0 else 0.0
 
     # HBM bytes and instruction counts per launch from the PMC passes (rocprofv3 --pmc cannot run inside this process): the
     # committed measurement of this same command (scripts/profile_bench.sh), valid for the batch it was taken at
@@ -378,15 +480,20 @@ def main():
             # waves; x 4 / (1024 SIMDs x launch cycles) = the fraction of SIMD cycles with a vector instruction executing
             simd_cycles = 256 * 4 * 2.4e9 * hog_avg_ms * 1e-3
             valu_issue = {"valu_insts_per_launch": float(ent["SQ_INSTS_VALU"]), "salu_insts_per_launch": float(ent.get("SQ_INSTS_SALU", 0.0)),
+                          "mfma_f32_busy_frac": (float(ent["SQ_VALU_MFMA_BUSY_CYCLES"]) / simd_cycles) if "SQ_VALU_MFMA_BUSY_CYCLES" in ent else None,
+                          "lds_busy_frac": (float(ent["SQ_LDS_IDX_ACTIVE"]) / (256 * 2.4e9 * hog_avg_ms * 1e-3)) if "SQ_LDS_IDX_ACTIVE" in ent else None,
                           "simd_cycles_per_valu_inst": simd_cycles / float(ent["SQ_INSTS_VALU"]),
                           "valu_insts_per_patch": float(ent["SQ_INSTS_VALU"]) / (args.batch * L),
                           "frac": (4.0 * float(ent["SQ_ACTIVE_INST_VALU"]) / simd_cycles) if "SQ_ACTIVE_INST_VALU" in ent else None,
                           "lds_bank_conflict_ratio": (float(ent["SQ_LDS_BANK_CONFLICT"]) / float(ent["SQ_LDS_IDX_ACTIVE"]))
                           if "SQ_LDS_IDX_ACTIVE" in ent and ent["SQ_LDS_IDX_ACTIVE"] else None,
-                          "note": "frac = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x 2.4 GHz x this run's average launch time), counters from the "
-                                  "committed profile of the same command; round 3 measured that the launch time does not follow the "
-                                  "instruction count (-8 % vector, -33 % scalar instructions: +-0 % time, profiles/r03_hog_experiments.txt), "
-                                  "so this is an occupancy figure, not a bound"}
+                          "note": "compute-side picture of the launch, from the committed PMC passes of this command: frac = 4 x "
+                                  "SQ_ACTIVE_INST_VALU / (1024 SIMDs x 2.4 GHz x this run's average launch time) = share of SIMD cycles with a "
+                                  "vector instruction executing; mfma_f32_busy_frac = the band folds' f32 matrix instructions (they slow the "
+                                  "vector pipe of the same SIMD 2.5x while they run: profiles/r04_ubench_mfma_valu_overlap.txt); lds_busy_frac = "
+                                  "LDS array cycles.  The round-4 ablations (profiles/r04_hog_ablations.txt) price the phases: image-load path "
+                                  "24 %, band folds 20 %, per-row LDS table reads 11 %, binning 8 %, ALL resize arithmetic 4 % -- the launch is "
+                                  "bound by dependent memory / LDS round trips per pixel row, not by instruction count"}
     except (OSError, KeyError, ValueError, ZeroDivisionError):
         pass
 
@@ -426,14 +533,21 @@ def main():
             "traffic_source": traffic_src,
             "valu_issue": valu_issue,
             "algorithmic_bytes_per_launch": bytes_per_launch,
-            "note": "not HBM bound (traffic = 1.1 x the algorithmic bytes) and not instruction-issue bound either: ~33 vector instructions "
-                    "per pixel row (bit-exact integer resize, sqrt, reference binning, LDS column sums), vector units ~70 % busy; what "
-                    "removing each phase buys is in profiles/r03_hog_experiments.txt",
+            "feature_write": "dropped: sdm_detect_batch multiplies the descriptors by the regressor on the chip (csrc/sdm_desc.hip); the "
+                             "launch writes raw cell histograms (800 B per patch, %.1f MB per launch) for that kernel instead of the "
+                             "%.1f MB feature matrix -- SURVEY.md 8d: 'if fused the feature write term drops out'"
+                             % (args.batch * L * 800.0 * (1.0 + cut_frac) / 1e6, sum(4.0 * args.batch * ctx.feature_dim(l) for l in range(n_levels)) / n_levels / 1e6),
+            "achieved_with_round3_byte_count": (hog_bytes / n_levels) / (hog_avg_ms * 1e-3) / 1e9 if hog_avg_ms > 0 else 0.0,
+            "note": "pixel kernel of the split launch (crop + cv::resize + gradient + orientation binning + column sums + band folds -> raw "
+                    "cells).  Not HBM bound: it reads every patch byte once (traffic ~1.1 x algorithmic) at a rate set by per-pixel-row "
+                    "dependent work; see valu_issue for the compute-side numbers",
             "avg_launch_ms": hog_avg_ms,
             "launches": hog_n,
         },
-        "apply_gemm": apply_report(apply_flops / n_levels, sum(4.0 * args.batch * ctx.feature_dim(l) for l in range(n_levels)) / n_levels,
-                                   app_ms / max(app_n, 1)),
+        "fused_apply": fused_apply_report(args.batch, L, 400, M, cut_frac, app_ms / max(app_n, 1)),
+        "no_preroll": {"value": args.batch * args.steps / dt_no_preroll, "unit": "faces/s", "ms_per_step": dt_no_preroll / args.steps * 1e3,
+                       "note": "the same K steps timed after only the W warm-up steps (GPU clocks still ramping after the host-side set-up); rank 0"},
+        "e2e_with_h2d": e2e,
         "train": {
             "metric": "train sec/cascade (RCR-22, MatrixNorm 1.5, bias unregularised)",
             "rows_total": int(n_train_global),
@@ -526,11 +640,96 @@ def main():
         par = compare(*gpu_cascade(_lib.SDM_HOG_COLUMNS))
         par_exact = compare(*gpu_cascade(_lib.SDM_HOG_EXACT_ORDER))
         ctx.set_hog_mode(_lib.SDM_HOG_COLUMNS)
+        # the MEASURED path: sdm_detect_batch (fused descriptor + apply launches, no feature matrix) on the same sample
+        ctx.set_images_device(d_images.data_ptr(), ns, 256, 256, 256)
+        ctx.set_x(x0[:ns])
+        x_fused = ctx.detect_batch(fetch=True)
+
+        def compare_x(xg, xo):
+            d = (xg - xo).astype(np.float64)
+            per_face = np.linalg.norm(d, axis=1) / np.linalg.norm(xo.astype(np.float64), axis=1)
+            return {"rel_l2_landmarks_vs_oracle": float(np.linalg.norm(d) / np.linalg.norm(xo.astype(np.float64))),
+                    "max_per_face_rel_error": float(per_face.max()), "faces_above_1e-4": int((per_face > 1e-4).sum())}
+        # the oracle with cv::gemm's double accumulation (SURVEY a-6; oracle/sdm_oracle.py LinearRegressor.accumulate_double)
+        oregs64 = []
+        for l in range(n_levels):
+            r = orc.LinearRegressor(accumulate_double=True)
+            r.x = regressors[l]
+            oregs64.append(r)
+        ohog64 = orc.HogTransform(images[:ns], oparams, re, le, None, n_threads=cores)
+        ohog64.keep_idx = True
+        ox64 = orc.SupervisedDescentOptimiser(oregs64, orc.InterEyeDistanceNormalisation(re, le)).test(x0[:ns], None, ohog64)
+        idx_keep = ohog.idx_per_level
+        ohog.idx_per_level = ohog64.idx_per_level
+        ox_keep, ox = ox, ox64
+        par64 = compare(*gpu_cascade(_lib.SDM_HOG_COLUMNS))
+        ox, ohog.idx_per_level = ox_keep, idx_keep
         out["parity"] = dict(par, faces_checked=ns, tolerance=1e-4, levels=n_levels,
                              exact_order_mode=par_exact,
+                             detect_batch_fused=dict(compare_x(x_fused, ox), vs_double_accumulating_oracle=compare_x(x_fused, ox64),
+                                                     note="sdm_detect_batch as timed (descriptors x regressor slices on the chip)"),
+                             vs_double_accumulating_oracle=par64,
                              note="free-running 4-level cascade; a face 'differs in integer decisions' when a cvRound'ed patch centre or the "
                                   "patch half-width at any level differs from the oracle's (a landmark within float rounding of x.5): from "
-                                  "there on it is a different, equally valid trajectory")
+                                  "there on it is a different, equally valid trajectory.  The oracle's predict accumulates in float32 (BLAS "
+                                  "sgemm) by default; vs_double_accumulating_oracle = the same comparison against cv::gemm's double accumulation")
+
+        # ---- RCR-68 (BASELINE configs 4 / 5): the detect shard's first faces against the oracle, regressors as trained on the GPU ----
+        if rcr68 is not None:
+            n68 = min(512, nb68)
+            re68, le68 = ibug.eye_indices(ids68)
+            oregs68 = []
+            for r68_ in sdo68.regressors:
+                r = orc.LinearRegressor()
+                r.x = r68_.x
+                oregs68.append(r)
+            ohog68 = orc.HogTransform(images[:n68], oparams, re68, le68, None, n_threads=cores)
+            t0 = time.perf_counter()
+            ox68 = orc.SupervisedDescentOptimiser(oregs68, orc.InterEyeDistanceNormalisation(re68, le68)).test(x068[:n68], None, ohog68)
+            cpu68_dt = time.perf_counter() - t0
+            out["rcr68_detect_shard"]["parity"] = dict(compare_x(x68_fused[:n68], ox68), faces_checked=n68, tolerance=1e-4,
+                                                       stepwise_unfused=compare_x(x68_stepwise[:n68], ox68),
+                                                       cpu_oracle_faces_per_s=n68 / cpu68_dt, cores=cores,
+                                                       note="free-running 4-level RCR-68 cascade (F = 27 201, M = 136), sdm_detect_batch of the "
+                                                            "timed shard against the CPU oracle on its first faces")
+
+        # ---- CPU training baseline (sub-sampled, per stage as verbose_solver.hpp:66-97 prints): level 0 of the RCR-22
+        # cascade on the first 2 000 training rows, the oracle's stages timed on this box's cores, the GPU on the same rows ----------
+        nt = min(2000, int(txs.shape[0]))
+        n_timg = int(tidx[:nt].max()) + 1
+        t_hog = orc.HogTransform(timg[:n_timg], oparams[:1], re, le, tidx[:nt], n_threads=cores)
+        t0 = time.perf_counter(); A = np.asarray(t_hog(tx0[:nt], 0), np.float32); cpu_hog = time.perf_counter() - t0
+        bvec = ((tx0[:nt] - txs[:nt]) * orc.InterEyeDistanceNormalisation(re, le)(tx0[:nt])).astype(np.float32)
+        t0 = time.perf_counter(); AtA = (A.T @ A).astype(np.float32); Atb = (A.T @ bvec).astype(np.float32); cpu_gram = time.perf_counter() - t0
+        oreg = orc.Regulariser(orc.Regulariser.MATRIX_NORM, 1.5, False)
+        t0 = time.perf_counter()
+        lam = oreg.get_lambda(AtA, nt); dg = np.full(AtA.shape[0], lam, np.float32); dg[-1] = 0.0; AtA[np.diag_indices_from(AtA)] += dg
+        cpu_reg = time.perf_counter() - t0
+        from scipy.linalg import lu_factor, lu_solve
+        t0 = time.perf_counter(); lu = lu_factor(AtA, check_finite=False); cpu_lu = time.perf_counter() - t0
+        t0 = time.perf_counter(); Rcpu = lu_solve(lu, Atb, check_finite=False).astype(np.float32); cpu_sub = time.perf_counter() - t0
+        t0 = time.perf_counter(); _ = A @ Rcpu; cpu_apply = time.perf_counter() - t0
+        sdo_s = SupervisedDescentOptimiser([LinearRegressor(reg())], device=local_rank, stream=stream)
+        hog_s = HogTransform(timg[:n_timg], params[:1], ids, ibug.RIGHT_EYE_IDS, ibug.LEFT_EYE_IDS, tidx[:nt])
+        for rep in range(2):
+            sdo_s.ctx.enable_timing(True); sdo_s.ctx.get_timing(reset=True)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            sdo_s.train(txs[:nt], tx0[:nt], None, hog_s)
+            torch.cuda.synchronize(); gpu_level = time.perf_counter() - t0
+            tg = sdo_s.ctx.get_timing(reset=True)
+        Rg = sdo_s.regressors[0].x
+        out["cpu_baseline_train"] = {
+            "workload": "level 0 of the RCR-22 training cascade on the first %d training rows (sub-sampled: the full 100 000-row A^T A is "
+                        "1.5 x 10^13 flop per level), MatrixNorm 1.5, bias unregularised" % nt,
+            "cores": cores, "kind": "reference-hog" if ref_hog else "port", "unit": "ms",
+            "cpu_stage_ms": {"hog_features": cpu_hog * 1e3, "AtA_Atb (numpy sgemm)": cpu_gram * 1e3, "regulariser": cpu_reg * 1e3,
+                             "partial-pivot LU (scipy sgetrf)": cpu_lu * 1e3, "substitution": cpu_sub * 1e3, "apply": cpu_apply * 1e3},
+            "cpu_total_ms": (cpu_hog + cpu_gram + cpu_reg + cpu_lu + cpu_sub + cpu_apply) * 1e3,
+            "gpu_same_rows_stage_ms": {k: v[0] for k, v in tg.items() if v[1] > 0},
+            "gpu_same_rows_wall_ms": gpu_level * 1e3,
+            "regressor_rel_l2_gpu_vs_cpu": float(np.linalg.norm(Rg - Rcpu) / np.linalg.norm(Rcpu)),
+            "note": "CPU stages as the reference's VerbosePartialPivLUSolver prints them (verbose_solver.hpp:66-97): Eigen's f32 GEMM / "
+                    "PartialPivLU restated with numpy sgemm / LAPACK sgetrf on all cores; never extrapolated to the full row count"}
     print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

@@ -154,6 +154,10 @@ int sdm_apply(sdm_ctx* ctx, int level);
 /* All levels: SupervisedDescentOptimiser::test (superviseddescent.hpp:262-306) with an empty
  * template, = rcr::detection_model::detect (model.hpp:132-157) for a batch.  x_host may be NULL. */
 int sdm_detect_batch(sdm_ctx* ctx, float* x_host);
+/* One cascade level of sdm_detect_batch on the current x (the loop body of SupervisedDescentOptimiser::test,
+ * superviseddescent.hpp:269-301: projection -> predict -> update): x_{k+1} replaces x_k on the device.  Same launches as
+ * sdm_detect_batch, so a level-by-level run (callbacks between the levels, superviseddescent.hpp:303) gives the same bits. */
+int sdm_detect_level(sdm_ctx* ctx, int level);
 
 /* Known-template mode (superviseddescent.hpp:195-197, 287-289): when `templates` (n_samples x
  * feature_dim, row n = the known y of sample n) is set, every sdm_hog_features call stores features - templates, which
@@ -266,6 +270,18 @@ int sdm_debug_gram_fallbacks(sdm_ctx* ctx);
  * superviseddescent_amd/csrc/sdm_kernels.h (HogPlanDev); passes = P + Pt <= max_passes. */
 int sdm_debug_hog_plan(int num_cells, int cell_size, int num_bins, int num_landmarks, int* info5, unsigned* lane_tab,
                        float* wb, int* pass_info, int max_passes);
+/* cut[num_landmarks]: 1 where the landmark's patch is cut by a pass boundary of that plan (its raw cell histograms arrive in two
+ * parts, csrc/sdm_hog_fast.hip CELLS form); host only.  Returns SDM_ERR_INVALID when the geometry has no packed instance. */
+int sdm_debug_hog_plan_cut(int num_cells, int cell_size, int num_bins, int num_landmarks, int* cut);
+/* Round 4, A/B and tests: which launches the packed default mode uses.  fused != 0 (default; env SDM_DETECT_UNFUSED=1 turns it
+ * off): sdm_detect_batch runs  pixel kernel -> raw cell histograms -> descriptors x regressor slices on the 16-bit matrix cores
+ * (csrc/sdm_desc.hip) -> landmark update, and never writes the N x F feature matrix (LinearRegressor::predict,
+ * regressors.hpp:377-381, fused behind HogTransform::operator(), adaptive_vlhog.hpp:109-185) when 2L <= 64 (wider outputs stay on the
+ * feature-matrix path, which is faster there; fused == 2 fuses them too).  split_store != 0 (default 0; env
+ * SDM_HOG_SPLIT_STORE=1): sdm_hog_features / training produce the feature rows through the same raw cells + the store form of
+ * that kernel instead of normalising inside the pixel kernel (identical arithmetic, last-bit differences from the summation order
+ * of the four clamped block terms). */
+int sdm_debug_set_detect_path(sdm_ctx* ctx, int fused, int split_store);
 
 #ifdef __cplusplus
 }

@@ -318,15 +318,22 @@ def _unblocked_lu_solve_f32(A: np.ndarray, B: np.ndarray) -> np.ndarray:
 class LinearRegressor:
     """regressors.hpp:318-400."""
 
-    def __init__(self, regulariser: Optional[Regulariser] = None):
+    def __init__(self, regulariser: Optional[Regulariser] = None, accumulate_double: bool = False):
         self.x: Optional[np.ndarray] = None
         self.regulariser = regulariser or Regulariser()
+        # `values * x` is cv::gemm on CV_32F (regressors.hpp:377-381).  OpenCV's generic f32 kernel is known to accumulate the
+        # dot products in double and round the result to float (SURVEY.md row a-6; OpenCV itself is absent from the reference
+        # checkout, so this cannot be pinned here): accumulate_double=True restates that; False (the default the gtest goldens of
+        # tests/test_oracle_regressors.py were pinned with) accumulates in float32 as a BLAS sgemm does.  Parity reports use both.
+        self.accumulate_double = accumulate_double
 
     def learn(self, data: np.ndarray, labels: np.ndarray) -> bool:
         self.x = partial_piv_lu_solve(data, labels, self.regulariser)   # :345-350
         return True
 
     def predict(self, values: np.ndarray) -> np.ndarray:
+        if self.accumulate_double:
+            return (np.asarray(values, np.float64) @ self.x.astype(np.float64)).astype(np.float32)
         return (np.asarray(values, np.float32) @ self.x).astype(np.float32)  # :377-381
 
     def test(self, data: np.ndarray, labels: np.ndarray) -> float:

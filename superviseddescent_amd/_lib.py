@@ -25,11 +25,11 @@ EXPORTED = [
     "sdm_set_model_geometry", "sdm_set_hog_mode", "sdm_get_hog_info", "sdm_feature_dim", "sdm_upload_images_u8", "sdm_set_images_device",
     "sdm_set_sample_image_index", "sdm_set_x", "sdm_get_x", "sdm_set_x_device", "sdm_get_x_device",
     "sdm_hog_features", "sdm_get_patch_indices", "sdm_set_regressor", "sdm_get_regressor", "sdm_apply",
-    "sdm_detect_batch", "sdm_set_targets", "sdm_gram_rhs", "sdm_set_allreduce", "sdm_set_allreduce_rccl", "sdm_allreduce_gram_rhs",
+    "sdm_detect_batch", "sdm_detect_level", "sdm_set_targets", "sdm_gram_rhs", "sdm_set_allreduce", "sdm_set_allreduce_rccl", "sdm_allreduce_gram_rhs",
     "sdm_set_solve_sharding", "sdm_set_solve_sharding_rccl", "sdm_set_reduce_scatter", "sdm_set_reduce_scatter_rccl",
     "sdm_set_templates", "sdm_init_from_boxes", "sdm_normalised_errors", "sdm_solve", "sdm_solve_normal_equations", "sdm_train_level", "sdm_gram_device_ptr", "sdm_x_device_ptr", "sdm_features_device_ptr",
     "sdm_enable_timing", "sdm_get_timing", "sdm_debug_patch", "sdm_debug_hog_profile", "sdm_debug_gradient_table",
-    "sdm_debug_set_hog_packing", "sdm_debug_gram_fallbacks", "sdm_debug_hog_plan", "sdm_upload_images_bgr_u8", "sdm_debug_download_images",
+    "sdm_debug_set_hog_packing", "sdm_debug_gram_fallbacks", "sdm_debug_hog_plan", "sdm_debug_hog_plan_cut", "sdm_debug_set_detect_path", "sdm_upload_images_bgr_u8", "sdm_debug_download_images",
 ]
 
 
@@ -119,6 +119,7 @@ def lib() -> ctypes.CDLL:
             "sdm_get_regressor": [c_void_p, c_int, c_float_p],
             "sdm_apply": [c_void_p, c_int],
             "sdm_detect_batch": [c_void_p, c_float_p],
+            "sdm_detect_level": [c_void_p, c_int],
             "sdm_set_targets": [c_void_p, c_float_p, c_int],
             "sdm_gram_rhs": [c_void_p, c_int],
             "sdm_set_allreduce": [c_void_p, ALLREDUCE_FN, c_void_p, c_int],
@@ -147,6 +148,8 @@ def lib() -> ctypes.CDLL:
             "sdm_debug_set_hog_packing": [c_void_p, c_int],
             "sdm_debug_gram_fallbacks": [c_void_p],
             "sdm_debug_hog_plan": [c_int, c_int, c_int, c_int, c_int_p, c_void_p, c_void_p, c_void_p, c_int],
+            "sdm_debug_hog_plan_cut": [c_int, c_int, c_int, c_int, c_int_p],
+            "sdm_debug_set_detect_path": [c_void_p, c_int, c_int],
         }
         for name, args in sigs.items():
             fn = getattr(L, name)

@@ -92,6 +92,7 @@ struct sdm_ctx {
     // rows is HBM-bound on its own (55 us per 4 096 x 22 patches) and hides behind the pixel work there; measured 5 % slower split.
     bool split_store = false;       // SDM_HOG_SPLIT_STORE=1: feature rows through cells + sdm_desc.hip's store form (A/B, tests)
     bool fuse_apply = true;         // SDM_DETECT_UNFUSED=1: sdm_detect_batch through the feature matrix + apply GEMM (A/B)
+    bool fuse_wide = false;         // sdm_debug_set_detect_path(fused = 2): fuse also when 2L > 64 (tests of the wide launch)
     bool packing = true;            // sdm_debug_set_hog_packing / SDM_HOG_NO_PACK=1: run the one-patch-per-wave kernel instead
     int hog_mode = SDM_HOG_COLUMNS;
     int Fmax = 0;
@@ -121,6 +122,7 @@ struct sdm_ctx {
     DevBuf<float> feat;
     int feat_level = -1;
     DevBuf<int> patch_idx;
+    bool have_patch_idx = false;    // the last HOG launch (feature rows or fused cascade level) left its integer decisions in patch_idx
     DevBuf<int> status;
     DevBuf<float> partial;
 
@@ -353,6 +355,7 @@ int do_hog(sdm_ctx* c, int level)
     }
     HIP_TRY(hipGetLastError());
     c->feat_level = level;
+    c->have_patch_idx = true;
     return SDM_OK;
 }
 
@@ -393,39 +396,52 @@ int do_apply(sdm_ctx* c, int level)
 // one cascade level of sdm_detect_batch without the feature matrix: cells -> (descriptors x regressor slices) -> landmark update
 bool fused_ok(const sdm_ctx* c, int level)
 {
-    return c->fuse_apply && split_ok(c, level) && c->have_R[level] && c->Rd[level].p && c->Rp[level].p && c->tmpl_N == 0;
+    // Wide outputs stay on the feature-matrix path: a fused workgroup (32 samples x one landmark) reads the landmark's whole P x 2L
+    // slice of the regressor from L2 -- 77 KB at 2L = 44, 230 KB at 2L = 136, where that traffic (4 GB per level at 8 192 samples)
+    // makes the launch slower than writing the rows and running the GEMM (RCR-68 detect: 0.53 against 0.25 ms per level;
+    // SDM_DETECT_FUSE_WIDE=1 fuses anyway)
+    static const bool fuse_wide = getenv("SDM_DETECT_FUSE_WIDE") && getenv("SDM_DETECT_FUSE_WIDE")[0] == '1';
+    return c->fuse_apply && (Mp_of(c->M) <= 64 || fuse_wide || c->fuse_wide) && split_ok(c, level) && c->have_R[level] && c->Rd[level].p &&
+           c->Rp[level].p && c->tmpl_N == 0;
 }
-// sdm_detect_batch with every level fused: cells -> (descriptors x regressor slices) -> landmark update; the feature matrix is not
+// A cascade level of detect, fused: cells -> (descriptors x regressor slices) -> landmark update; the feature matrix is not
 // written.  (Measured and dropped: the batch as two blocks of rows on two queues, so that the short descriptor / update launches of
 // one block overlap the pixel kernel of the other -- 1.352 against 1.354 ms: the pixel kernel's workgroups hold every register
 // and LDS slot of a CU, the 51 KB descriptor workgroups of the other queue are admitted only when it drains.)
-int detect_fused(sdm_ctx* c)
+int detect_level_fused(sdm_ctx* c, int l)
 {
-    const int nl = (int)c->levels.size();
-    for (int l = 0; l < nl; ++l) { const int rci = hog_checks(c, l); if (rci) return rci; }
+    { const int rci = hog_checks(c, l); if (rci) return rci; }
     const int Mp = Mp_of(c->M);
     int rc;
     size_t cells_max = 0;
-    for (int l = 0; l < nl; ++l) { const size_t n = sdm_cells_floats(c->levels[l], c->N, c->L); if (n > cells_max) cells_max = n; }
+    for (size_t q = 0; q < c->levels.size(); ++q) { const size_t n = sdm_cells_floats(c->levels[q], c->N, c->L); if (n > cells_max) cells_max = n; }
     if ((rc = c->cells.ensure(cells_max)) || (rc = c->partial.ensure((size_t)c->L * c->N * Mp))) return rc;
-    for (int l = 0; l < nl; ++l) {
-        const HogLevelDev& lv = c->levels[l];
-        {
-            Timer t(c, SDM_T_HOG);
-            sdm_launch_hog_cells(image_set(c), c->idx_identity ? nullptr : c->img_idx.p, c->x[c->cur].p, c->N, c->L, c->eyes, lv,
-                                 c->plans[l].dev, c->cells.p, c->patch_idx.p, c->status.p, c->stream);
-        }
-        {
-            Timer t(c, SDM_T_APPLY);
-            sdm_launch_desc_apply(lv, c->cells.p, c->plans[l].cut.p, c->N, c->L, c->M, c->Rd[l].p, c->Rmax.p + (size_t)l * Mp,
-                                  c->Rt[l].p, c->ldf, c->partial.p, c->stream);
-            sdm_launch_apply_reduce(c->partial.p, c->L, c->N, c->M, c->x[c->cur].p, c->x[c->cur ^ 1].p, c->L, c->eyes, c->stream);
-        }
-        HIP_TRY(hipGetLastError());
-        c->cur ^= 1;
+    const HogLevelDev& lv = c->levels[l];
+    {
+        Timer t(c, SDM_T_HOG);
+        sdm_launch_hog_cells(image_set(c), c->idx_identity ? nullptr : c->img_idx.p, c->x[c->cur].p, c->N, c->L, c->eyes, lv,
+                             c->plans[l].dev, c->cells.p, c->patch_idx.p, c->status.p, c->stream);
     }
+    {
+        Timer t(c, SDM_T_APPLY);
+        sdm_launch_desc_apply(lv, c->cells.p, c->plans[l].cut.p, c->N, c->L, c->M, c->Rd[l].p, c->Rmax.p + (size_t)l * Mp,
+                              c->Rt[l].p, c->ldf, c->partial.p, c->stream);
+        sdm_launch_apply_reduce(c->partial.p, c->L, c->N, c->M, c->x[c->cur].p, c->x[c->cur ^ 1].p, c->L, c->eyes, c->stream);
+    }
+    HIP_TRY(hipGetLastError());
+    c->cur ^= 1;
     c->feat_level = -1;          // (the feature rows were not produced)
+    c->have_patch_idx = true;    // (this level's patch half-widths and centres)
     return SDM_OK;
+}
+
+// one cascade level of detect: fused when the level qualifies, else feature rows + apply GEMM
+int detect_level(sdm_ctx* c, int l)
+{
+    if (fused_ok(c, l)) return detect_level_fused(c, l);
+    int rc = do_hog(c, l);
+    if (!rc) rc = do_apply(c, l);
+    return rc;
 }
 
 }  // namespace
@@ -664,7 +680,7 @@ int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int*
     c->Rd.assign(n_levels, DevBuf<unsigned char>());
     c->cells.release();
     c->have_R.assign(n_levels, false);
-    c->feat.release(); c->feat_level = -1;
+    c->feat.release(); c->feat_level = -1; c->have_patch_idx = false;
     c->N = 0; c->have_targets = false; c->g_level = -1;
     return SDM_OK;
 }
@@ -831,7 +847,7 @@ static int set_x_common(sdm_ctx* c, const float* x, int N, hipMemcpyKind kind)
     HIP_TRY(hipSetDevice(c->device));
     int rc = ensure_sample_buffers(c, N);
     if (rc) return rc;
-    if (N != c->N) { c->have_targets = false; c->feat_level = -1; }
+    if (N != c->N) { c->have_targets = false; c->feat_level = -1; c->have_patch_idx = false; }
     c->N = N; c->cur = 0;
     HIP_TRY(hipMemcpyAsync(c->x[0].p, x, (size_t)N * c->M * sizeof(float), kind, c->stream));
     if (kind == hipMemcpyHostToDevice) HIP_TRY(hipStreamSynchronize(c->stream));
@@ -870,7 +886,7 @@ int sdm_init_from_boxes(sdm_ctx* c, const float* mean, const int* boxes, const f
     HIP_TRY(hipMemcpyAsync(d_box.p, boxes, (size_t)4 * N * sizeof(int), hipMemcpyHostToDevice, c->stream));
     if (perturbations)
         HIP_TRY(hipMemcpyAsync(d_pert.p, perturbations, (size_t)3 * N * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    if (N != c->N) { c->have_targets = false; c->feat_level = -1; }
+    if (N != c->N) { c->have_targets = false; c->feat_level = -1; c->have_patch_idx = false; }
     c->N = N; c->cur = 0;
     sdm_launch_init_boxes(d_mean.p, d_box.p, perturbations ? d_pert.p : nullptr, N, c->L, c->x[0].p, c->stream);
     HIP_TRY(hipGetLastError());
@@ -936,7 +952,7 @@ int sdm_hog_features(sdm_ctx* c, int level, float* feat_host)
 
 int sdm_get_patch_indices(sdm_ctx* c, int* idx)
 {
-    if (!c || !idx || c->N <= 0 || c->feat_level < 0) return fail(SDM_ERR_INVALID, "no HOG call to report");
+    if (!c || !idx || c->N <= 0 || !c->have_patch_idx) return fail(SDM_ERR_INVALID, "no HOG call to report");
     HIP_TRY(hipMemcpyAsync(idx, c->patch_idx.p, (size_t)c->N * (1 + 2 * c->L) * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SDM_OK;
@@ -984,18 +1000,18 @@ int sdm_detect_batch(sdm_ctx* c, float* x_host)
     HIP_TRY(hipSetDevice(c->device));
     c->chain_timers = true; c->ev_fresh = false;
     int rc = SDM_OK;
-    bool all_fused = true;
-    for (int l = 0; l < (int)c->levels.size(); ++l) all_fused = all_fused && fused_ok(c, l);
-    if (all_fused) rc = detect_fused(c);
-    else
-        for (int l = 0; l < (int)c->levels.size() && !rc; ++l) {
-            rc = do_hog(c, l);
-            if (!rc) rc = do_apply(c, l);
-        }
+    for (int l = 0; l < (int)c->levels.size() && !rc; ++l) rc = detect_level(c, l);
     c->chain_timers = false; c->ev_fresh = false;
     if (rc) return rc;
     if (x_host) return sdm_get_x(c, x_host);
     return SDM_OK;
+}
+
+int sdm_detect_level(sdm_ctx* c, int level)
+{
+    if (!c || level < 0 || level >= (int)c->levels.size()) return fail(SDM_ERR_INVALID, "bad level");
+    HIP_TRY(hipSetDevice(c->device));
+    return detect_level(c, level);
 }
 
 int sdm_set_targets(sdm_ctx* c, const float* xstar, int N)
@@ -1439,6 +1455,28 @@ int sdm_debug_hog_plan(int num_cells, int cell_size, int num_bins, int num_landm
     if (lane_tab) memcpy(lane_tab, hp.lane_tab.data(), hp.lane_tab.size() * sizeof(unsigned));
     if (wb) memcpy(wb, hp.wb.data(), hp.wb.size() * sizeof(float));
     if (pass_info) memcpy(pass_info, hp.pass_info.data(), hp.pass_info.size() * sizeof(int));
+    return SDM_OK;
+}
+
+int sdm_debug_hog_plan_cut(int num_cells, int cell_size, int num_bins, int num_landmarks, int* cut)
+{
+    if (!cut || num_landmarks <= 0) return fail(SDM_ERR_INVALID, "bad arguments");
+    HogLevelDev lv;
+    memset(&lv, 0, sizeof(lv));
+    lv.variant = SDM_VARIANT_UOCTTI; lv.C = num_cells; lv.cell = cell_size; lv.O = num_bins; lv.S = num_cells * cell_size;
+    fill_row_tab(lv);
+    HogPlanHost hp;
+    if (!sdm_hog_plan_build(lv, num_landmarks, hp)) return fail(SDM_ERR_INVALID, "no packed instance for this geometry");
+    memcpy(cut, hp.cut.data(), (size_t)num_landmarks * sizeof(int));
+    return SDM_OK;
+}
+
+int sdm_debug_set_detect_path(sdm_ctx* c, int fused, int split_store)
+{
+    if (!c) return fail(SDM_ERR_INVALID, "null context");
+    c->fuse_apply = fused != 0;
+    c->fuse_wide = fused == 2;
+    c->split_store = split_store != 0;
     return SDM_OK;
 }
 

@@ -241,6 +241,10 @@ class Context:
     def apply(self, level: int):
         check(self._lib.sdm_apply(self._h, level))
 
+    def detect_level(self, level: int):
+        """One cascade level of ``detect_batch`` (same launches, same bits): x_{k+1} replaces x_k on the device."""
+        check(self._lib.sdm_detect_level(self._h, level))
+
     def detect_batch(self, fetch: bool = True) -> Optional[np.ndarray]:
         if fetch:
             out = np.empty((self.N, 2 * self.L), np.float32)
@@ -414,6 +418,12 @@ class Context:
         """Lane packing of the HOG launch (include/sdm.h: sdm_debug_set_hog_packing); on by default."""
         check(self._lib.sdm_debug_set_hog_packing(self._h, int(on)))
 
+    def set_detect_path(self, fused: bool = True, split_store: bool = False):
+        """Round-4 A/B switch (``sdm_debug_set_detect_path``): ``fused`` -- ``detect_batch`` multiplies the descriptors by the
+        regressor on the chip and never writes the feature matrix (default for 2L <= 64; ``fused="wide"`` also for wider outputs); ``split_store`` -- feature rows through the raw cell
+        histograms + the store form of csrc/sdm_desc.hip instead of the pixel kernel's own normalisation (default off)."""
+        check(self._lib.sdm_debug_set_detect_path(self._h, 2 if fused == "wide" else int(bool(fused)), int(bool(split_store))))
+
     def gram_fallbacks(self) -> int:
         """Gram launches of this context repeated with three bf16 pieces (an operand beyond float16's range); tests."""
         return check(self._lib.sdm_debug_gram_fallbacks(self._h))
@@ -438,8 +448,10 @@ def hog_plan(num_cells: int, cell_size: int, num_bins: int, num_landmarks: int, 
     if info[0] == 0:
         return None
     n = int(info[1] + info[4])
+    cut = np.zeros(num_landmarks, np.int32)
+    check(L.sdm_debug_hog_plan_cut(num_cells, cell_size, num_bins, num_landmarks, _ip(cut)))
     return {"G": int(info[0]), "P": int(info[1]), "n_main": int(info[2]), "Gt": int(info[3]), "Pt": int(info[4]),
-            "lane_tab": lane_tab[:n], "wb": wb[:n], "pass_info": pass_info[:n]}
+            "lane_tab": lane_tab[:n], "wb": wb[:n], "pass_info": pass_info[:n], "cut": cut}
 
 
 # --------------------------------------------------------------------------------------------------
@@ -654,8 +666,7 @@ class SupervisedDescentOptimiser:
         if on_regressor_iteration_callback is None:
             return c.detect_batch()                                           # :262-306
         for level in range(len(self.regressors)):
-            c.hog_features(level)
-            c.apply(level)
+            c.detect_level(level)                                             # (the launches detect_batch runs: same bits)
             on_regressor_iteration_callback(c.get_x())                        # :303
         return c.get_x()
 

@@ -159,8 +159,9 @@ struct BatchedBackend<rcr::HogTransform, LinearRegressor<Solver>, rcr::InterEyeD
         // the default callback (the free function no_eval) needs no device->host copy of the intermediate x
         constexpr bool has_callback = !std::is_same<typename std::decay<Callback>::type, void (*)(const cv::Mat&)>::value;
         for (size_t level = 0; level < regressors.size(); ++level) {
-            hip::check(sdm_hog_features(c, (int)level, nullptr), "sdm_hog_features");
-            hip::check(sdm_apply(c, (int)level), "sdm_apply");
+            // one level of the device cascade: projection -> predict -> update; in the default mode the descriptors are multiplied
+            // by the regressor on the chip and the feature matrix is never written (csrc/sdm_desc.hip)
+            hip::check(sdm_detect_level(c, (int)level), "sdm_detect_level");
             if (has_callback) on_regressor_iteration_callback(fetch_x(c, x0.rows, x0.cols));
         }
         return fetch_x(c, x0.rows, x0.cols);

@@ -131,3 +131,42 @@ def test_plan_packs_the_shipped_levels(built):
         assert p9 is not None and (p9["G"], p9["P"]) == (got[cell]["G"], got[cell]["P"])
         assert np.array_equal(p9["lane_tab"], got[cell]["lane_tab"]) and np.array_equal(p9["wb"], got[cell]["wb"])
     assert hog_plan(5, 11, 6, 22) is None                   # 6 orientations: no packed instance (its sector shortcut fails the exhaustive check)
+
+
+@pytest.mark.parametrize("cell,L", [(11, 22), (10, 22), (8, 22), (6, 22), (10, 68), (8, 68), (6, 7), (10, 3)])
+def test_cut_flags_match_the_lane_tables(cell, L):
+    """Round 4 (CELLS form of the packed launch): a landmark's raw cell histograms arrive in two parts exactly when its patch
+    appears in two passes of the plan -- the flags sdm_desc.hip reads must say so for every landmark, main groups and tail."""
+    plan = hog_plan(5, cell, 4, L)
+    assert plan is not None
+    G, P, n_main, Gt, Pt = plan["G"], plan["P"], plan["n_main"], plan["Gt"], plan["Pt"]
+    want = np.zeros(L, np.int32)
+
+    def slots_in_two_passes(passes):
+        seen = {}
+        for pt in passes:
+            for d in plan["lane_tab"][pt]:
+                if (int(d) >> 17) & 1:
+                    seen.setdefault(int(d) & 0xff, set()).add(pt)
+        return [s for s, v in seen.items() if len(v) > 1], seen
+
+    two, seen = slots_in_two_passes(range(P))
+    assert all(len(v) <= 2 for v in seen.values())              # a patch (S <= 64 columns) is cut at most once
+    for g in range(n_main):
+        for s in two:
+            want[g * G + s] = 1
+    two_t, seen_t = slots_in_two_passes(range(P, P + Pt))
+    assert all(len(v) <= 2 for v in seen_t.values())
+    for s in two_t:
+        want[n_main * G + s] = 1
+    assert np.array_equal(plan["cut"], want)
+    # the first pass of a cut patch is the one holding its column 0 (part 0), the second does not (part 1)
+    for passes in (range(P), range(P, P + Pt)):
+        for pt in passes:
+            first_bits = (int(plan["pass_info"][pt][3]) >> 24) & 7
+            for seg in range(3):
+                slot = int(plan["pass_info"][pt][seg])
+                if slot < 0:
+                    continue
+                cols = [(int(d) >> 8) & 0xff for d in plan["lane_tab"][pt] if ((int(d) >> 17) & 1) and (int(d) & 0xff) == slot and ((int(d) >> 20) & 3) == seg]
+                assert ((first_bits >> seg) & 1) == (1 if 0 in cols else 0)
