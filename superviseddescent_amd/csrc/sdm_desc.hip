@@ -23,6 +23,7 @@
 //     three piece products per product with f32 accumulation, and writes partial[l][sample][2L]; the existing split-K reduction
 //     (apply_reduce_kernel) sums the landmarks in order and applies x - u * IED.  The N x F feature matrix is never written.
 #include "sdm_kernels.h"
+#include <stdlib.h>
 
 #pragma clang fp contract(off)
 
@@ -54,8 +55,8 @@ __device__ inline int desc_f16_exponent(unsigned maxbits)      // (= apply_f16_e
 }
 
 // One wave = two patches (lane >> 5), one lane = one cell (lane & 31 < C*C).  FB samples x one landmark per workgroup.
-template <int TO, int TC, int VARIANT, bool FUSED, int FB>
-__global__ void __launch_bounds__(DS_WAVES * 64, (TO > 4 && !FUSED) ? 2 : ((TO <= 4 && FUSED) ? DS_MINW : 4))      // (the 31 / 36 features per cell of 9 orientations need > 128 registers in the store form)
+template <int TO, int TC, int VARIANT, bool FUSED, int FB, int W = DS_WAVES>      // W waves per workgroup
+__global__ void __launch_bounds__(W * 64, (TO > 4 && !FUSED) ? 2 : ((TO <= 4 && FUSED) ? DS_MINW : 4))      // (the 31 / 36 features per cell of 9 orientations need > 128 registers in the store form)
 desc_kernel(const float* __restrict__ cells, const int* __restrict__ cut, int N, int L,
             float* __restrict__ feat, long long ldf, int has_bias,
             const u32x4* __restrict__ planes, int NT, const unsigned* __restrict__ rmax, const float* __restrict__ Rt, long long ldr,
@@ -83,7 +84,7 @@ desc_kernel(const float* __restrict__ cells, const int* __restrict__ cut, int N,
 
     if (FUSED) {      // the rows' padding (and the spare bytes behind the last row) is read by the last k-step: zero it once
         constexpr int PADW = KS - P;
-        for (int i = threadIdx.x; i < 2 * FB * PADW; i += DS_WAVES * 64) {
+        for (int i = threadIdx.x; i < 2 * FB * PADW; i += W * 64) {
             const int piece = i / (FB * PADW), r = i - piece * (FB * PADW);
             const int m = r / PADW, k = P + (r - m * PADW);
             (piece ? stage_lo : stage_hi)[(size_t)m * KS + k] = 0;
@@ -99,8 +100,8 @@ desc_kernel(const float* __restrict__ cells, const int* __restrict__ cut, int N,
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef float f32x4u __attribute__((ext_vector_type(4), aligned(8)));
     typedef float f32x2u __attribute__((ext_vector_type(2), aligned(8)));
-    constexpr int NIT = FB / (2 * DS_WAVES);
-    auto face_of = [&](int it) { const int fr = tile * FB + it * (2 * DS_WAVES) + wave * 2 + half; return fr < N ? fr : N - 1; };      // (a partial last tile repeats the last sample; never stored)
+    constexpr int NIT = FB / (2 * W);
+    auto face_of = [&](int it) { const int fr = tile * FB + it * (2 * W) + wave * 2 + half; return fr < N ? fr : N - 1; };      // (a partial last tile repeats the last sample; never stored)
     // cells[sample][landmark][part][cell][2O]: this lane's cell = 2O consecutive floats
     auto load_cells = [&](int it, float* h) {
         const float* hp = cells + ((((long long)face_of(it) * L + l) * 2) * CC + cc) * (2 * O);
@@ -119,7 +120,7 @@ desc_kernel(const float* __restrict__ cells, const int* __restrict__ cut, int N,
     load_cells(0, hn);
 #pragma unroll 1
     for (int it = 0; it < NIT; ++it) {
-        const int m = it * (2 * DS_WAVES) + wave * 2 + half;             // sample of the tile
+        const int m = it * (2 * W) + wave * 2 + half;             // sample of the tile
         const int face_real = tile * FB + m;
         const int face = face_real < N ? face_real : N - 1;
         float h[2 * O];
@@ -194,7 +195,7 @@ desc_kernel(const float* __restrict__ cells, const int* __restrict__ cut, int N,
     // Wave w multiplies k-part w % KPARTS of the column tiles w / KPARTS, + 8 / KPARTS, ...: a part is <= 7 k-steps, so ALL of its
     // regressor fragments are requested before the first product (one L2 round trip per task; with the fragments fetched one k-step
     // ahead every k-step waited ~600 cycles for ~100 cycles of matrix work).  Parts > 0 hand their tile to part 0 through LDS.
-    constexpr int KPARTS = KSTEPS <= 14 ? 2 : 4, NW = DS_WAVES / KPARTS;
+    constexpr int KPARTS = KSTEPS <= 14 ? 2 : 4, NW = W / KPARTS;
     constexpr int KBASE = KSTEPS / KPARTS, KREM = KSTEPS % KPARTS, KMAX = KBASE + (KREM ? 1 : 0);
     constexpr int MAXT = (9 + NW - 1) / NW;                         // column tiles per wave at 2L <= 144
     const int li = lane & 15, lq = lane >> 4;
@@ -294,7 +295,7 @@ __global__ void __launch_bounds__(256) desc_planes_kernel(const float* __restric
     planes[frag * 128 + 64 + lane] = p2;
 }
 
-template <int TO, int VARIANT, bool FUSED, int FB>
+template <int TO, int VARIANT, bool FUSED, int FB, int W = DS_WAVES>
 void launch_desc(const float* cells, const int* cut, int N, int L, float* feat, long long ldf, int has_bias, const void* planes, int NT,
                  const unsigned* rmax, const float* Rt, long long ldr, float* partial, hipStream_t stream)
 {
@@ -303,8 +304,8 @@ void launch_desc(const float* cells, const int* cut, int N, int L, float* feat, 
     const unsigned grid = (unsigned)(((long long)N + FB - 1) / FB * L);
     static unsigned long long seen = 0;
     if (FUSED && sdm_first_use_on_device(seen))
-        SDM_SET_ATTR((const void*)desc_kernel<TO, 5, VARIANT, FUSED, FB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((desc_kernel<TO, 5, VARIANT, FUSED, FB>), dim3(grid), dim3(DS_WAVES * 64), lds, stream, cells, cut, N, L, feat, ldf,
+        SDM_SET_ATTR((const void*)desc_kernel<TO, 5, VARIANT, FUSED, FB, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((desc_kernel<TO, 5, VARIANT, FUSED, FB, W>), dim3(grid), dim3(W * 64), lds, stream, cells, cut, N, L, feat, ldf,
                        has_bias, (const u32x4*)planes, NT, rmax, Rt, ldr, partial);
 }
 
