@@ -241,6 +241,9 @@ int sdm_train_level(sdm_ctx* ctx, int level, int reg_type, float reg_param, int 
 /* Device views for collectives / zero-copy interop (valid until the next allocation-changing call). */
 int sdm_gram_device_ptr(sdm_ctx* ctx, void** dev_ptr, size_t* count_f32);
 int sdm_x_device_ptr(sdm_ctx* ctx, void** dev_ptr, size_t* count_f32);
+/* (Handing out the pointer marks the rows as possibly caller-written: an sdm_apply of this level then runs the f32 matrix-core
+ * kernel instead of the float16-piece one, whose 2^12 pre-scale is exact only for |feature| < 16 -- always true of HOG output,
+ * not of arbitrary data.  The same holds once templates have been subtracted, sdm_set_templates.) */
 int sdm_features_device_ptr(sdm_ctx* ctx, void** dev_ptr, long long* ld, int* n_rows);
 
 /* Profiling. */

@@ -121,6 +121,10 @@ struct sdm_ctx {
     bool have_targets = false;
     DevBuf<float> feat;
     int feat_level = -1;
+    // The float16-piece apply (sdm_apply.hip) scales every feature by 2^12 before the split: exact for |feature| < 16, which HOG
+    // descriptors (<= 0.4) satisfy by construction.  Rows that are NOT plain HOG output -- templates subtracted, or the caller holds
+    // the device pointer (sdm_features_device_ptr) and may have written them -- go through the f32 matrix-core kernel.
+    bool feat_bounded = false;
     DevBuf<int> patch_idx;
     bool have_patch_idx = false;    // the last HOG launch (feature rows or fused cascade level) left its integer decisions in patch_idx
     DevBuf<int> status;
@@ -144,6 +148,7 @@ struct sdm_ctx {
     DevBuf<float> winv;    // [Fp/128][128][128] transposed inverses of the diagonal factor tiles
     DevBuf<int> gram_flag;               // raised by the float16 split when an operand leaves float16's range
     int gram_fallbacks = 0;              // launches repeated with three bf16 pieces (sdm_debug_gram_fallbacks)
+    int gram_f32_fallbacks = 0;          // launches that ran on the f32 matrix-core kernel because the planes could not be allocated
     DevBuf<unsigned char> gram_planes;   // the feature matrix as three bf16 planes (sdm_gram_bf16.hip), scratch of sdm_gram_rhs
     DevBuf<float> lambda_dev;
 
@@ -355,6 +360,7 @@ int do_hog(sdm_ctx* c, int level)
     }
     HIP_TRY(hipGetLastError());
     c->feat_level = level;
+    c->feat_bounded = c->tmpl_N == 0;
     c->have_patch_idx = true;
     return SDM_OK;
 }
@@ -386,7 +392,8 @@ int do_apply(sdm_ctx* c, int level)
         Timer t(c, SDM_T_APPLY);
         sdm_launch_apply(c->feat.p, c->ldf, c->N, F, c->Rt[level].p, c->ldf, c->M, c->x[c->cur].p,
                          c->x[c->cur ^ 1].p, c->L, c->eyes, c->partial.p, splits, c->stream,
-                         c->Rp[level].p, c->Rp[level].p ? c->Rmax.p + (size_t)level * Mp_of(c->M) : nullptr);
+                         c->feat_bounded ? c->Rp[level].p : nullptr,
+                         (c->feat_bounded && c->Rp[level].p) ? c->Rmax.p + (size_t)level * Mp_of(c->M) : nullptr);
     }
     HIP_TRY(hipGetLastError());
     c->cur ^= 1;
@@ -1047,22 +1054,27 @@ int sdm_gram_rhs(sdm_ctx* c, int level)
     // f32 matrix-core kernel of rounds 1-2 (A/B); SDM_GRAM_BF16X3=1: always the three-bf16 form.
     static const bool gram_f32 = getenv("SDM_GRAM_F32") && getenv("SDM_GRAM_F32")[0] == '1';
     static const bool gram_bf16 = getenv("SDM_GRAM_BF16X3") && getenv("SDM_GRAM_BF16X3")[0] == '1';
-    if (!gram_f32) {
-        if ((rc = c->gram_planes.ensure(sdm_gram_bf16x3_plane_bytes(c->N, ncols)))) return rc;
-        bool done = false;
-        if (!gram_bf16) {
-            if ((rc = c->gram_flag.ensure(1))) return rc;
-            HIP_TRY(hipMemsetAsync(c->gram_flag.p, 0, sizeof(int), c->stream));
-            sdm_launch_gram_bf16x3(c->feat.p, c->ldf, c->N, ncols, c->gram_planes.p, c->G.p, ncols, c->stream, c->gram_flag.p);
-            int over = 0;
-            HIP_TRY(hipMemcpyAsync(&over, c->gram_flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            done = over == 0;
-            c->gram_fallbacks += done ? 0 : 1;
+    // Scratch: the float16 form needs two planes (4 bytes per feature-matrix element); the third (bf16 repeat) is
+    // allocated only when a launch actually overflowed.  If the scratch cannot be had (the feature matrix of 100 000 x 27 392 is
+    // 11 GB, its planes another 11 / 16 GB) the f32 matrix-core kernel forms the Gram matrix from the rows in place.
+    int form = gram_f32 ? 0 : (gram_bf16 ? 3 : 2);      // pieces per operand; 0 = the f32 matrix-core kernel
+    if (form && c->gram_planes.ensure(sdm_gram_bf16x3_plane_bytes(c->N, ncols, form))) { (void)hipGetLastError(); form = 0; c->gram_f32_fallbacks += 1; }
+    if (form == 3) sdm_launch_gram_bf16x3(c->feat.p, c->ldf, c->N, ncols, c->gram_planes.p, c->G.p, ncols, c->stream);
+    else if (form == 2) {
+        if ((rc = c->gram_flag.ensure(1))) return rc;
+        HIP_TRY(hipMemsetAsync(c->gram_flag.p, 0, sizeof(int), c->stream));
+        sdm_launch_gram_bf16x3(c->feat.p, c->ldf, c->N, ncols, c->gram_planes.p, c->G.p, ncols, c->stream, c->gram_flag.p);
+        // (one 4-byte read-back per level: the only host wait of sdm_train_level; the queue is idle for ~0.1 ms of a 40 ... 300 ms level)
+        int over = 0;
+        HIP_TRY(hipMemcpyAsync(&over, c->gram_flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (over) {
+            c->gram_fallbacks += 1;
+            if (c->gram_planes.ensure(sdm_gram_bf16x3_plane_bytes(c->N, ncols, 3))) { (void)hipGetLastError(); form = 0; c->gram_f32_fallbacks += 1; }
+            else sdm_launch_gram_bf16x3(c->feat.p, c->ldf, c->N, ncols, c->gram_planes.p, c->G.p, ncols, c->stream);
         }
-        if (!done) sdm_launch_gram_bf16x3(c->feat.p, c->ldf, c->N, ncols, c->gram_planes.p, c->G.p, ncols, c->stream);
-    } else
-    sdm_launch_syrk_tn(c->feat.p, c->ldf, c->N, ncols, c->G.p, ncols, 1.0f, 0, 0, c->stream);
+    }
+    if (form == 0) sdm_launch_syrk_tn(c->feat.p, c->ldf, c->N, ncols, c->G.p, ncols, 1.0f, 0, 0, c->stream);
     HIP_TRY(hipGetLastError());
     c->g_ncols = ncols; c->g_fp = Fp; c->g_level = level;
     return SDM_OK;
@@ -1360,6 +1372,7 @@ int sdm_features_device_ptr(sdm_ctx* c, void** p, long long* ld, int* n_rows)
 {
     if (!c || c->feat_level < 0) return fail(SDM_ERR_INVALID, "no features");
     *p = c->feat.p; *ld = c->ldf; *n_rows = c->N;
+    c->feat_bounded = false;      // (the caller may write the rows: sdm_apply of this level then takes the f32 kernel)
     return SDM_OK;
 }
 

@@ -546,11 +546,12 @@ static const std::vector<int>& gram_tile_order_w(int T)
 
 static size_t gram_order_bytes(int ncols) { const int T = ncols / GB_TILE; return ((size_t)(T * (T + 1) / 2 + 8) * sizeof(int) + 255) & ~(size_t)255; }
 
-size_t sdm_gram_bf16x3_plane_bytes(int N, int ncols)
+size_t sdm_gram_bf16x3_plane_bytes(int N, int ncols, int pieces)
 {
+    // pieces = 2: the float16 form (what a launch needs unless an operand leaves float16's range), 3: the bf16 repeat
     const size_t NG = (size_t)((N + 31) / 32) * 4;
     const size_t ncols2 = (size_t)((ncols + 255) / 256) * 256;
-    return 3 * NG * ncols2 * 16 + gram_order_bytes(ncols);
+    return (size_t)pieces * NG * ncols2 * 16 + gram_order_bytes(ncols);
 }
 void sdm_launch_gram_bf16x3(const float* A, long long lda, int N, int ncols, void* planes, float* C, long long ldc, hipStream_t stream,
                             int* f16_flag)
@@ -569,7 +570,7 @@ void sdm_launch_gram_bf16x3(const float* A, long long lda, int N, int ncols, voi
         SDM_SET_ATTR((const void*)syrk_tn_bf16x3_w_kernel<3, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     const std::vector<int>& ow = gram_tile_order_w(ncols / GB_TILE);
-    int* d_ow = (int*)((unsigned char*)planes + 3 * (size_t)NG * (size_t)ncols2 * 16);      // (the table lives behind the planes; the vector is cached for the process)
+    int* d_ow = (int*)((unsigned char*)planes + (f16_flag ? 2 : 3) * (size_t)NG * (size_t)ncols2 * 16);      // (the table lives behind the planes of this form; the vector is cached for the process)
     (void)hipMemcpyAsync(d_ow, ow.data(), ow.size() * sizeof(int), hipMemcpyHostToDevice, stream);
     static const bool waves16 = getenv("SDM_GRAM_WAVES16") && atoi(getenv("SDM_GRAM_WAVES16")) != 0;      // A/B: the sixteen-wave float16 kernel
     if (f16_flag && !waves16)

@@ -194,7 +194,7 @@ void sdm_launch_syrk_tn(const float* A, long long lda, int rows, int ncols, floa
 // The Gram launch on the bf16 matrix cores with float32 accuracy (sdm_gram_bf16.hip): every f32 operand split into three bf16
 // pieces, six piece products per product.  `planes`: scratch of sdm_gram_bf16x3_plane_bytes(N, ncols) bytes.  Writes the upper
 // 128 x 128 tiles of the ncols x ncols matrix (ncols % 128 == 0), like sdm_launch_syrk_tn(..., accumulate = 0, tile_i0 = 0).
-size_t sdm_gram_bf16x3_plane_bytes(int N, int ncols);
+size_t sdm_gram_bf16x3_plane_bytes(int N, int ncols, int pieces = 3);      // pieces = 2: the float16 form only
 void sdm_launch_gram_bf16x3(const float* A, long long lda, int N, int ncols, void* planes, float* C, long long ldc, hipStream_t stream,
                             int* f16_flag = nullptr);
 

@@ -157,3 +157,27 @@ def test_fused_with_templates_falls_back(ctx):
     ctx.set_x(x0); x_u = ctx.detect_batch()
     ctx.set_templates(None)
     assert np.array_equal(x_t, x_u)
+
+
+def test_apply_of_rows_that_are_not_hog_output(ctx):
+    """the float16-piece apply GEMM pre-scales by 2^12 and is exact only for |feature| < 16.  Rows with templates
+    subtracted (here: templates of magnitude 40) must take the f32 matrix-core kernel -- at 2 048+ rows, where the float16 kernel
+    would otherwise serve."""
+    n = 2048
+    images, x0 = bind(ctx, IDS22, RE22, LE22, SHIPPED[1:2], n, 361, off_canvas=False)
+    rng = np.random.default_rng(11)
+    F = ctx.feature_dim(0)
+    R = (rng.standard_normal((F, 44)) * 1e-4).astype(np.float32)
+    ctx.set_regressor(0, R)
+    ctx.set_x(x0)
+    feat = ctx.hog_features(0, fetch=True)
+    tmpl = (rng.standard_normal((n, F)) * 40.0).astype(np.float32)
+    ctx.set_templates(tmpl)
+    ctx.set_x(x0)
+    ctx.hog_features(0)
+    ctx.apply(0)
+    x1 = ctx.get_x()
+    ctx.set_templates(None)
+    ied = 1.0 / orc.InterEyeDistanceNormalisation(RE22, LE22)(x0)[:, :1].astype(np.float64)
+    want = x0.astype(np.float64) - ((feat.astype(np.float64) - tmpl.astype(np.float64)) @ R.astype(np.float64)) * ied
+    assert np.abs(x1 - want).max() / np.abs(want - x0).max() < 1e-5
