@@ -268,6 +268,10 @@ int sdm_debug_set_hog_packing(sdm_ctx* ctx, int on);
  * range (the Gram matrix A^T A / A^T b of regressors.hpp:208,225 is formed on the 16-bit matrix cores from two float16 pieces per
  * f32 operand -- float32 accuracy, see csrc/sdm_gram_bf16.hip; the repeat keeps float32's range).  Tests. */
 int sdm_debug_gram_fallbacks(sdm_ctx* ctx);
+/* How many factorisations of this context ran their trailing updates on the f32 matrix-core kernel because the diagonal of the
+ * regularised Gram matrix spanned more than 2^20 (the float16-piece updates of csrc/sdm_gram_bf16.hip share one power-of-two
+ * scale per factorisation; PartialPivLUSolver::solve, regressors.hpp:224-225, on arbitrary data).  Tests. */
+int sdm_debug_update_fallbacks(sdm_ctx* ctx);
 /* The packing plan of a level geometry (host only, no device needed): info5 = {G, P, n_main, Gt, Pt} (G == 0: no packed
  * instance for this geometry); lane_tab [passes][64], wb [passes][64][16], pass_info [passes][4] as documented in
  * superviseddescent_amd/csrc/sdm_kernels.h (HogPlanDev); passes = P + Pt <= max_passes. */

@@ -29,7 +29,7 @@ EXPORTED = [
     "sdm_set_solve_sharding", "sdm_set_solve_sharding_rccl", "sdm_set_reduce_scatter", "sdm_set_reduce_scatter_rccl",
     "sdm_set_templates", "sdm_init_from_boxes", "sdm_normalised_errors", "sdm_solve", "sdm_solve_normal_equations", "sdm_train_level", "sdm_gram_device_ptr", "sdm_x_device_ptr", "sdm_features_device_ptr",
     "sdm_enable_timing", "sdm_get_timing", "sdm_debug_patch", "sdm_debug_hog_profile", "sdm_debug_gradient_table",
-    "sdm_debug_set_hog_packing", "sdm_debug_gram_fallbacks", "sdm_debug_hog_plan", "sdm_debug_hog_plan_cut", "sdm_debug_set_detect_path", "sdm_upload_images_bgr_u8", "sdm_debug_download_images",
+    "sdm_debug_set_hog_packing", "sdm_debug_gram_fallbacks", "sdm_debug_update_fallbacks", "sdm_debug_hog_plan", "sdm_debug_hog_plan_cut", "sdm_debug_set_detect_path", "sdm_upload_images_bgr_u8", "sdm_debug_download_images",
 ]
 
 
@@ -147,6 +147,7 @@ def lib() -> ctypes.CDLL:
             "sdm_debug_hog_profile": [c_void_p, c_int, ctypes.POINTER(ctypes.c_ulonglong)],
             "sdm_debug_set_hog_packing": [c_void_p, c_int],
             "sdm_debug_gram_fallbacks": [c_void_p],
+            "sdm_debug_update_fallbacks": [c_void_p],
             "sdm_debug_hog_plan": [c_int, c_int, c_int, c_int, c_int_p, c_void_p, c_void_p, c_void_p, c_int],
             "sdm_debug_hog_plan_cut": [c_int, c_int, c_int, c_int, c_int_p],
             "sdm_debug_set_detect_path": [c_void_p, c_int, c_int],

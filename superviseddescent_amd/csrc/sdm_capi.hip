@@ -71,7 +71,7 @@ struct sdm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    SolveAux solve_aux = {nullptr, nullptr, nullptr, nullptr, nullptr};   // second queue of the Cholesky look-ahead (+ the scratch of its float16 updates, set per solve)
+    SolveAux solve_aux = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // second queue of the Cholesky look-ahead (+ the scratch of its float16 updates, set per solve)
     DevBuf<unsigned char> upd_planes;    // one panel group as float16 planes (sdm_update_f16_plane_bytes)
     DevBuf<unsigned> upd_maxdiag;
 
@@ -148,6 +148,7 @@ struct sdm_ctx {
     DevBuf<float> winv;    // [Fp/128][128][128] transposed inverses of the diagonal factor tiles
     DevBuf<int> gram_flag;               // raised by the float16 split when an operand leaves float16's range
     int gram_fallbacks = 0;              // launches repeated with three bf16 pieces (sdm_debug_gram_fallbacks)
+    int update_range_fallbacks = 0;      // factorisations that ran their trailing updates in f32 because the diagonal spanned > 2^20
     int gram_f32_fallbacks = 0;          // launches that ran on the f32 matrix-core kernel because the planes could not be allocated
     DevBuf<unsigned char> gram_planes;   // the feature matrix as three bf16 planes (sdm_gram_bf16.hip), scratch of sdm_gram_rhs
     DevBuf<float> lambda_dev;
@@ -1181,9 +1182,10 @@ int sdm_set_solve_sharding_rccl(sdm_ctx* c, void* nccl_comm, int rank, int world
 int solve_update_scratch(sdm_ctx* c, int ncols)
 {
     int rc;
-    if ((rc = c->upd_planes.ensure(sdm_update_f16_plane_bytes(512, ncols))) || (rc = c->upd_maxdiag.ensure(3))) return rc;
+    if ((rc = c->upd_planes.ensure(sdm_update_f16_plane_bytes(512, ncols))) || (rc = c->upd_maxdiag.ensure(4))) return rc;
     c->solve_aux.upd_planes = c->upd_planes.p;
     c->solve_aux.upd_maxdiag = c->upd_maxdiag.p;
+    c->solve_aux.range_fallbacks = &c->update_range_fallbacks;
     return SDM_OK;
 }
 
@@ -1278,8 +1280,15 @@ int sdm_solve(sdm_ctx* c, int level, int reg_type, float reg_param, int regulari
         if (c->g_scattered && !(sharded && c->shard_world == c->world_size))
             return fail(SDM_ERR_INVALID, "sdm_solve: the Gram matrix was reduce-scattered over the ranks; the factorisation must be sharded over the same ranks");
         if (sharded) {
-            if ((rc = c->shard_stage.ensure(sdm_solve_shard_stage_tiles(ncols, c->shard_world) * 128 * 128))) return rc;
-            shard.rank = c->shard_rank; shard.world = c->shard_world; shard.stage = c->shard_stage.p; shard.stage_floats = c->shard_stage.cap; shard.self = c;
+            // The staging size is a function of (ncols, 2L, world) only and is what the launcher decides by -- not the buffer's
+            // capacity, which a reused context may hold larger than its peers (one rank would then take the all-gather of
+            // the sharded back substitution and the others not).  Sized so that the sharded back substitution always fits.
+            const size_t nj_rhs = (size_t)(Mp / 16), bs_per = (nj_rhs + c->shard_world - 1) / c->shard_world;
+            size_t stage_need = sdm_solve_shard_stage_tiles(ncols, c->shard_world) * 128 * 128;
+            const size_t bs_need = (size_t)(c->shard_world + 1) * (size_t)Fp * 16 * bs_per;
+            if (bs_need > stage_need) stage_need = bs_need;
+            if ((rc = c->shard_stage.ensure(stage_need))) return rc;
+            shard.rank = c->shard_rank; shard.world = c->shard_world; shard.stage = c->shard_stage.p; shard.stage_floats = stage_need; shard.self = c;
             shard.bcast = shard_bcast_thunk; shard.allgather = shard_allgather_thunk;
             static const int emulate = getenv("SDM_SOLVE_SHARD_EMULATE") ? atoi(getenv("SDM_SOLVE_SHARD_EMULATE")) : 0;
             shard.emulate_chain = emulate;
@@ -1443,6 +1452,12 @@ int sdm_debug_gram_fallbacks(sdm_ctx* c)
 {
     if (!c) return fail(SDM_ERR_INVALID, "null context");
     return c->gram_fallbacks;
+}
+
+int sdm_debug_update_fallbacks(sdm_ctx* c)
+{
+    if (!c) return fail(SDM_ERR_INVALID, "null context");
+    return c->update_range_fallbacks;
 }
 
 int sdm_debug_set_hog_packing(sdm_ctx* c, int on)

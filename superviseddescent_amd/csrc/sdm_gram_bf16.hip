@@ -415,6 +415,11 @@ __global__ void __launch_bounds__(256) diag_absmax_kernel(const float* __restric
     float v = i < F ? __builtin_fabsf(G[(long long)i * ldg + i]) : 0.0f;
     for (int o = 32; o; o >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, o));
     if ((threadIdx.x & 63) == 0) atomicMax(out, __builtin_bit_cast(unsigned, v));      // (non-negative floats order like their bit patterns)
+    // ... and the smallest |diagonal entry| (out[3]): the float16 updates carry ONE power-of-two scale per factorisation, so a
+    // diagonal that spans more than ~2^20 would push the small columns' factor entries below float16's resolution
+    float m = i < F ? __builtin_fabsf(G[(long long)i * ldg + i]) : 3.0e38f;
+    for (int o = 32; o; o >>= 1) m = __builtin_fminf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMin(out + 3, __builtin_bit_cast(unsigned, m));
 }
 
 // largest |entry| of a rows x cols block (a panel group's right-hand-side columns, <= 512 x 256): one workgroup per 8 rows
@@ -594,6 +599,7 @@ size_t sdm_update_f16_plane_bytes(int rows_max, int ncols)
 void sdm_launch_diag_absmax(const float* G, long long ldg, int F, unsigned* scales, hipStream_t stream)
 {
     (void)hipMemsetAsync(scales, 0, 3 * sizeof(unsigned), stream);
+    (void)hipMemsetAsync(scales + 3, 0x7f, sizeof(unsigned), stream);      // 0x7f7f7f7f = 3.4e38: the start of the minimum
     hipLaunchKernelGGL(diag_absmax_kernel, dim3((F + 255) / 256), dim3(256), 0, stream, G, ldg, F, scales);
 }
 

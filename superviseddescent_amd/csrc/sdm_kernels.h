@@ -240,7 +240,8 @@ struct SolveAux {
     hipStream_t stream; hipEvent_t chain_done, tail_done;
     // scratch of the float16 trailing update (sdm_gram_bf16.hip): planes of one panel group (sdm_update_f16_plane_bytes(512, ncols))
     // and three scale words (largest diagonal entry, largest right-hand-side entry of the group x two slots); null = every trailing update on the f32 matrix-core kernel
-    void* upd_planes; unsigned* upd_maxdiag;
+    void* upd_planes; unsigned* upd_maxdiag;      // (upd_maxdiag: 4 words -- largest diagonal entry, two right-hand-side scale slots, smallest diagonal entry)
+    int* range_fallbacks;                          // host counter: factorisations whose diagonal spanned > 2^20 and therefore ran their updates in f32 (may be null)
 };
 size_t sdm_update_f16_plane_bytes(int rows_max, int ncols);
 void sdm_launch_diag_absmax(const float* G, long long ldg, int F, unsigned* scales, hipStream_t stream);

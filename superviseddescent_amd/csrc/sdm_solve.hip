@@ -1190,8 +1190,26 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
     const bool overlap = aux && aux->stream && Tf > 2 * LAZY;
     static const bool upd_f32_only = getenv("SDM_UPDATE_F32") && getenv("SDM_UPDATE_F32")[0] == '1';      // (A/B: every trailing update on the f32 kernel)
     static const int upd_min_tiles = getenv("SDM_UPDATE_F16_MIN_TILES") ? atoi(getenv("SDM_UPDATE_F16_MIN_TILES")) : 40;
-    const bool upd_f16 = aux && aux->upd_planes && aux->upd_maxdiag && !upd_f32_only;
-    if (upd_f16) sdm_launch_diag_absmax(G, ldg, F, aux->upd_maxdiag, stream);
+    bool upd_f16 = aux && aux->upd_planes && aux->upd_maxdiag && !upd_f32_only;
+    if (upd_f16) {
+        sdm_launch_diag_absmax(G, ldg, F, aux->upd_maxdiag, stream);
+        // Range guard: the float16 pieces of the panel rows share one power-of-two scale taken from the largest
+        // diagonal entry.  A regularised Gram matrix of HOG features spans ~2^10 on its diagonal; arbitrary data handed to
+        // sdm_solve_normal_equations may span far more, and the factor rows of its small columns would fall below float16's
+        // resolution -- silently.  One 16-byte read-back per factorisation decides: beyond 2^20 (or a non-positive entry) every
+        // trailing update of this factorisation runs on the f32 matrix-core kernel.  Every rank of a sharded factorisation holds the
+        // same (summed) diagonal, so all take the same branch.
+        if (Tf >= upd_min_tiles) {
+            unsigned sc[4] = {0, 0, 0, 0};
+            if (hipMemcpyAsync(sc, aux->upd_maxdiag, sizeof(sc), hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess) {
+                const float dmax = __builtin_bit_cast(float, sc[0]), dmin = __builtin_bit_cast(float, sc[3]);
+                if (!(dmin > 0.0f) || !(dmax < 3.0e38f) || dmax > dmin * 1048576.0f) {
+                    upd_f16 = false;
+                    if (aux->range_fallbacks) *aux->range_fallbacks += 1;
+                }
+            }
+        }
+    }
     const int W = shard ? shard->world : 1, me = shard ? shard->rank : 0;
     bool tail_pending = false;
     for (int k = 0; k < Tf; ++k) {

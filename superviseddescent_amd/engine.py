@@ -428,6 +428,10 @@ class Context:
         """Gram launches of this context repeated with three bf16 pieces (an operand beyond float16's range); tests."""
         return check(self._lib.sdm_debug_gram_fallbacks(self._h))
 
+    def update_fallbacks(self) -> int:
+        """Factorisations that ran their trailing updates in f32 because the Gram diagonal spanned more than 2^20."""
+        return check(self._lib.sdm_debug_update_fallbacks(self._h))
+
     def debug_gradient_table(self, level: int):
         g = np.empty((511, 511), np.float32)
         b = np.empty((511, 511), np.int32)

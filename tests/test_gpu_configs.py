@@ -30,7 +30,10 @@ from superviseddescent_amd import HoGParam, HogTransform, LinearRegressor, Regul
 pytestmark = pytest.mark.gpu
 
 FIX = np.load(os.path.join(os.path.dirname(__file__), "golden", "config_oracle_levels.npz"))
-DRIFT = json.load(open(os.path.join(os.path.dirname(__file__), "..", "profiles", "r03_cpu_solver_drift.json")))
+# (a copy of profiles/r03_cpu_solver_drift.json, written by scripts/make_config_fixtures.py on the CPU: the tolerances below are
+#  test fixtures and live with the other fixtures, not with the profiling artefacts -- ADVICE r03)
+DRIFT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "cpu_solver_drift.json")))
+F64_PATH = os.path.join(os.path.dirname(__file__), "golden", "config_f64_levels.npz")
 CONFIGS = {
     # name: (ids, HoG parameters, regulariser, images, rows per image, seed, tolerance level 0, unused)
     "config3": (ibug.RCR22_IDS, [(1, 5, 11, 9, 1.0), (1, 5, 10, 9, 0.7), (1, 5, 8, 9, 0.4), (1, 5, 6, 9, 0.25), (1, 5, 6, 9, 0.25)],
@@ -79,6 +82,9 @@ def test_training_at_baseline_configuration(built, name):
         if name == "config3":
             scale = np.linalg.norm(want[l].astype(np.float64)) / np.linalg.norm(x_star[rows].astype(np.float64))
             assert abs(e_gpu - e_orc) <= free_running_tolerance(name, l) * scale, (name, l)
+            # ... and, independently of the landmark bound above: the two NLSRs have agreed to 4e-4 ... 5e-2 (relative) over every
+            # solver variant measured (profiles/r03_cpu_solver_drift.json); a factor of two on the worst of them
+            assert e_gpu == pytest.approx(e_orc, rel=0.1), (name, l)
         else:
             assert e_gpu == pytest.approx(e_orc, rel=1e-3), (name, l)
     assert rel_l2(levels[-1], x_star) < 0.5 * rel_l2(x0, x_star)
@@ -115,7 +121,9 @@ def test_teacher_forced_training_level_by_level(built, name):
     c.set_x(x0)
     c.set_targets(x_star)
     c.set_allreduce(None, 1)
-    errs = []
+    f64 = np.load(F64_PATH) if os.path.exists(F64_PATH) else None
+    have64 = f64 is not None and name + "_x64" in f64 and f64[name + "_sha1"].tobytes() == digest
+    errs, vs64 = [], []
     for k in range(len(params)):
         c.set_x(x0 if k == 0 else want[k - 1])                      # the oracle's landmarks entering level k
         c.hog_features(k)
@@ -123,15 +131,25 @@ def test_teacher_forced_training_level_by_level(built, name):
         c.allreduce_gram_rhs()
         c.solve(k, reg[0], reg[1], reg[2], x0.shape[0], fetch=False)
         c.apply(k)
-        errs.append(rel_l2(c.get_x(), want[k]))
+        xg = c.get_x()
+        errs.append(rel_l2(xg, want[k]))
+        if have64:      # the same level in float64 (scripts/make_f64_fixture.py): distance of the device / of the oracle's LU32 from it
+            rows = f64[name + "_rows"]
+            vs64.append((float(np.linalg.norm((xg[rows] - f64[name + "_x64"][k]).astype(np.float64))), float(f64[name + "_dist_lu32"][k])))
     print(name, "teacher-forced rel-L2 per level:", " ".join("%.2e" % e for e in errs))
+    if vs64:
+        print(name, "distance from the float64 level, device / oracle LU32:", " ".join("%.2e/%.2e" % v for v in vs64))
     for k, e in enumerate(errs):
         assert e < 1e-4, (name, k, errs)
+    # on identical inputs the device is no further from exact (float64) arithmetic than the reference's own
+    # float32 PartialPivLU is (x 1.5) -- at EVERY level; this is what backs the widened free-running bound of the test above
+    for k, (dg, dl) in enumerate(vs64):
+        assert dg <= 1.5 * dl, (name, k, vs64)
 
 
 def test_rcr68_detect_shard_matches_oracle(built):
-    """Config 4's path (RCR-68 detect, F = 27 201, M = 136) on 512 faces of a rank's shard, free-running, against the oracle
-    running the same regressors; the 8 192-face run is recorded in profiles/r02_parity_configs.json."""
+    """Config 4's path (RCR-68 detect, F = 27 201, M = 136) on a rank's whole shard -- 8 192 faces (65 536 / 8) -- free-running,
+    against the oracle running the same regressors (~15 s of oracle time on the GPU box's cores)."""
     from oracle import sdm_oracle as orc
     ids = ibug.IBUG68_IDS
     re, le = ibug.eye_indices(ids)
@@ -140,7 +158,7 @@ def test_rcr68_detect_shard_matches_oracle(built):
     txs, tx0, tidx = synth.make_samples(tbox, tgt, ids, n_perturb=9, seed=41002)
     sdo = SupervisedDescentOptimiser([LinearRegressor(Regulariser(1, 1.5, False)) for _ in params])
     sdo.train(txs, tx0, None, HogTransform(timg, [HoGParam(*p) for p in params], ids, ibug.RIGHT_EYE_IDS, ibug.LEFT_EYE_IDS, tidx))
-    images, boxes, gt = synth.make_faces(512, seed=41003)
+    images, boxes, gt = synth.make_faces(8192, seed=41003)
     _, x0, _ = synth.make_samples(boxes, gt, ids, 0, seed=41004)
     got = sdo.test(x0, None, HogTransform(images, [HoGParam(*p) for p in params], ids, ibug.RIGHT_EYE_IDS, ibug.LEFT_EYE_IDS, None))
     oregs = []
@@ -151,4 +169,7 @@ def test_rcr68_detect_shard_matches_oracle(built):
     osdo = orc.SupervisedDescentOptimiser(oregs, orc.InterEyeDistanceNormalisation(re, le))
     ohog = orc.HogTransform(images, [orc.HoGParam(*p) for p in params], re, le, None, n_threads=os.cpu_count() or 1)
     want = osdo.test(x0, None, ohog)
+    per_face = np.linalg.norm((got - want).astype(np.float64), axis=1) / np.linalg.norm(want.astype(np.float64), axis=1)
+    print("RCR-68 shard of 8 192: rel-L2 %.2e, worst face %.2e, faces above 1e-4: %d" % (rel_l2(got, want), per_face.max(), int((per_face > 1e-4).sum())))
     assert rel_l2(got, want) < 1e-4
+    assert np.median(per_face) < 2e-7 and (per_face > 1e-4).sum() <= 16      # (a cvRound on a knife edge sends a face down the other, equally valid path)

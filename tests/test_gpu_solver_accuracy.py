@@ -42,3 +42,32 @@ def test_wide_right_hand_sides(built, M):
     want = np.linalg.solve(G, A.astype(np.float64).T @ b.astype(np.float64))
     assert R.shape == (F, M)
     assert np.abs(R - want).max() <= 6e-6 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("decades,expect_f32", [(1.5, False), (3.0, True)], ids=["diagonal-span-2^20", "diagonal-span-2^33"])
+def test_badly_scaled_columns(built, decades, expect_f32):
+    """sdm_solve_normal_equations is a public entry point for arbitrary data, and while 40 or more trailing
+    tiles are left (here the first 19 of 59 panel steps) the blocked Cholesky's trailing updates run on float16 pieces with ONE
+    power-of-two scale per factorisation.  Columns scaled over +-`decades` decades.  Measured at F = 9 000 (scripts/
+    r4_scaled_solve.py, profiles/r04_scaled_solve.txt): up to a diagonal span of 2^20 the float16 updates are as accurate as the f32
+    ones (worst row 7.8e-5 against 1.1e-4, prediction 4.2e-6 against 4.4e-6); beyond it the factorisation must notice (smallest /
+    largest diagonal entry, read back once) and run its updates on the f32 kernel.  Accuracy against float64: the prediction A R
+    (scale-free) and the rows of R (row j scales with 1 / s_j)."""
+    F, N, M = 7500, 8100, 6
+    rng = np.random.default_rng(7500 + int(decades))
+    s = (10.0 ** rng.uniform(-decades, decades, F)).astype(np.float32)
+    A = rng.standard_normal((N, F)).astype(np.float32) * s[None, :]
+    b = rng.standard_normal((N, M)).astype(np.float32)
+    ctx = Context(0)
+    before = ctx.update_fallbacks()
+    R, lam = ctx.solve_normal_equations(A, b, 0, 1.0, True)
+    took_f32 = ctx.update_fallbacks() - before
+    ctx.close()
+    A64 = A.astype(np.float64)
+    G = A64.T @ A64 + np.eye(F)
+    want = np.linalg.solve(G, A64.T @ b.astype(np.float64))
+    row_err = np.abs(R - want).max(axis=1) / np.abs(want).max(axis=1)
+    pred = np.linalg.norm(A64 @ (R - want)) / np.linalg.norm(A64 @ want)
+    print("column scales over +-%.1f decades: f32 updates %d, rows worst %.2e median %.2e, prediction %.2e" % (decades, took_f32, row_err.max(), np.median(row_err), pred))
+    assert (took_f32 == 1) == expect_f32
+    assert pred <= 2e-5 and np.median(row_err) <= 6e-5 and row_err.max() <= 1e-3
