@@ -1088,34 +1088,7 @@ __host__ __device__ inline size_t packed_scratch_bytes(int C, int O = 4)
 // (the finish scratch overlays the column rows, which are all zero between two passes)
 // (the generic instance issues its image loads two rows ahead without looking: entries S and S + 1 repeat the last row; the
 //  instances specialised on the cell size know at compile time where the ROI ends and keep S entries)
-// Round 4: the per-row entries no longer live in LDS at all (HP_ROWREG).  The ablation profiles/r04_hog_ablations.txt priced the two
-// broadcast LDS reads per pixel row (this table + the band-slot weights) at 23 % of the kernel -- more than all of the resize
-// arithmetic (4 %): every one is a dependent round trip through a queue that 24 waves keep ~60 % busy.  Lane d still holds the
-// taps of coordinate d in registers, so row y's entry is four v_readlane (scalar operands of the address adds and of the two
-// vertical multiplies), and the specialised instances take the band-slot weights as compile-time constants (PackedWs).
-#ifndef HP_ROWREG
-#define HP_ROWREG 0      /* measured: 1.188 against 1.147 ms (sum of the four levels) -- the four v_readlane per row cost more than the two LDS reads */
-#endif
-__host__ __device__ inline size_t packed_rowtab_bytes(int S, bool spec = false) { return HP_ROWREG ? 0 : (size_t)(S + (spec ? 0 : 2)) * 16; }
-// band-slot weights {slot 0, slot 1} of resized-ROI row d, evaluated at compile time with the host's expressions
-// (sdm_set_model_geometry's lv.row_tab, hog.c:697-704); sdm_hog_plan_build compares the two bit for bit before a specialised
-// instance may be chosen
-template <int CELL, int TC>
-struct PackedWs {
-    float w[64][2];
-    constexpr PackedWs() : w{}
-    {
-        for (int d = 0; d < 64 && d < CELL * TC; ++d) {
-            const float hx = (float)((d + 0.5) / (double)CELL - 0.5);
-            int b = (int)hx;
-            if (!(hx >= 0.0f || (float)b == hx)) b -= 1;
-            const float w2 = hx - (float)b, w1 = (float)(1.0 - w2);
-            const float wlo = b >= 0 ? w1 : 0.0f, whi = b + 1 <= TC - 1 ? w2 : 0.0f;
-            w[d][0] = (b & 1) ? whi : wlo;
-            w[d][1] = (b & 1) ? wlo : whi;
-        }
-    }
-};
+__host__ __device__ inline size_t packed_rowtab_bytes(int S, bool spec = false) { return (size_t)(S + (spec ? 0 : 2)) * 16; }
 __host__ __device__ inline size_t packed_lds_bytes(int C, int O, int S, int hist_slots, bool spec = false)
 {
     return al16(HP_ROWS_BYTES(O)) + packed_rowtab_bytes(S, spec) + hist_slots * al16(HP_HIST_BYTES(O, C * C)) + (HP_OVERLAY ? 0 : packed_scratch_bytes(C, O));
@@ -1124,7 +1097,7 @@ __host__ __device__ inline size_t packed_lds_bytes(int C, int O, int S, int hist
 // workgroup behind the waves' regions, read per row with a broadcast 8-byte LDS read straight into the register pair the
 // packed multiply-add takes (scalar loads of them cannot stay in SGPRs over an unrolled ROI: the compiler spilled them to
 // vector lanes and paid two v_readlane per row)
-__host__ __device__ inline size_t packed_wstab_bytes(int S) { return HP_ROWREG ? 0 : al16((size_t)S * 8); }
+__host__ __device__ inline size_t packed_wstab_bytes(int S) { return al16((size_t)S * 8); }
 __host__ __device__ inline size_t packed_wg_lds_bytes(int C, int O, int S, int hist_slots, bool spec)
 {
     return packed_lds_bytes(C, O, S, hist_slots, spec) * HP_WAVES + (spec ? packed_wstab_bytes(S) : 0);
@@ -1356,9 +1329,7 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
     wave_sync();
     // the per-row table: every lane reads entry y with ONE broadcast LDS read per row (no v_readlane, no scalar decoding);
     // entries S and S + 1 (the row loop issues its loads two rows ahead) repeat the last row
-    if (HP_ROWREG) {
-        // (nothing in LDS: row y's entry is read out of lane min(y, S - 1) of row_ent with v_readlane)
-    } else if (SPEC) {
+    if (SPEC) {
         // specialised layout: entry e = {offsets of row e + 2, weights of row e}: the row loop wants exactly that pair at row e, in
         // ONE 16-byte broadcast read; the offsets of rows 0 and 1 (issued before the loop) sit in the last two entries
         if (lane < S) {
@@ -1369,8 +1340,8 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
     } else if (lane < S + 2) rowtab[lane] = row_ent;
     // (every wave of the workgroup writes the same values; a wave's own LDS accesses execute in order, so it reads what it -- or
     //  a neighbour, identically -- wrote: no workgroup barrier)
-    if (!HP_ROWREG && SPEC && lane < S) wstab[lane] = (f32x2){lv.row_tab[lane][0], lv.row_tab[lane][1]};
-    if (!HP_ROWREG && !SPEC && S + 2 > 64 && lane < S + 2 - 64) {
+    if (SPEC && lane < S) wstab[lane] = (f32x2){lv.row_tab[lane][0], lv.row_tab[lane][1]};
+    if (!SPEC && S + 2 > 64 && lane < S + 2 - 64) {
         i32x4 last;
 #pragma unroll
         for (int k = 0; k < 4; ++k) last[k] = __builtin_amdgcn_readlane(row_ent[k], 63);
@@ -1441,15 +1412,10 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
 
         // ---- row loop ----------------------------------------------------------------------------------------------------------
         // the image loads of row y: the two source rows' byte offsets come from the row table (one broadcast 8-byte LDS read)
-        const i32x2 abl_rr = HP_ROWREG ? (i32x2){0, 0} : *(const i32x2*)&rowtab[0], abl_bb = HP_ROWREG ? (i32x2){1 << 22, 1 << 22} : *((const i32x2*)&rowtab[0] + 1);
-        const f32x2 abl_ws = (!HP_ROWREG && SPEC) ? wstab[0] : (f32x2){0.5f, 0.5f};
+        const i32x2 abl_rr = *(const i32x2*)&rowtab[0], abl_bb = *((const i32x2*)&rowtab[0] + 1);
+        const f32x2 abl_ws = SPEC ? wstab[0] : (f32x2){0.5f, 0.5f};
         auto issue_row = [&](int y, unsigned short& q0, unsigned short& q1) {
-            i32x2 rr;
-            if (HP_ABL == 7 || HP_ABL == 11) rr = abl_rr;
-            else if (HP_ROWREG) {      // byte offsets of row y's two source rows: scalar operands of the two address adds
-                const int yl = y < S ? y : S - 1;      // (generic instance: the two loads issued past the last row repeat it)
-                rr = (i32x2){__builtin_amdgcn_readlane(row_ent.x, yl), __builtin_amdgcn_readlane(row_ent.y, yl)};
-            } else rr = *(const i32x2*)&rowtab[SPEC ? (y >= 2 ? y - 2 : y + S - 2) : y];
+            const i32x2 rr = (HP_ABL == 7 || HP_ABL == 11) ? abl_rr : *(const i32x2*)&rowtab[SPEC ? (y >= 2 ? y - 2 : y + S - 2) : y];
             if (HP_ABL == 4) { q0 = (unsigned short)(vb + rr.x); q1 = (unsigned short)(vb + rr.y); return; }
             // (the row offset stays in the VECTOR offset: the hardware range check that yields the black canvas covers voffset only)
             q0 = __builtin_amdgcn_raw_buffer_load_b16(img_rsrc, vb + rr.x, 0, 0);
@@ -1462,10 +1428,6 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
         };
         auto vertical = [&](int H0, int H1, int y) -> float {
             if (HP_ABL == 8) return (float)(H0 + H1);
-            if (HP_ROWREG && HP_ABL != 7) {      // the row's two weights << 12 as scalar operands
-                const unsigned b0 = (unsigned)__builtin_amdgcn_readlane(row_ent.z, y), b1 = (unsigned)__builtin_amdgcn_readlane(row_ent.w, y);
-                return (float)(int)((mul_hi_u24(b0, (unsigned)H0 & ~15u) + mul_hi_u24(b1, (unsigned)H1 & ~15u) + 2u) >> 2);
-            }
             const i32x2 bb = (HP_ABL == 7 || HP_ABL == 12) ? abl_bb : *((const i32x2*)&rowtab[y] + 1);      // the row's two weights << 12
             const int out = (int)((mul_hi_u24_vv((unsigned)bb.x, (unsigned)H0 & ~15u) + mul_hi_u24_vv((unsigned)bb.y, (unsigned)H1 & ~15u) + 2u) >> 2);
             return (float)out;
@@ -1608,7 +1570,6 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
                 const float* rt = lv.row_tab[yy];
                 f32x2 wsv;
                 if (HP_ABL == 7 || HP_ABL == 12) wsv = abl_ws;
-                else if (SPEC && HP_ROWREG) { constexpr PackedWs<(CELL > 0 ? CELL : 1), TC> WS{}; wsv = (f32x2){WS.w[yy][0], WS.w[yy][1]}; }
                 else if (SPEC) wsv = wstab[yy];
                 else wsv = (f32x2){rt[0], rt[1]};
                 const float ws0 = wsv.x, ws1 = wsv.y;
@@ -1783,16 +1744,6 @@ bool sdm_hog_plan_build(const HogLevelDev& lv, int L, HogPlanHost& out)
     for (int d = 0; d < S; ++d) {      // the specialised instances compute the band of a row in integers: must equal the table
         int b; memcpy(&b, &lv.row_tab[d][2], sizeof(int));
         if (b != packed_band_of(d, lv.cell)) return false;
-    }
-    // ... and take the band-slot weights as compile-time constants: must equal the table bit for bit
-    {
-        bool same = true;
-        auto cmp = [&](const float (*w)[2]) { for (int d = 0; d < S; ++d) if (memcmp(&w[d][0], &lv.row_tab[d][0], 4) || memcmp(&w[d][1], &lv.row_tab[d][1], 4)) same = false; };
-        if (lv.cell == 11) { static const PackedWs<11, 5> W; cmp(W.w); }
-        else if (lv.cell == 10) { static const PackedWs<10, 5> W; cmp(W.w); }
-        else if (lv.cell == 8) { static const PackedWs<8, 5> W; cmp(W.w); }
-        else if (lv.cell == 6) { static const PackedWs<6, 5> W; cmp(W.w); }
-        if (!same) return false;
     }
     std::vector<std::vector<PlanLane>> tmp;
     // group size: fewest passes per sample; among equals at least two passes per wave (the per-group set-up is then shared),
