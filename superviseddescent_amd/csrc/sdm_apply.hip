@@ -572,20 +572,15 @@ void sdm_launch_landmark_errors(const float* x, const float* xstar, int N, int L
 // the LDS-staged kernel serves narrow outputs (<= 3 column tiles) on batches that fill the chip
 // The LDS-staged kernel serves every output width on batches that fill the chip: 64-row blocks (four waves) for narrow outputs
 // (<= 3 column tiles: RCR-22), 128-row blocks (eight waves, the regressor slab staged once per 128 rows) for 4 ... 9 column tiles
-// (RCR-68: 703 -> 544 us per level at 8 192 x 27 201 x 136, 86 -> 111.5 TF; 64-row blocks: 632 us).  SDM_APPLY_PARTIAL=1 forces the
-// direct-to-register kernel (A/B).
+// (RCR-68: 703 -> 544 us per level at 8 192 x 27 201 x 136, 86 -> 111.5 TF; 64-row blocks: 632 us).  
 static bool apply_use_tiled(int N, int M)
 {
-    static const bool force_partial = getenv("SDM_APPLY_PARTIAL") && getenv("SDM_APPLY_PARTIAL")[0] == '1';
     const int nt = (M + 15) / 16;
-    return !force_partial && nt <= 9 && N >= 2048;
+    return nt <= 9 && N >= 2048;
 }
 static int apply_bm(int M)
 {
-    static const int forced = getenv("SDM_APPLY_BM") ? atoi(getenv("SDM_APPLY_BM")) : 0;      // (A/B: 64 or 128 rows per workgroup)
-    if (forced == 64 && (M + 15) / 16 <= 3) return 64;
-    if (forced == 128) return 128;
-    return (M + 15) / 16 <= 3 ? AT_BM : 128;
+    return (M + 15) / 16 <= 3 ? AT_BM : 128;      // (rows-per-workgroup / split-K sweep: profiles/r03 apply experiments; 64 x 8 splits stays best at RCR-22)
 }
 
 int sdm_apply_splits(int N, int F, int M)
@@ -595,8 +590,6 @@ int sdm_apply_splits(int N, int F, int M)
         const int row_blocks = (N + bm - 1) / bm, kslabs = (F + AT_BK - 1) / AT_BK;
         int splits = ((bm == 128 ? 256 : 512) + row_blocks - 1) / row_blocks;     // two 61 KB workgroups per CU (64 rows), one of 90 - 139 KB (128 rows)
         if (splits > kslabs / 4) splits = kslabs / 4;
-        static const int forced_splits = getenv("SDM_APPLY_SPLITS") ? atoi(getenv("SDM_APPLY_SPLITS")) : 0;      // (A/B)
-        if (forced_splits > 0) splits = forced_splits;
         return splits < 1 ? 1 : (splits > 64 ? 64 : splits);
     }
     // enough workgroups to cover 256 CUs a few times over, but at least 4 k-groups per wave

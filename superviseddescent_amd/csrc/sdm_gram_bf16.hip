@@ -19,8 +19,7 @@
 //   syrk_tn_split_w8p_kernel  two float16 pieces; workgroup = 256 x 128 tile (two tile rows x one tile column of the upper
 //                             triangle + right-hand-side columns), eight waves of 64 x 64, K in slabs of 16 rows: 24 KB straight
 //                             into LDS (four buffers), fragments of slab s + 1 read while slab s is multiplied
-//   syrk_tn_bf16x3_w_kernel   the same tile on sixteen waves of 64 x 32, compiler-scheduled: three bf16 pieces (the fallback), or
-//                             two float16 pieces (SDM_GRAM_WAVES16=1, A/B)
+//   syrk_tn_bf16x3_w_kernel   the same tile on sixteen waves of 64 x 32, compiler-scheduled: three bf16 pieces (the fallback)
 // What was tried on the way (128 x 128 and 256 x 256 tiles, register-staged and in-kernel splitting, 32-row slabs, two bf16 pieces,
 // deeper load queues, eight waves without the fragment prefetch, ablations of loads / fragment reads / barriers) is kept as
 // scripts/experiments/gram_16bit_variants.patch with the measurements in profiles/r03_gram_16bit_experiments.txt.
@@ -532,8 +531,7 @@ static const std::vector<int>& gram_tile_order_w(int T)
     std::vector<int>& o = cache[T];
     if (!o.empty()) return o;
     const int TI = (T + 1) / 2;
-    static const int BH = getenv("SDM_GRAM_BLOCK_H") ? atoi(getenv("SDM_GRAM_BLOCK_H")) : 4;      // (A/B of the block shape)
-    static const int BW = getenv("SDM_GRAM_BLOCK_W") ? atoi(getenv("SDM_GRAM_BLOCK_W")) : 8;
+    const int BH = 4, BW = 8;      // block shape (super-rows x tile columns): moves the fabric traffic by 1.5x and the time not at all (profiles/r03_gram_pmc.txt)
     std::vector<int> seq;
     for (int bi = 0; bi * BH < TI; ++bi)
         for (int bj = 0; bj * BW < T; ++bj)
@@ -572,17 +570,12 @@ void sdm_launch_gram_bf16x3(const float* A, long long lda, int N, int ncols, voi
     if (sdm_first_use_on_device(attr)) {
         SDM_SET_ATTR((const void*)syrk_tn_split_w8p_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         SDM_SET_ATTR((const void*)syrk_tn_bf16x3_w_kernel<3, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        SDM_SET_ATTR((const void*)syrk_tn_bf16x3_w_kernel<3, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     const std::vector<int>& ow = gram_tile_order_w(ncols / GB_TILE);
     int* d_ow = (int*)((unsigned char*)planes + (f16_flag ? 2 : 3) * (size_t)NG * (size_t)ncols2 * 16);      // (the table lives behind the planes of this form; the vector is cached for the process)
     (void)hipMemcpyAsync(d_ow, ow.data(), ow.size() * sizeof(int), hipMemcpyHostToDevice, stream);
-    static const bool waves16 = getenv("SDM_GRAM_WAVES16") && atoi(getenv("SDM_GRAM_WAVES16")) != 0;      // A/B: the sixteen-wave float16 kernel
-    if (f16_flag && !waves16)
+    if (f16_flag)
         hipLaunchKernelGGL(syrk_tn_split_w8p_kernel<4>, dim3((unsigned)ow.size()), dim3(512), (size_t)4 * (2 * 2 * 384) * 16, stream,
-                           (const bf16x8*)planes, NG, ncols2, ncols, C, ldc, d_ow, (int)ow.size());
-    else if (f16_flag)
-        hipLaunchKernelGGL((syrk_tn_bf16x3_w_kernel<3, 2, true>), dim3((unsigned)ow.size()), dim3(1024), (size_t)3 * (2 * 2 * 384) * 16, stream,
                            (const bf16x8*)planes, NG, ncols2, ncols, C, ldc, d_ow, (int)ow.size());
     else
         hipLaunchKernelGGL((syrk_tn_bf16x3_w_kernel<3, 3, false>), dim3((unsigned)ow.size()), dim3(1024), (size_t)3 * (3 * 2 * 384) * 16, stream,

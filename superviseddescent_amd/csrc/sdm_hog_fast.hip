@@ -1837,11 +1837,9 @@ static void launch_hog_packed(const ImageSetDev& imgs, const int* img_idx, const
         if (plan.raw_sqrt) HP_LAUNCH_O(9, 0, true); else HP_LAUNCH_O(9, 0, false);
         return;
     }
-    // instances specialised on the shipped cell sizes (apps/rcr/rcr-train.cpp:447: 11, 10, 8, 6); any other cell size, a level
-    // whose v_sqrt_f32 verdict is negative, or SDM_HOG_NO_SPECIALISE=1 (A/B measurements) run the generic instance
-    static const bool no_spec = getenv("SDM_HOG_NO_SPECIALISE") && getenv("SDM_HOG_NO_SPECIALISE")[0] == '1';
+    // instances specialised on the shipped cell sizes (apps/rcr/rcr-train.cpp:447: 11, 10, 8, 6); any other cell size or a level
+    // whose fast-arithmetic verdict is negative run the generic instance
     if (!plan.raw_sqrt) { HP_LAUNCH(0, false); return; }
-    if (no_spec) { HP_LAUNCH(0, true); return; }
     switch (lv.cell) {
     case 11: HP_LAUNCH(11, true); break;
     case 10: HP_LAUNCH(10, true); break;

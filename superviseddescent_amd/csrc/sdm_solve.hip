@@ -150,100 +150,6 @@ __device__ inline void glds16_solve(const float* g, float* lds_dst)
 {
     __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
-template <bool CHUNKED>
-__global__ void __launch_bounds__(256)
-syrk_tn_glds_kernel(const float* __restrict__ A, long long lda, int rows, float* __restrict__ C, long long ldc,
-                    float alpha, int accumulate, int tile_i0, int own_first, int own_stride)
-{
-    const int ti = blockIdx.y + tile_i0, tj = tile_i0 + own_first + blockIdx.x * own_stride;
-    if (tj < ti) return;
-    extern __shared__ __attribute__((aligned(16))) float glds[];      // [2 buffers][A | B][SYRK_GBK][TILE]
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const bool diag = (ti == tj);
-    const float* Ai = A + (long long)ti * TILE;
-    const float* Aj = A + (long long)tj * TILE;
-
-    f32x16 acc[2][2], tot[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { acc[m][n][e] = 0.0f; tot[m][n][e] = 0.0f; }
-
-    // thread t fetches float4 number (t % 32) of slab rows t/32 + 8p; a wave's 64 lanes cover rows 2w+8p, 2w+8p+1
-    const int lrow = t >> 5, lcol = (t & 31) * 4;
-    auto issue = [&](int s, int buf) {
-        float* a = glds + (size_t)buf * 2 * SYRK_GBK * TILE;
-        float* b = a + SYRK_GBK * TILE;
-#pragma unroll
-        for (int p = 0; p < SYRK_GBK / 8; ++p) {
-            const long long n = (long long)s * SYRK_GBK + lrow + 8 * p;
-            // LDS destination: wave-uniform base (+ lane * 16 bytes, added by the hardware)
-            float* la = a + (2 * wave + 8 * p) * TILE;
-            __builtin_amdgcn_global_load_lds(Ai + n * lda + lcol, (__attribute__((address_space(3))) void*)la, 16, 0, 0);
-            if (!diag) {
-                float* lb = b + (2 * wave + 8 * p) * TILE;
-                __builtin_amdgcn_global_load_lds(Aj + n * lda + lcol, (__attribute__((address_space(3))) void*)lb, 16, 0, 0);
-            }
-        }
-    };
-    const int nslabs = rows / SYRK_GBK;
-    constexpr int chunk = SYRK_CHUNK * SYRK_BK / SYRK_GBK;      // slabs per 256-row chunk
-    issue(0, 0);
-    // Two nested loops, not one loop with an "every 8th slab" branch: inside the inner loop the accumulators are touched by
-    // MFMAs only and stay in the accumulation registers; with the branch the compiler kept them in VGPRs across the back-edge
-    // and copied all 64 of them to the AGPRs and back around the MFMAs of EVERY slab (128 v_accvgpr moves + a drain of the
-    // matrix pipeline per 64 MFMAs: 9 % of the Gram launch, found with a loads-only / compute-only ablation in round 2).
-    const int step = CHUNKED ? chunk : nslabs;
-    for (int c0 = 0; c0 < nslabs; c0 += step) {
-        const int c1 = c0 + step < nslabs ? c0 + step : nslabs;
-        for (int s = c0; s < c1; ++s) {
-            __syncthreads();                 // slab s has landed (the barrier drains the LDS-direct loads); buffer (s+1)%2 is free
-            if (s + 1 < nslabs) issue(s + 1, (s + 1) & 1);
-            const float (*As)[TILE] = (const float (*)[TILE])(glds + (size_t)(s & 1) * 2 * SYRK_GBK * TILE);
-            const float (*Bp)[TILE] = diag ? As : (const float (*)[TILE])(glds + (size_t)(s & 1) * 2 * SYRK_GBK * TILE + SYRK_GBK * TILE);
-#pragma unroll
-            for (int kk = 0; kk < SYRK_GBK; kk += 2) {
-                const int k = kk + (lane >> 5);
-                float a[2], b[2];
-#pragma unroll
-                for (int m = 0; m < 2; ++m) a[m] = As[k][wr * 64 + m * 32 + (lane & 31)];
-#pragma unroll
-                for (int n = 0; n < 2; ++n) b[n] = Bp[k][wc * 64 + n * 32 + (lane & 31)];
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
-            }
-        }
-        if (CHUNKED) {   // fold the chunk
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) { tot[m][n][e] += acc[m][n][e]; acc[m][n][e] = 0.0f; }
-        }
-    }
-    // C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int r = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                const long long gi = (long long)ti * TILE + wr * 64 + m * 32 + r;
-                const long long gj = (long long)tj * TILE + wc * 64 + n * 32 + (lane & 31);
-                float* p = C + gi * ldc + gj;
-                float v = alpha * (CHUNKED ? tot[m][n][e] : acc[m][n][e]);
-                if (accumulate) v += *p;
-                *p = v;
-            }
-}
 
 
 // ---- the Gram instance (round 3): EIGHT waves per 128 x 128 tile -- wave = (32-row strip wr of 4) x (64-column half wc of 2), two
@@ -729,109 +635,6 @@ trsm_tile_kernel(float* __restrict__ G, long long ldg, int k0, int tile_j0, int 
         for (int e = 0; e < 4; ++e) B[(long long)(IB * rb + 4 * lq + e) * ldb + IB * wave + li] = acc[rb][e];
 }
 
-// ---- back substitution, one launch per tile step k (descending) ------------------------------------------------
-// every workgroup first forms R_k = U_kk^-1 Y_k = (W^T)^T Y_k from the stored transposed inverse (a 128x128x nrhs
-// product, redundantly: it is cheaper than a launch boundary); workgroup k stores it, workgroup i < k then updates
-// Y_i -= U_ik R_k.  Thread (tr, tc) owns rows tr+16a and columns tc+16b.
-template <int NJ>
-__global__ void __launch_bounds__(256)
-backsolve_step_kernel(float* __restrict__ G, long long ldg, int k0, int rhs0, const float* __restrict__ winv_t,
-                      float* __restrict__ R_base, long long ldr, int col0)
-{
-    // this launch handles the RHS columns [col0, col0 + 16*NJ) (wide right-hand sides are processed in column chunks).
-    // Both 128 x 128 x nrhs products run on the f32 matrix cores (v_mfma_f32_16x16x4_f32): wave w owns rows 32w..32w+31
-    // (two 16-row tiles) x NJ 16-column tiles; lane (li, lq) feeds A[row li][k lq] and B[k lq][col li].
-    constexpr int nrhs = NJ * 16;
-    rhs0 += col0;
-    float* R = R_base + col0;
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* A = sm;                          // [128][128+4]: first W^T (k-major for the product), then U_ik
-    float* Yk = sm + TILE * (TILE + 4);     // [128][nrhs]
-    float* Rk = Yk + TILE * nrhs;           // [128][nrhs]
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int li = lane & 15, lq = lane >> 4;
-    const int k = k0 / TILE;
-    const bool last = (int)blockIdx.x == k;
-    const int lr = t >> 5, lc = (t & 31) * 4;
-    const float* Yg = G + (long long)k0 * ldg + rhs0;
-    // U_ik of the second product is fetched now, into registers: its memory round trip runs under the first product
-    const long long i0 = (long long)blockIdx.x * TILE;
-    const float* Uik = G + i0 * ldg + k0;
-    f32x4s upre[TILE / 8];
-    if (!last) {
-#pragma unroll
-        for (int q = 0; q < TILE / 8; ++q) upre[q] = *(const f32x4s*)(Uik + (long long)(lr + 8 * q) * ldg + lc);
-    }
-    for (int r = lr; r < TILE; r += 8) *(f32x4s*)(A + r * (TILE + 4) + lc) = *(const f32x4s*)(winv_t + r * TILE + lc);
-    for (int idx = t; idx < TILE * nrhs; idx += 256) {
-        const int r = idx / nrhs, cc = idx - r * nrhs;     // nrhs is a compile-time constant here
-        Yk[idx] = Yg[(long long)r * ldg + cc];
-    }
-    __syncthreads();
-    f32x4 acc[2][NJ];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < NJ; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // R_k[r][c] = sum_m W^T[m][r] * Y_k[m][c]
-#pragma unroll 4
-    for (int kk = 0; kk < TILE / 4; ++kk) {
-        const int m = 4 * kk + lq;
-        float av[2], bv[NJ];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) av[a] = A[m * (TILE + 4) + 32 * wave + 16 * a + li];
-#pragma unroll
-        for (int b = 0; b < NJ; ++b) bv[b] = Yk[m * nrhs + 16 * b + li];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < NJ; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
-    }
-    // C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + e
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < NJ; ++b)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int row = 32 * wave + 16 * a + 4 * lq + e, col = 16 * b + li;
-                Rk[row * nrhs + col] = acc[a][b][e];
-                if (last) R[(long long)(k0 + row) * ldr + col] = acc[a][b][e];
-            }
-    if (last) return;
-    __syncthreads();
-    // Y_i -= U_ik * R_k
-    float* Yi = G + i0 * ldg + rhs0;
-#pragma unroll
-    for (int q = 0; q < TILE / 8; ++q) *(f32x4s*)(A + (lr + 8 * q) * (TILE + 4) + lc) = upre[q];
-    __syncthreads();
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < NJ; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int kk = 0; kk < TILE / 4; ++kk) {
-        const int m = 4 * kk + lq;
-        float av[2], bv[NJ];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) av[a] = A[(32 * wave + 16 * a + li) * (TILE + 4) + m];
-#pragma unroll
-        for (int b = 0; b < NJ; ++b) bv[b] = Rk[m * nrhs + 16 * b + li];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < NJ; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
-    }
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < NJ; ++b)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int row = 32 * wave + 16 * a + 4 * lq + e, col = 16 * b + li;
-                Yi[(long long)row * ldg + col] -= acc[a][b][e];
-            }
-}
 
 
 // ---- back substitution in ONE launch (round 3) -------------------------------------------------------
@@ -970,30 +773,15 @@ void sdm_launch_syrk_tn(const float* A, long long lda, int rows, int ncols, floa
     }
     if (rows % SYRK_GBK == 0) {      // LDS-direct staging
         const size_t lds = (size_t)2 * 2 * SYRK_GBK * TILE * sizeof(float);      // 64 KB
-        static unsigned long long attr_seen = 0;
-        if (sdm_first_use_on_device(attr_seen)) {
-            sdm_check_launch_attr(hipFuncSetAttribute((const void*)syrk_tn_glds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "syrk_tn_glds_kernel");
-            sdm_check_launch_attr(hipFuncSetAttribute((const void*)syrk_tn_glds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "syrk_tn_glds_kernel");
+        static unsigned long long attr8 = 0;
+        if (sdm_first_use_on_device(attr8)) {
+            sdm_check_launch_attr(hipFuncSetAttribute((const void*)syrk_tn_gldsw_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "syrk_tn_gldsw_kernel<8>");
+            sdm_check_launch_attr(hipFuncSetAttribute((const void*)syrk_tn_gldsw_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "syrk_tn_gldsw_kernel<8,false>");
         }
-        static const bool w8 = !(getenv("SDM_GRAM_W4") && getenv("SDM_GRAM_W4")[0] == '1');      // (SDM_GRAM_W4=1: the four-wave instance, A/B)
-        if (chunked && w8) {
-            static unsigned long long attr8 = 0;
-            if (sdm_first_use_on_device(attr8)) {
-                sdm_check_launch_attr(hipFuncSetAttribute((const void*)syrk_tn_gldsw_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "syrk_tn_gldsw_kernel<8>");
-            }
-            hipLaunchKernelGGL((syrk_tn_gldsw_kernel<8, true>), dim3(Tx, Ty), dim3(512), lds, stream, A, lda, rows, C, ldc, alpha, accumulate, tile_i0, first, W);
-        } else if (chunked)
-            hipLaunchKernelGGL(syrk_tn_glds_kernel<true>, dim3(Tx, Ty), dim3(256), lds, stream, A, lda, rows, C, ldc, alpha, accumulate, tile_i0, first, W);
-        else {
-            // (round 3: eight waves per tile for the Cholesky's trailing updates as well: factor + solve 83.5 -> 78.7 ms at F = 27 201,
-            //  7.22 -> 7.07 ms at F = 8 801; SDM_UPDATE_W4=1: the four-wave instance, A/B)
-            static const bool upd8 = !(getenv("SDM_UPDATE_W4") && getenv("SDM_UPDATE_W4")[0] == '1');
-            static unsigned long long attru = 0;
-            if (sdm_first_use_on_device(attru))
-                sdm_check_launch_attr(hipFuncSetAttribute((const void*)syrk_tn_gldsw_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "syrk_tn_gldsw_kernel<8,false>");
-            if (upd8) hipLaunchKernelGGL((syrk_tn_gldsw_kernel<8, false>), dim3(Tx, Ty), dim3(512), lds, stream, A, lda, rows, C, ldc, alpha, accumulate, tile_i0, first, W);
-            else hipLaunchKernelGGL(syrk_tn_glds_kernel<false>, dim3(Tx, Ty), dim3(256), lds, stream, A, lda, rows, C, ldc, alpha, accumulate, tile_i0, first, W);
-        }
+        // eight waves per tile (round 3; the four-wave kernel of rounds 1-2 measured 68.4 -> 66.8 ms at 100 000 x 8 801 and 83.5 -> 78.7 ms
+        // factor + solve at F = 27 201 against it and is retired)
+        if (chunked) hipLaunchKernelGGL((syrk_tn_gldsw_kernel<8, true>), dim3(Tx, Ty), dim3(512), lds, stream, A, lda, rows, C, ldc, alpha, accumulate, tile_i0, first, W);
+        else hipLaunchKernelGGL((syrk_tn_gldsw_kernel<8, false>), dim3(Tx, Ty), dim3(512), lds, stream, A, lda, rows, C, ldc, alpha, accumulate, tile_i0, first, W);
     } else if (chunked)
         hipLaunchKernelGGL(syrk_tn_kernel<true>, dim3(Tx, Ty), dim3(256), 0, stream, A, lda, rows, C, ldc, alpha,
                            accumulate, tile_i0, first, W);
@@ -1167,9 +955,6 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
     if (sdm_first_use_on_device(attr_seen)) {
         SDM_SET_ATTR((const void*)potrf_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         SDM_SET_ATTR((const void*)trsm_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-#define BSATTR(NJv) SDM_SET_ATTR((const void*)backsolve_step_kernel<NJv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-        BSATTR(1); BSATTR(2); BSATTR(3); BSATTR(4); BSATTR(5);
-#undef BSATTR
     }
     // Panels are processed in groups of LAZY: inside a group only the NEXT tile row receives the pending rank-128
     // updates (a thin launch); the whole trailing matrix is updated once per group with K = 128*LAZY.  That is 1/LAZY of
@@ -1189,7 +974,7 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
     const int LAZY = 4;
     const bool overlap = aux && aux->stream && Tf > 2 * LAZY;
     static const bool upd_f32_only = getenv("SDM_UPDATE_F32") && getenv("SDM_UPDATE_F32")[0] == '1';      // (A/B: every trailing update on the f32 kernel)
-    static const int upd_min_tiles = getenv("SDM_UPDATE_F16_MIN_TILES") ? atoi(getenv("SDM_UPDATE_F16_MIN_TILES")) : 40;
+    const int upd_min_tiles = 40;      // trailing tiles from which the float16-piece update pays (its split pre-pass is per panel group)
     bool upd_f16 = aux && aux->upd_planes && aux->upd_maxdiag && !upd_f32_only;
     if (upd_f16) {
         sdm_launch_diag_absmax(G, ldg, F, aux->upd_maxdiag, stream);
@@ -1282,8 +1067,7 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
     }
     if (tail_pending) (void)hipStreamWaitEvent(stream, aux->tail_done, 0);
     int nj = nrhs / 16;   // nrhs is a multiple of 16, <= 144 (sharded: narrowed to this rank's column tiles below)
-    static const bool bs_steps = getenv("SDM_BACKSOLVE_STEPS") && getenv("SDM_BACKSOLVE_STEPS")[0] == '1';   // (A/B: the round-2 launch per step)
-    if (!bs_steps) {
+    {
         // one persistent launch: Tf workgroups x chunks of <= 5 column tiles; flags (one int per tile row and chunk) behind the
         // inverses in `work`, cleared on the stream
         // Sharded: the right-hand-side columns are independent, so rank r substitutes the column tiles r per ... (r + 1) per - 1 only
@@ -1303,8 +1087,7 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
         const int nj_full = nj;
         nj = bs_n;
         const int rhs_shift = 16 * bs_lo;
-        static const int max_nj = getenv("SDM_BACKSOLVE_MAX_NJ") ? atoi(getenv("SDM_BACKSOLVE_MAX_NJ")) : 5;      // column tiles per workgroup (1 ... 5)
-        const int cap = max_nj < 1 ? 1 : (max_nj > 5 ? 5 : max_nj);
+        const int cap = 5;      // column tiles per workgroup (measured 42.3 / 43.7 / 47.4 / 56.2 ms at F = 27 201 for 5 / 3 / 2 / 1)
         const int nchunks = nj > 0 ? (nj + cap - 1) / cap : 0, NJ = nchunks ? (nj + nchunks - 1) / nchunks : 1;
         int* flags = (int*)(work + (size_t)Tf * TILE * TILE);
         if (nchunks) (void)hipMemsetAsync(flags, 0, (size_t)nchunks * Tf * sizeof(int), stream);
@@ -1335,21 +1118,6 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
                                        recv + (size_t)r * per_rank, 1);
         }
         return 0;
-    }
-    for (int k = Tf - 1; k >= 0; --k) {
-        float* wk = work + (size_t)k * TILE * TILE;
-#define BS(NJv, C0) hipLaunchKernelGGL(backsolve_step_kernel<NJv>, dim3(k + 1), dim3(256), \
-                                       ((size_t)TILE * (TILE + 4) + 2 * (size_t)TILE * NJv * 16) * sizeof(float), stream, G, ldg, k * TILE, rhs0, wk, R_out, ldr, C0)
-        // the right-hand sides are independent per column: at most 5 column tiles (80 columns) per launch keep the
-        // workgroup inside the 160 KB of LDS
-        for (int done = 0; done < nj;) {
-            const int left = nj - done;
-            const int take = left <= 5 ? left : (left >= 8 ? 4 : left - 3);   // 6 -> 3+3, 7 -> 4+3, 8 -> 4+4, 9 -> 4+5
-            switch (take) { case 1: BS(1, done * 16); break; case 2: BS(2, done * 16); break; case 3: BS(3, done * 16); break;
-                            case 4: BS(4, done * 16); break; default: BS(5, done * 16); break; }
-            done += take;
-        }
-#undef BS
     }
     return 0;
 }
