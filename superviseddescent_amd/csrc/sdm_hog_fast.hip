@@ -1242,6 +1242,9 @@ __host__ __device__ constexpr int packed_band_of(int d, int cell)
 #ifndef HP_PAIRFOLD
 #define HP_PAIRFOLD 1               /* CELLS, 4 orientations: the last two bands of a pass in one set of matrix-core products */
 #endif
+#ifndef HP_SPLIT_PASSES
+#define HP_SPLIT_PASSES 1           /* CELLS: one pass per wave instead of one group of patches per wave */
+#endif
 #ifndef HP_MINW_CELLS
 #define HP_MINW_CELLS 6             /* the CELLS form needs 5.1 KB of LDS per wave: seven waves per SIMD fit if the registers do (<= 72) */
 #endif
@@ -1263,13 +1266,20 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
     const unsigned nb = gridDim.x, bid = blockIdx.x;
     const unsigned q8 = nb / 8, r8 = nb % 8, xcd = bid % 8;
     const unsigned blk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / 8;
-    const int gpf = plan.n_main + (plan.Gt > 0 ? 1 : 0);            // groups per sample
+    // work unit of a wave: a group of patches (all its passes), or -- CELLS: the passes share nothing but the group geometry, every
+    // fold stores its cells to HBM -- ONE pass (HP_SPLIT_PASSES): uniform, short waves whose number is a finer multiple of the
+    // 6 144 wave slots of the chip (RCR-22 level 1 at 4 096 faces: 20 480 waves of four or two passes = 3.3 rounds of slots
+    // became 73 728 waves of one pass = 12.0 rounds)
+    constexpr bool SPLIT = CELLS && HP_SPLIT_PASSES;
+    const int gpf = SPLIT ? plan.n_main * plan.P + plan.Pt : plan.n_main + (plan.Gt > 0 ? 1 : 0);      // units per sample
     const long long wid = (long long)blk * HP_WAVES + wave;
     if (wid >= (long long)N * gpf) return;                           // (no workgroup barrier anywhere below)
-    const int s = (int)(wid / gpf), g = (int)(wid - (long long)s * gpf);
+    const int s = (int)(wid / gpf), u = (int)(wid - (long long)s * gpf);
+    const int g = SPLIT ? (u < plan.n_main * plan.P ? u / plan.P : plan.n_main) : u;
     const bool main_group = g < plan.n_main;
     const int lm0 = main_group ? g * plan.G : plan.n_main * plan.G;   // first landmark of the group
-    const int npass = main_group ? plan.P : plan.Pt;
+    const int t_first = SPLIT ? u - g * plan.P : 0;                   // (tail group: u - n_main P)
+    const int npass = SPLIT ? t_first + 1 : (main_group ? plan.P : plan.Pt);
     const int pass0 = main_group ? 0 : plan.P;
     constexpr int SC = TC * CELL;                 // (0 for the generic instance)
     const int S = CELL > 0 ? SC : lv.S;
@@ -1353,7 +1363,7 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
     asm volatile("" : "+v"(spread_sel));
     const int li = lane & 15, lq = lane >> 4;
 
-    for (int t = 0; t < npass; ++t) {
+    for (int t = t_first; t < (HP_ABL == 13 ? t_first : npass); ++t) {
         const int pt = pass0 + t;
         // ---- this lane's column in this pass -----------------------------------------------------------------------------
         const unsigned desc = plan.lane_tab[pt * 64 + lane];
@@ -1595,6 +1605,10 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
         };
         row_step(0, 0, false);
         row_step(1, 1, false);
+        if constexpr (HP_ABL == 14) {      // (timing experiment: the set-up of a pass without its rows)
+            asm volatile("" :: "v"(wq[0]), "v"(wq[1]), "v"(wq[2]), "v"(wq[3]), "v"(hrecv), "v"(recv), "v"(rm1));
+            continue;
+        }
         if constexpr (CELL > 0) {
 #pragma unroll
             for (int yrow = 2; yrow < SC; ++yrow) row_step(yrow & 1, yrow, true);
@@ -1819,7 +1833,7 @@ static void launch_hog_packed(const ImageSetDev& imgs, const int* img_idx, const
                               const EyeIdxDev& eyes, const HogLevelDev& lv, const HogPlanDev& plan, float* feat, long long ldf,
                               int* idx_out, int* status, hipStream_t stream)
 {
-    const int gpf = plan.n_main + (plan.Gt > 0 ? 1 : 0);
+    const int gpf = (CELLS && HP_SPLIT_PASSES) ? plan.n_main * plan.P + plan.Pt : plan.n_main + (plan.Gt > 0 ? 1 : 0);
     const long long total = (long long)N * gpf;
     if (total <= 0) return;
     const unsigned grid = (unsigned)((total + HP_WAVES - 1) / HP_WAVES);
