@@ -226,6 +226,18 @@ int sdm_set_reduce_scatter_rccl(sdm_ctx* ctx, int enable, void* nccl_reduce_scat
  * PartialPivLU: the regularised Gram matrix is SPD).  Stores R as the level's regressor; R_host may be NULL. */
 int sdm_solve(sdm_ctx* ctx, int level, int reg_type, float reg_param, int regularise_last_row,
               long long n_train_global, float* R_host, float* lambda_out);
+/* Which of the reference's two solvers sdm_solve / sdm_solve_normal_equations / sdm_train_level run (LinearRegressor<Solver>,
+ * regressors.hpp:318):
+ *   SDM_SOLVER_CHOLESKY   (default) PartialPivLUSolver's role, regressors.hpp:199-234 -- blocked Cholesky, the SPD system needs no pivoting;
+ *   SDM_SOLVER_COLPIV_QR  ColPivHouseholderQRSolver, regressors.hpp:242-306 -- Householder QR with column pivoting of AtA + reg on the
+ *                         device (csrc/sdm_qr.hip), x = P R^-1 Q^T (At b); "much MUCH slower" there too (level-2 work, 2 F launches), and the
+ *                         one that can tell a singular system: sdm_last_rank.  Replicated only (not with sdm_set_solve_sharding), F <= 38 400. */
+#define SDM_SOLVER_CHOLESKY 0
+#define SDM_SOLVER_COLPIV_QR 1
+int sdm_set_solver(sdm_ctx* ctx, int solver);
+/* Rank of the last column-pivoted QR by Eigen's threshold (|R_kk| > eps * F * max |R_kk|) and the full rank F: what
+ * qr_of_AtA.rank() / isInvertible() report at regressors.hpp:288-292 (the caller prints the warning; the library writes nothing to stdout). */
+int sdm_last_rank(sdm_ctx* ctx, int* rank, int* full_rank);
 /* Stand-alone normal equations for host data (any projection function, not only HOG): what
  * LinearRegressor<Solver>::learn hands to Solver::solve(data, labels, regulariser)
  * (regressors.hpp:199-234, 345-350).  A is n_rows x n_features, b is n_rows x n_outputs (<= 144),

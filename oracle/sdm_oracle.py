@@ -315,10 +315,108 @@ def _unblocked_lu_solve_f32(A: np.ndarray, B: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(B, dtype=f32)
 
 
+def col_piv_householder_qr_f32(A: np.ndarray):
+    """Eigen::ColPivHouseholderQR of a square float matrix, restated in float32 (Eigen is not vendored by the reference,
+    CMakeLists.txt:41 -- "parity unpinned" for this solver beyond its mathematical definition): at step k the remaining column of
+    largest (down-dated) squared norm is swapped to position k (lowest index among equals), the Householder vector of column k
+    below the diagonal is v = a / (a_kk - beta), beta = -sign(a_kk) ||a_k:||, tau = (beta - a_kk) / beta, the reflection
+    I - tau v v^T is applied to the remaining columns and their norms are down-dated by the new row-k entries.  Returns
+    (qr, tau, perm, rank): R on and above the diagonal of qr, the vectors below it; rank = #{|R_kk| > eps * n * max |R_kk|}
+    (Eigen's default threshold, what rank() / isInvertible() at regressors.hpp:289-290 use)."""
+    f32 = np.float32
+    qr = np.array(A, dtype=f32, order="C")
+    n = qr.shape[0]
+    tau = np.zeros(n, f32)
+    perm = np.arange(n)
+    cn = np.zeros(n, f32)
+    for i in range(n):                                        # (rows ascending: the order a plain loop over the column takes)
+        cn += qr[i] * qr[i]
+    maxpiv = f32(0.0)
+    for k in range(n):
+        p = k + int(np.argmax(cn[k:]))                        # first of the maxima
+        if p != k:
+            qr[:, [k, p]] = qr[:, [p, k]]
+            cn[[k, p]] = cn[[p, k]]
+            perm[[k, p]] = perm[[p, k]]
+        col = qr[k + 1:, k]
+        tail = f32(np.sum((col * col).astype(f32), dtype=f32)) if col.size else f32(0.0)
+        c0 = qr[k, k]
+        beta, t = c0, f32(0.0)
+        if tail > 0:
+            beta = f32(np.sqrt(f32(c0 * c0 + tail)))
+            if c0 >= 0:
+                beta = f32(-beta)
+            qr[k + 1:, k] = (col / f32(c0 - beta)).astype(f32)
+            t = f32(f32(beta - c0) / beta)
+        tau[k] = t
+        qr[k, k] = beta
+        maxpiv = max(maxpiv, f32(abs(beta)))
+        if k + 1 < n:
+            v = qr[k + 1:, k]
+            d = (qr[k, k + 1:] + (v @ qr[k + 1:, k + 1:]).astype(f32)).astype(f32)
+            d = (d * t).astype(f32)
+            qr[k, k + 1:] = (qr[k, k + 1:] - d).astype(f32)
+            qr[k + 1:, k + 1:] = (qr[k + 1:, k + 1:] - np.outer(v, d).astype(f32)).astype(f32)
+            cn[k + 1:] = (cn[k + 1:] - qr[k, k + 1:] * qr[k, k + 1:]).astype(f32)
+    thr = f32(np.finfo(f32).eps) * f32(n) * maxpiv
+    rank = int(np.sum(np.abs(np.diagonal(qr)) > thr))
+    return qr, tau, perm, rank
+
+
+def _qr_solve_f32(qr, tau, perm, B):
+    """A^-1 B through the factorisation: Q^T B, back substitution with R, inverse column permutation (float32)."""
+    f32 = np.float32
+    from scipy.linalg import solve_triangular
+    n = qr.shape[0]
+    B = np.array(B, dtype=f32, order="C")
+    for k in range(n):
+        v = qr[k + 1:, k]
+        d = ((B[k] + (v @ B[k + 1:]).astype(f32)).astype(f32) * tau[k]).astype(f32)
+        B[k] = (B[k] - d).astype(f32)
+        if k + 1 < n:
+            B[k + 1:] = (B[k + 1:] - np.outer(v, d).astype(f32)).astype(f32)
+    if np.all(np.diagonal(qr) != 0):
+        Y = solve_triangular(np.triu(qr), B, lower=False, check_finite=False).astype(f32)
+    else:      # a singular R: Eigen divides regardless ("may return garbage", regressors.hpp:291) -- inf / nan, no exception
+        Y = B.copy()
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            for i in range(n - 1, -1, -1):
+                Y[i] = ((Y[i] - (qr[i, i + 1:] @ Y[i + 1:]).astype(f32)) / qr[i, i]).astype(f32)
+    X = np.empty_like(Y)
+    X[perm] = Y
+    return X
+
+
+class ColPivHouseholderQRSolver:
+    """regressors.hpp:242-306: AtA + reg factored by a column-pivoted Householder QR, the invertibility report, the inverse from
+    the factorisation (:293) and x = inverse * At * b (:296), all in float32."""
+
+    def __init__(self):
+        self.rank = None
+        self.full_rank = None
+
+    def solve(self, data: np.ndarray, labels: np.ndarray, regulariser: "Regulariser") -> np.ndarray:
+        A = np.ascontiguousarray(data, dtype=np.float32)
+        b = np.ascontiguousarray(labels, dtype=np.float32)
+        AtA = (A.T @ A).astype(np.float32)                       # :272
+        lam = regulariser.get_lambda(AtA, A.shape[0])            # :276
+        diag = np.full(AtA.shape[0], lam, np.float32)
+        if not regulariser.regularise_last_row:
+            diag[-1] = 0.0
+        AtA[np.diag_indices_from(AtA)] += diag                   # :279-285
+        qr, tau, perm, rank = col_piv_householder_qr_f32(AtA)    # :288
+        self.rank, self.full_rank = rank, AtA.shape[0]           # :289-293 (the reference prints a warning when rank < F)
+        inv = _qr_solve_f32(qr, tau, perm, np.eye(AtA.shape[0], dtype=np.float32))      # :294
+        # :297, evaluated left to right as Eigen does: (inverse * At) * b
+        with np.errstate(invalid="ignore", over="ignore"):       # (a singular system: inf / nan travel, as in Eigen)
+            return np.ascontiguousarray(((inv @ A.T).astype(np.float32) @ b).astype(np.float32))
+
+
 class LinearRegressor:
     """regressors.hpp:318-400."""
 
-    def __init__(self, regulariser: Optional[Regulariser] = None, accumulate_double: bool = False):
+    def __init__(self, regulariser: Optional[Regulariser] = None, accumulate_double: bool = False, solver=None):
+        self.solver = solver                                      # None: PartialPivLUSolver (the reference's default template argument)
         self.x: Optional[np.ndarray] = None
         self.regulariser = regulariser or Regulariser()
         # `values * x` is cv::gemm on CV_32F (regressors.hpp:377-381).  OpenCV's generic f32 kernel is known to accumulate the
@@ -328,7 +426,10 @@ class LinearRegressor:
         self.accumulate_double = accumulate_double
 
     def learn(self, data: np.ndarray, labels: np.ndarray) -> bool:
-        self.x = partial_piv_lu_solve(data, labels, self.regulariser)   # :345-350
+        if self.solver is not None:
+            self.x = self.solver.solve(data, labels, self.regulariser)
+        else:
+            self.x = partial_piv_lu_solve(data, labels, self.regulariser)   # :345-350
         return True
 
     def predict(self, values: np.ndarray) -> np.ndarray:

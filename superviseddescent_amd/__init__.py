@@ -4,9 +4,9 @@ patrikhuber/superviseddescent (batched HOG extraction + LinearRegressor normal e
 Product code.  The HIP kernels live in ``csrc/`` and are reached only through the C-ABI declared in
 ``include/sdm.h``; this package is the Python mirror of the reference's operator surface on top of it.
 """
-from .engine import (Context, HoGParam, HogTransform, InterEyeDistanceNormalisation, LinearRegressor,
-                     Regulariser, SupervisedDescentOptimiser, detection_model)
+from .engine import (ColPivHouseholderQRSolver, Context, HoGParam, HogTransform, InterEyeDistanceNormalisation, LinearRegressor,
+                     PartialPivLUSolver, Regulariser, SupervisedDescentOptimiser, detection_model)
 from ._lib import SdmError
 
-__all__ = ["Context", "HoGParam", "HogTransform", "InterEyeDistanceNormalisation", "LinearRegressor",
+__all__ = ["ColPivHouseholderQRSolver", "PartialPivLUSolver", "Context", "HoGParam", "HogTransform", "InterEyeDistanceNormalisation", "LinearRegressor",
            "Regulariser", "SupervisedDescentOptimiser", "detection_model", "SdmError"]

@@ -88,6 +88,9 @@ struct sdm_ctx {
     // round 4: the packed launch stops at the raw cell histograms (cells[N][L][2][2O][C*C]); sdm_desc.hip normalises them into the
     // feature rows, or -- sdm_detect_batch -- multiplies the descriptors by the regressor without writing the feature matrix
     DevBuf<float> cells;
+    int solver_kind = SDM_SOLVER_CHOLESKY;      // sdm_set_solver
+    int last_rank = -1, last_rank_full = 0;     // of the last column-pivoted QR (sdm_last_rank)
+    DevBuf<float> qr_work;
     // The feature ROWS (training, sdm_hog_features) still come from the launch that normalises inside the pixel kernel: writing the
     // rows is HBM-bound on its own (55 us per 4 096 x 22 patches) and hides behind the pixel work there; measured 5 % slower split.
     bool split_store = false;       // SDM_HOG_SPLIT_STORE=1: feature rows through cells + sdm_desc.hip's store form (A/B, tests)
@@ -522,7 +525,7 @@ void sdm_destroy(sdm_ctx* c)
     c->partial.release(); c->shard_stage.release(); c->G.release(); c->gpack.release(); c->fro.release(); c->Rsol.release(); c->winv.release(); c->gram_planes.release(); c->gram_flag.release(); c->upd_planes.release(); c->upd_maxdiag.release(); c->lambda_dev.release();
     for (auto& r : c->Rp) r.release();
     for (auto& r : c->Rd) r.release();
-    c->cells.release();
+    c->cells.release(); c->qr_work.release();
     c->Rmax.release();
     for (auto& r : c->Rt) r.release();
     for (auto& q : c->plans) { q.lane_tab.release(); q.wb.release(); q.pass_info.release(); q.cut.release(); q.taps.release(); }
@@ -1251,6 +1254,41 @@ int sdm_allreduce_gram_rhs(sdm_ctx* c)
     return SDM_OK;
 }
 
+namespace {
+// ColPivHouseholderQRSolver (regressors.hpp:287-296) on [G | At b]; the rank is read back (one int) for sdm_last_rank
+int qr_solve(sdm_ctx* c, float* G, int ncols, int F, int Fp, int Mp, float* R_out)
+{
+    if (!sdm_colpiv_qr_supported(F)) return fail(SDM_ERR_INVALID, "column-pivoted QR: at most 38 400 features (a solution column is kept in LDS)");
+    int rc;
+    if ((rc = c->qr_work.ensure(sdm_colpiv_qr_work_floats(F)))) return rc;
+    int* rank_dev = nullptr;
+    sdm_launch_colpiv_qr_solve(G, ncols, F, Fp, Mp, R_out, Mp, Fp, c->qr_work.p, &rank_dev, c->stream);
+    HIP_TRY(hipGetLastError());
+    int rank = -1;
+    HIP_TRY(hipMemcpyAsync(&rank, rank_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->last_rank = rank; c->last_rank_full = F;
+    return SDM_OK;
+}
+}  // namespace
+
+int sdm_set_solver(sdm_ctx* c, int solver)
+{
+    if (!c) return fail(SDM_ERR_INVALID, "null handle");
+    if (solver != SDM_SOLVER_CHOLESKY && solver != SDM_SOLVER_COLPIV_QR) return fail(SDM_ERR_INVALID, "unknown solver");
+    c->solver_kind = solver;
+    return SDM_OK;
+}
+
+int sdm_last_rank(sdm_ctx* c, int* rank, int* full_rank)
+{
+    if (!c) return fail(SDM_ERR_INVALID, "null handle");
+    if (c->last_rank < 0) return fail(SDM_ERR_INVALID, "sdm_last_rank: no column-pivoted QR solve has run on this handle");
+    if (rank) *rank = c->last_rank;
+    if (full_rank) *full_rank = c->last_rank_full;
+    return SDM_OK;
+}
+
 int sdm_solve(sdm_ctx* c, int level, int reg_type, float reg_param, int regularise_last_row,
               long long n_train_global, float* R_host, float* lambda_out)
 {
@@ -1293,12 +1331,17 @@ int sdm_solve(sdm_ctx* c, int level, int reg_type, float reg_param, int regulari
             static const int emulate = getenv("SDM_SOLVE_SHARD_EMULATE") ? atoi(getenv("SDM_SOLVE_SHARD_EMULATE")) : 0;
             shard.emulate_chain = emulate;
         }
+        if (c->solver_kind == SDM_SOLVER_COLPIV_QR) {
+            if (sharded || c->g_scattered) return fail(SDM_ERR_INVALID, "sdm_solve: the column-pivoted QR solver is not sharded over ranks");
+            if ((rc = qr_solve(c, c->G.p, ncols, F, Fp, Mp, c->Rsol.p))) { c->g_level = -1; return rc; }
+        } else {
         if ((rc = solve_update_scratch(c, ncols))) return rc;
         const int crc = sdm_launch_cholesky_solve(c->G.p, ncols, F, Fp, Mp, c->Rsol.p, Mp, c->winv.p, c->status.p, c->stream,
                                                   &c->solve_aux, sharded ? &shard : nullptr);
         if (crc) {
             c->g_level = -1;      // G is partly factored: sdm_gram_rhs has to run again
             return fail(SDM_ERR_COMM, "sharded factorisation: a collective failed with status " + std::to_string(crc));
+        }
         }
     }
     HIP_TRY(hipGetLastError());
@@ -1340,8 +1383,13 @@ int sdm_solve_normal_equations(sdm_ctx* c, const float* A, int N, int F, const f
         if (reg_type == SDM_REG_MATRIX_NORM) sdm_launch_fro2_upper(dG.p, ncols, F, dfro.p, c->stream);
         sdm_launch_add_diag(dG.p, ncols, F, dfro.p + F, reg_type, reg_param, N, regularise_last_row, c->lambda_dev.p, c->stream);
     }
+    if (c->solver_kind == SDM_SOLVER_COLPIV_QR) {
+        Timer t(c, SDM_T_FACTOR);
+        if ((rc = qr_solve(c, dG.p, ncols, F, Fp, Mp, dR.p))) return rc;
+    } else {
     if ((rc = solve_update_scratch(c, ncols))) return rc;
     { Timer t(c, SDM_T_FACTOR); (void)sdm_launch_cholesky_solve(dG.p, ncols, F, Fp, Mp, dR.p, Mp, dW.p, c->status.p, c->stream, &c->solve_aux); }
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy2DAsync(R_host, (size_t)M * sizeof(float), dR.p, (size_t)Mp * sizeof(float), (size_t)M * sizeof(float), F,
                              hipMemcpyDeviceToHost, c->stream));

@@ -140,6 +140,14 @@ void sdm_launch_desc_apply(const HogLevelDev& lv, const float* cells, const int*
 void sdm_launch_apply_reduce(const float* partial, int splits, int N, int M, const float* x_in, float* x_out, int L,
                              const EyeIdxDev& eyes, hipStream_t stream);
 
+// ---- ColPivHouseholderQRSolver on the device (sdm_qr.hip; regressors.hpp:242-306) ----
+// [G | At b] in the solver's buffer (upper tiles of G valid), F <= 38 400 (a solution column lives in LDS); work: sdm_colpiv_qr_work_floats(F)
+// floats; *rank_dev_out = device address of the rank (an int inside `work`, valid after the stream has drained)
+size_t sdm_colpiv_qr_work_floats(int F);
+bool sdm_colpiv_qr_supported(int F);
+void sdm_launch_colpiv_qr_solve(float* G, long long ldg, int F, int rhs0, int nrhs, float* R_out, long long ldr, int r_rows,
+                                float* work, int** rank_dev_out, hipStream_t stream);
+
 void sdm_launch_hog_fast_profile(const ImageSetDev& imgs, const int* img_idx, const float* x, int N, int L,
                                  const EyeIdxDev& eyes, const HogLevelDev& lv, float* feat, long long ldf,
                                  int* status, unsigned long long* prof_dev, hipStream_t stream);

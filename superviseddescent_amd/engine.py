@@ -350,6 +350,18 @@ class Context:
                                   n_train_global, _fp(R) if fetch else None, ctypes.byref(lam)))
         return R, lam.value
 
+    def set_solver(self, solver):
+        """Which of the reference's solvers ``solve`` / ``solve_normal_equations`` / ``train_level`` run: ``"cholesky"`` (default;
+        PartialPivLUSolver's role) or ``"colpivqr"`` (ColPivHouseholderQRSolver, regressors.hpp:242-306, on the device)."""
+        kind = {"cholesky": 0, "lu": 0, "colpivqr": 1, "qr": 1}.get(solver, solver) if isinstance(solver, str) else int(solver)
+        check(self._lib.sdm_set_solver(self._h, int(kind)))
+
+    def last_rank(self):
+        """``(rank, full_rank)`` of the last column-pivoted QR: qr_of_AtA.rank() and the matrix order (regressors.hpp:288-292)."""
+        r, f = ctypes.c_int(0), ctypes.c_int(0)
+        check(self._lib.sdm_last_rank(self._h, ctypes.byref(r), ctypes.byref(f)))
+        return r.value, f.value
+
     def solve_normal_equations(self, data: np.ndarray, labels: np.ndarray, reg_type: int = 0, reg_param: float = 0.0,
                                regularise_last_row: bool = True):
         """Solver::solve(data, labels, regulariser) of regressors.hpp:199-234 on the GPU, for host matrices."""
@@ -485,15 +497,44 @@ class _ResidentToken:
         self.array, self.version = array, version
 
 
+class PartialPivLUSolver:
+    """regressors.hpp:181-234: the default solver of LinearRegressor.  On the device the regularised normal matrix -- symmetric
+    positive definite -- is factored by a blocked Cholesky (csrc/sdm_solve.hip)."""
+    kind = 0
+
+
+class ColPivHouseholderQRSolver:
+    """regressors.hpp:242-306: Householder QR with column pivoting of AtA + reg, on the device (csrc/sdm_qr.hip).  Like the
+    reference it reports a system that is not invertible (``rank``, ``is_invertible`` after a solve; the warning text is the
+    reference's) and is much slower than the default."""
+    kind = 1
+
+    def __init__(self):
+        self.rank: Optional[int] = None
+        self.full_rank: Optional[int] = None
+
+    @property
+    def is_invertible(self) -> Optional[bool]:
+        return None if self.rank is None else self.rank == self.full_rank
+
+    def _report(self, ctx):
+        self.rank, self.full_rank = ctx.last_rank()
+        if self.rank != self.full_rank:      # regressors.hpp:289-292
+            print("The regularised AtA is not invertible. We continued learning, but Eigen may return garbage (their docu is not "
+                  "very specific). (The rank is %d, full rank would be %d). Increase lambda." % (self.rank, self.full_rank))
+
+
 class LinearRegressor:
-    """regressors.hpp:318-400.  ``x`` is the learned F x M matrix (public, as in the reference).
+    """regressors.hpp:318-400.  ``x`` is the learned F x M matrix (public, as in the reference); ``solver`` the reference's
+    template parameter (PartialPivLUSolver by default, or ColPivHouseholderQRSolver).
 
     The optimiser keeps an unchanged regressor resident on the device between calls.  "Unchanged" is enforced, not assumed:
     while a device copy of ``x`` exists the array is read-only, so ``reg.x[...] = v`` or ``reg.x *= s`` raise instead of
     silently leaving the device with stale coefficients.  Assign a new array (``reg.x = ...``), or call ``touch()`` and then
     edit in place: both make the next ``test``/``predict``/``detect`` upload the level again."""
 
-    def __init__(self, regulariser: Optional[Regulariser] = None):
+    def __init__(self, regulariser: Optional[Regulariser] = None, solver=None):
+        self.solver = solver or PartialPivLUSolver()
         self._x: Optional[np.ndarray] = None
         self._version = 0
         self._frozen = None          # (array, its original writeable flag) while a device copy exists
@@ -627,8 +668,13 @@ class SupervisedDescentOptimiser:
             c.gram_rhs(level)                                                # :199-205 + regressors.hpp:208,225
             c.allreduce_gram_rhs()
             r = reg.regulariser
+            kind = getattr(reg.solver, "kind", 0)
+            if hasattr(c, "set_solver"):
+                c.set_solver(kind)                                           # LinearRegressor<Solver>, regressors.hpp:318
             reg.x, reg.last_lambda = c.solve(level, r.regularisation_type, r.param, r.regularise_last_row,
                                              n_glob)                         # :207
+            if kind == 1 and hasattr(c, "last_rank"):
+                reg.solver._report(c)
             self._mark_resident(level, reg)                                  # (sdm_solve left it on the device)
             c.apply(level)                                                   # :209-216
             if on_training_epoch_callback is not None:

@@ -9,6 +9,8 @@
 //                                 "simple_function ... CPU Eigen path (plumbing, no GPU)") and the reference's
 //                                 known-answer tests.  Eigen is not vendored by the reference
 //                                 (CMakeLists.txt:41); its algorithm is restated here.
+//   * ColPivHouseholderQRSolver   Householder QR with column pivoting of AtA + reg ON THE DEVICE (csrc/sdm_qr.hip); reports a
+//                                 system that is not invertible as the reference does.  No CPU fallback.
 //   * VerbosePartialPivLUSolver   the solver type baked into rcr::detection_model::model_type
 //                                 (include/rcr/model.hpp:125).  Here it is the MI355X path: Gram/RHS build on
 //                                 the f32 matrix cores, regulariser and blocked Cholesky on the device through
@@ -154,119 +156,33 @@ public:
     }
 };
 
-namespace detail {
-// Eigen::ColPivHouseholderQR of a square float matrix, restated: Householder reflections with column pivoting on the
-// largest remaining column norm; rank = number of |R_ii| above eps * n * max|R_ii| (Eigen's default threshold);
-// returns the inverse through the factorisation, as ColPivHouseholderQR::inverse() does.
-struct ColPivQR {
-    int n = 0, rank = 0;
-    std::vector<float> qr, tau;     // Householder vectors below the diagonal of qr (row-major), R on and above it
-    std::vector<int> perm;
-
-    explicit ColPivQR(const std::vector<float>& A, int n_) : n(n_), qr(A), tau((size_t)n_), perm((size_t)n_)
-    {
-        for (int i = 0; i < n; ++i) perm[(size_t)i] = i;
-        std::vector<float> cn((size_t)n);
-        for (int j = 0; j < n; ++j) {
-            float s = 0.0f;
-            for (int i = 0; i < n; ++i) s += qr[(size_t)i * n + j] * qr[(size_t)i * n + j];
-            cn[(size_t)j] = s;
-        }
-        float maxpiv = 0.0f;
-        for (int k = 0; k < n; ++k) {
-            int p = k;
-            for (int j = k + 1; j < n; ++j) if (cn[(size_t)j] > cn[(size_t)p]) p = j;
-            if (p != k) {
-                for (int i = 0; i < n; ++i) std::swap(qr[(size_t)i * n + k], qr[(size_t)i * n + p]);
-                std::swap(cn[(size_t)k], cn[(size_t)p]);
-                std::swap(perm[(size_t)k], perm[(size_t)p]);
-            }
-            // Householder vector of column k below the diagonal
-            float tail = 0.0f;
-            for (int i = k + 1; i < n; ++i) tail += qr[(size_t)i * n + k] * qr[(size_t)i * n + k];
-            const float c0 = qr[(size_t)k * n + k];
-            float beta = c0, t = 0.0f;
-            if (tail > 0.0f) {
-                beta = std::sqrt(c0 * c0 + tail);
-                if (c0 >= 0.0f) beta = -beta;
-                for (int i = k + 1; i < n; ++i) qr[(size_t)i * n + k] /= (c0 - beta);
-                t = (beta - c0) / beta;
-            }
-            tau[(size_t)k] = t;
-            qr[(size_t)k * n + k] = beta;
-            if (std::fabs(beta) > maxpiv) maxpiv = std::fabs(beta);
-            // apply H_k = I - t v v^T to the remaining columns
-            for (int j = k + 1; j < n; ++j) {
-                float d = qr[(size_t)k * n + j];
-                for (int i = k + 1; i < n; ++i) d += qr[(size_t)i * n + k] * qr[(size_t)i * n + j];
-                d *= t;
-                qr[(size_t)k * n + j] -= d;
-                for (int i = k + 1; i < n; ++i) qr[(size_t)i * n + j] -= d * qr[(size_t)i * n + k];
-                cn[(size_t)j] -= qr[(size_t)k * n + j] * qr[(size_t)k * n + j];
-            }
-        }
-        const float thr = std::numeric_limits<float>::epsilon() * (float)n * maxpiv;
-        for (int k = 0; k < n; ++k) if (std::fabs(qr[(size_t)k * n + k]) > thr) ++rank;
-    }
-
-    bool is_invertible() const { return rank == n; }
-
-    // X = A^-1 B (B is n x m, row-major): Q^T B, back substitution with R, undo the column permutation
-    std::vector<float> solve(std::vector<float> B, int m) const
-    {
-        for (int k = 0; k < n; ++k)
-            for (int c = 0; c < m; ++c) {
-                float d = B[(size_t)k * m + c];
-                for (int i = k + 1; i < n; ++i) d += qr[(size_t)i * n + k] * B[(size_t)i * m + c];
-                d *= tau[(size_t)k];
-                B[(size_t)k * m + c] -= d;
-                for (int i = k + 1; i < n; ++i) B[(size_t)i * m + c] -= d * qr[(size_t)i * n + k];
-            }
-        for (int i = n - 1; i >= 0; --i)
-            for (int c = 0; c < m; ++c) {
-                float v = B[(size_t)i * m + c];
-                for (int j = i + 1; j < n; ++j) v -= qr[(size_t)i * n + j] * B[(size_t)j * m + c];
-                B[(size_t)i * m + c] = v / qr[(size_t)i * n + i];
-            }
-        std::vector<float> X((size_t)n * m);
-        for (int i = 0; i < n; ++i)
-            for (int c = 0; c < m; ++c) X[(size_t)perm[(size_t)i] * m + c] = B[(size_t)i * m + c];
-        return X;
-    }
-};
-}  // namespace detail
-
-/** Host solver that can report a singular system (regressors.hpp:245-306): (AtA + reg)^-1 through a column-pivoted
- *  Householder QR, then x = inverse * At * b.  "Much MUCH slower than a PartialPivLUSolver" in the reference too; like
- *  PartialPivLUSolver it serves the generic host surface, not the batched device path. */
+/** The solver that can report a singular system (regressors.hpp:242-306): AtA + reg factored by a Householder QR with column
+ *  pivoting ON THE DEVICE (csrc/sdm_qr.hip through sdm_set_solver(SDM_SOLVER_COLPIV_QR) + sdm_solve_normal_equations), the
+ *  reference's warning when rank < F (:289-293), x = P R^-1 Q^T (At b).  "Much MUCH slower than a PartialPivLUSolver" here too.
+ *  No CPU fallback: it throws std::runtime_error without a device. */
 class ColPivHouseholderQRSolver {
 public:
     cv::Mat solve(cv::Mat data, cv::Mat labels, Regulariser regulariser)
     {
-        std::vector<float> AtA, Atb;
-        detail::normal_equations_host(data, labels, AtA, Atb);
-        const int F = data.cols, M = labels.cols;
-        cv::Mat AtA_map(F, F, CV_32FC1, AtA.data());
-        const float lambda = regulariser.get_lambda(AtA_map, data.rows);            // :275
-        for (int i = 0; i < F; ++i)
-            if (i < F - 1 || regulariser.regularises_last_row()) AtA[(size_t)i * F + i] += lambda;   // :278-284
-        detail::ColPivQR qr(AtA, F);                                                 // :287
-        if (!qr.is_invertible())                                                     // :289-292
+        hip::Handle& h = hip::default_handle();
+        cv::Mat A = data.isContinuous() ? data : data.clone();
+        cv::Mat b = labels.isContinuous() ? labels : labels.clone();
+        cv::Mat x(data.cols, labels.cols, CV_32FC1);
+        hip::check(sdm_set_solver(h.get(), SDM_SOLVER_COLPIV_QR), "sdm_set_solver");
+        const int rc = sdm_solve_normal_equations(
+            h.get(), A.ptr<float>(), A.rows, A.cols, b.ptr<float>(), b.cols,
+            regulariser.type() == Regulariser::RegularisationType::MatrixNorm ? SDM_REG_MATRIX_NORM : SDM_REG_MANUAL,
+            regulariser.param(), regulariser.regularises_last_row() ? 1 : 0, x.ptr<float>(), nullptr);
+        (void)sdm_set_solver(h.get(), SDM_SOLVER_CHOLESKY);      // (the handle is shared with the default solver)
+        hip::check(rc, "sdm_solve_normal_equations");
+        hip::check(sdm_last_rank(h.get(), &rank, &full_rank), "sdm_last_rank");
+        if (rank != full_rank)                                    // :290-293
             std::cout << "The regularised AtA is not invertible. We continued learning, but Eigen may return garbage (their "
-                         "docu is not very specific). (The rank is " << qr.rank << ", full rank would be " << F
+                         "docu is not very specific). (The rank is " << rank << ", full rank would be " << full_rank
                       << "). Increase lambda." << std::endl;
-        std::vector<float> eye((size_t)F * F, 0.0f);
-        for (int i = 0; i < F; ++i) eye[(size_t)i * F + i] = 1.0f;
-        const std::vector<float> inv = qr.solve(eye, F);                             // qr_of_AtA.inverse(), :293
-        cv::Mat x(F, M, CV_32FC1);                                                   // x = AtAInv * At * b, :296
-        for (int i = 0; i < F; ++i)
-            for (int c = 0; c < M; ++c) {
-                float v = 0.0f;
-                for (int j = 0; j < F; ++j) v += inv[(size_t)i * F + j] * Atb[(size_t)j * M + c];
-                x.at<float>(i, c) = v;
-            }
         return x;
     }
+    int rank = -1, full_rank = 0;      // qr_of_AtA.rank() of the last solve, and the matrix order
 };
 
 /** Device solver with the reference's stage printout (verbose_solver.hpp:53-111). */

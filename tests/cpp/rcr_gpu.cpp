@@ -6,6 +6,7 @@
 //   usage: rcr_gpu <dir>
 #include "rcr/model.hpp"
 
+#include <cmath>
 #include <cstdio>
 #include <fstream>
 #include <iostream>
@@ -153,6 +154,27 @@ int main(int argc, char** argv)
         LR lr(Regulariser(Regulariser::RegularisationType::Manual, 0.5f, true));
         lr.learn(Mat(lrN, lrF, CV_32FC1, Av.data()), Mat(lrN, lrM, CV_32FC1, bv.data()));
         write_mat(dir + "/cpp_lr_x.f32", lr.x);
+
+        // ---- ColPivHouseholderQRSolver (regressors.hpp:242-306; no test in the reference): the same system through the column-pivoted QR
+        LinearRegressor<ColPivHouseholderQRSolver> lq(Regulariser(Regulariser::RegularisationType::Manual, 0.5f, true));
+        lq.learn(Mat(lrN, lrF, CV_32FC1, Av.data()), Mat(lrN, lrM, CV_32FC1, bv.data()));
+        write_mat(dir + "/cpp_lr_x_qr.f32", lq.x);
+        {   // the regularised normal equations of ND.cpp:174-195 / 255-282: the coefficients the reference's LU test pins
+            Mat data = (cv::Mat_<float>(5, 3) << 1.0f, 4.0f, 2.0f, 4.0f, 9.0f, 1.0f, 6.0f, 5.0f, 2.0f, 0.0f, 6.0f, 2.0f, 6.0f, 1.0f, 9.0f);
+            Mat labels = (cv::Mat_<float>(5, 2) << 1.0f, 1.0f, 2.0f, 5.0f, 3.0f, -2.0f, 0.0f, 5.0f, 6.0f, 3.0f);
+            LinearRegressor<ColPivHouseholderQRSolver> lr3(Regulariser(Regulariser::RegularisationType::Manual, 50.0f, true));
+            lr3.learn(data, labels);
+            const float want[6] = {0.282755911f, -0.0989616f, 0.03607957f, 0.330635577f, 0.291039944f, 0.217046738f};
+            for (int i = 0; i < 3; ++i)
+                for (int c = 0; c < 2; ++c)
+                    if (std::fabs(lr3.x.at<float>(i, c) - want[i * 2 + c]) > 2e-6f) throw std::runtime_error("ColPivHouseholderQRSolver: ND.cpp coefficients");
+            // a rank-deficient system is reported, not fatal: two identical columns, no regularisation
+            Mat dup = (cv::Mat_<float>(3, 2) << 1.0f, 1.0f, 2.0f, 2.0f, 3.0f, 3.0f);
+            Mat y = (cv::Mat_<float>(3, 1) << 1.0f, 2.0f, 3.0f);
+            ColPivHouseholderQRSolver q;
+            (void)q.solve(dup, y, Regulariser());
+            if (!(q.rank == 1 && q.full_rank == 2)) throw std::runtime_error("ColPivHouseholderQRSolver: rank of a singular system");
+        }
         std::printf("rcr_gpu ok\n");
     } catch (const std::exception& e) {
         std::fprintf(stderr, "rcr_gpu failed: %s\n", e.what());

@@ -96,33 +96,7 @@ TEST(LinearRegressor, NDimManyExamplesNDimYBiasRegularisationButNotBias)   // ND
     EXPECT_TRUE(lr.test(test, groundtruth) <= 0.000011);
 }
 
-TEST(LinearRegressor, ColPivHouseholderQRSolverSolvesTheSameSystem)   // regressors.hpp:245-306 (no test in the reference)
-{
-    // the same regularised normal equations as ND.cpp:174-195 / 255-282, through the QR inverse: same coefficients
-    LinearRegressor<ColPivHouseholderQRSolver> lr(Regulariser(Regulariser::RegularisationType::Manual, 50.0f, true));
-    lr.learn(nd_data(), nd_labels());
-    EXPECT_NEAR(0.282755911f, lr.x.at<float>(0, 0), 0.000001);
-    EXPECT_NEAR(0.03607957f, lr.x.at<float>(1, 0), 0.000001);
-    EXPECT_NEAR(0.291039944f, lr.x.at<float>(2, 0), 0.000001);
-    EXPECT_NEAR(-0.0989616f, lr.x.at<float>(0, 1), 0.000001);
-    EXPECT_NEAR(0.330635577f, lr.x.at<float>(1, 1), 0.000001);
-    EXPECT_NEAR(0.217046738f, lr.x.at<float>(2, 1), 0.000001);
-    Mat data = nd_data();
-    cv::hconcat(data, Mat::ones(data.rows, 1, CV_32FC1), data);
-    LinearRegressor<ColPivHouseholderQRSolver> lb(Regulariser(Regulariser::RegularisationType::Manual, 50.0f, false));
-    lb.learn(data, nd_labels());
-    EXPECT_NEAR(1.53583705f, lb.x.at<float>(3, 0), 0.00001);
-    EXPECT_NEAR(1.82635951f, lb.x.at<float>(3, 1), 0.00001);
-    EXPECT_NEAR(0.2188783f, lb.x.at<float>(0, 0), 0.00001);
-    // a rank-deficient system is reported, not fatal: two identical columns, no regularisation
-    Mat dup = (cv::Mat_<float>(3, 2) << 1.0f, 1.0f, 2.0f, 2.0f, 3.0f, 3.0f);
-    Mat y = (cv::Mat_<float>(3, 1) << 1.0f, 2.0f, 3.0f);
-    std::vector<float> AtA, Atb;
-    superviseddescent::detail::normal_equations_host(dup, y, AtA, Atb);
-    superviseddescent::detail::ColPivQR qr(AtA, 2);
-    EXPECT_TRUE(!qr.is_invertible());
-    EXPECT_TRUE(qr.rank == 1);
-}
+// (ColPivHouseholderQRSolver runs on the device: its known-answer test is in rcr_gpu.cpp, run by tests/test_cpp_layer.py -m gpu)
 
 // ---- SupervisedDescentOptimiser (SDO.cpp) ----------------------------------------------------------------------
 template <typename ForwardIterator, typename T>

@@ -115,4 +115,11 @@ def test_cpp_rcr_scenario_matches_python_layer(cpp_bins, tmp_path):
     assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-5
     R, lam = ctx.solve_normal_equations(A, b, 0, 0.5, True)
     assert np.array_equal(R, got)
+    # LinearRegressor<ColPivHouseholderQRSolver> (regressors.hpp:242-306): the same system through the device's column-pivoted QR
+    got_qr = rd("cpp_lr_x_qr.f32", 5)
+    assert np.linalg.norm(got_qr - ref) / np.linalg.norm(ref) < 1e-5
+    ctx.set_solver("colpivqr")
+    Rq, _ = ctx.solve_normal_equations(A, b, 0, 0.5, True)
+    ctx.set_solver("cholesky")
+    assert np.array_equal(Rq, got_qr) and ctx.last_rank() == (37, 37)
     ctx.close()

@@ -1,0 +1,105 @@
+"""ColPivHouseholderQRSolver on the device (csrc/sdm_qr.hip; reference regressors.hpp:242-306) against the oracle's float32
+restatement of Eigen's column-pivoted Householder QR (oracle/sdm_oracle.py) and against float64 normal equations:
+well-conditioned systems (solution within the oracle's own distance from float64, same rank), HOG-like column scales, a
+rank-deficient system (rank reported as the oracle reports it, nothing raised), MatrixNorm with the bias row exempt, more
+right-hand sides than one tile column holds, and the solver inside SupervisedDescentOptimiser.train (LinearRegressor's template
+argument) against the default solver."""
+import numpy as np
+import pytest
+
+from oracle import sdm_oracle as orc
+from superviseddescent_amd import (ColPivHouseholderQRSolver, HoGParam, HogTransform, LinearRegressor, Regulariser,
+                                   SupervisedDescentOptimiser, ibug, synth)
+
+pytestmark = pytest.mark.gpu
+
+
+def f64_solution(A, b, lam, last_row):
+    G = A.astype(np.float64).T @ A.astype(np.float64)
+    d = np.full(G.shape[0], float(lam)); d[-1] = d[-1] if last_row else 0.0
+    return np.linalg.solve(G + np.diag(d), A.astype(np.float64).T @ b.astype(np.float64))
+
+
+def rel(a, b):
+    return float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b))
+
+
+@pytest.fixture
+def qctx(gpu_ctx):
+    gpu_ctx.set_solver("colpivqr")
+    yield gpu_ctx
+    gpu_ctx.set_solver("cholesky")
+
+
+@pytest.mark.parametrize("N,F,M,reg", [(400, 60, 6, (1, 0.5, False)), (900, 301, 44, (0, 2.0, True)), (700, 140, 136, (1, 1.5, False)),
+                                       (300, 1, 2, (0, 0.1, True)), (2000, 640, 10, (1, 0.8, True))])
+def test_qr_solver_against_oracle_and_float64(qctx, N, F, M, reg):
+    rng = np.random.default_rng(F)
+    A = rng.standard_normal((N, F)).astype(np.float32)
+    A *= np.exp(rng.uniform(-2.0, 2.0, F)).astype(np.float32)            # column scales over e^4
+    A[:, -1] = 1.0                                                         # the bias column of adaptive_vlhog.hpp:182
+    b = (A[:, :min(F, 8)] @ rng.standard_normal((min(F, 8), M)) + 0.1 * rng.standard_normal((N, M))).astype(np.float32)
+    R, lam = qctx.solve_normal_equations(A, b, *reg)
+    osolver = orc.ColPivHouseholderQRSolver()
+    oreg = orc.Regulariser(*reg)
+    x_orc = osolver.solve(A, b, oreg)
+    assert lam == pytest.approx(float(oreg.get_lambda((A.T @ A).astype(np.float32), N)), rel=2e-6)
+    x64 = f64_solution(A, b, lam, reg[2])
+    assert qctx.last_rank() == (osolver.rank, F) == (F, F)
+    # as far from exact arithmetic as the float32 restatement of the reference's path is (measured, scripts/r4_qr_probe.py: device
+    # 1.3e-7 ... 4.4e-5, restatement 1.6e-8 ... 3.3e-5 on these systems; a QR of the SQUARED system loses more than the default
+    # solver does, in the reference too: Cholesky / LU 2e-7 ... 9e-6 here)
+    assert rel(R, x64) <= max(3.0 * rel(x_orc, x64), 5e-6)
+    assert rel(R, x_orc.astype(np.float64)) < 1e-4
+
+
+def test_qr_solver_reports_a_singular_system(qctx):
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((200, 40)).astype(np.float32)
+    A[:, 17] = A[:, 5]                                                     # two identical columns, no regularisation
+    A[:, 30] = 0.0                                                         # and an empty one
+    b = rng.standard_normal((200, 3)).astype(np.float32)
+    R, _ = qctx.solve_normal_equations(A, b, 0, 0.0, True)                  # "we continued learning" (regressors.hpp:292): no error
+    osolver = orc.ColPivHouseholderQRSolver()
+    osolver.solve(A, b, orc.Regulariser(0, 0.0, True))
+    assert qctx.last_rank() == (osolver.rank, 40) and osolver.rank == 38
+    # with the reference's remedy ("Increase lambda") the system is invertible again
+    R, _ = qctx.solve_normal_equations(A, b, 0, 1.0, True)
+    assert qctx.last_rank() == (40, 40) and np.isfinite(R).all()
+
+
+def test_qr_pivot_order_is_the_oracles(qctx):
+    """Distinct column norms: the device brings the columns forward in the oracle's order -- seen through the solution of a system
+    whose right-hand side is the identity (x = inverse, columns permuted back), compared entry by entry."""
+    rng = np.random.default_rng(11)
+    F = 48
+    A = rng.standard_normal((300, F)).astype(np.float32) * (1.0 + np.arange(F, dtype=np.float32))[None, :]
+    G = (A.T @ A).astype(np.float32)
+    qr, tau, perm, rank = orc.col_piv_householder_qr_f32(G + np.float32(0.5) * np.eye(F, dtype=np.float32))
+    assert rank == F and not np.array_equal(perm, np.arange(F))
+    b = rng.standard_normal((300, 4)).astype(np.float32)
+    R, _ = qctx.solve_normal_equations(A, b, 0, 0.5, True)
+    x_orc = orc.ColPivHouseholderQRSolver().solve(A, b, orc.Regulariser(0, 0.5, True))
+    assert np.abs(R - x_orc).max() / np.abs(x_orc).max() < 2e-5
+
+
+def test_linear_regressor_with_the_qr_solver_trains_the_cascade(gpu_ctx):
+    """LinearRegressor<ColPivHouseholderQRSolver> inside SupervisedDescentOptimiser::train (superviseddescent.hpp:165-219): the
+    cascade learned with the QR solver equals the one learned with the default solver to solver rounding, on HOG features."""
+    ids = ibug.RCR22_IDS
+    params = [HoGParam(1, 3, 8, 4, 0.8), HoGParam(1, 3, 6, 4, 0.5)]        # F = 22 * 9 * 16 + 1 = 3 169
+    images, boxes, gt = synth.make_faces(60, seed=501)
+    xs, x0, idx = synth.make_samples(boxes, gt, ids, n_perturb=5, seed=502)
+    hog = HogTransform(images, params, ids, ibug.RIGHT_EYE_IDS, ibug.LEFT_EYE_IDS, idx)
+    reg = lambda: Regulariser(Regulariser.RegularisationType.MatrixNorm, 1.5, False)
+    sdo_qr = SupervisedDescentOptimiser([LinearRegressor(reg(), solver=ColPivHouseholderQRSolver()) for _ in params])
+    x_qr = sdo_qr.train(xs, x0, None, hog)
+    sdo_lu = SupervisedDescentOptimiser([LinearRegressor(reg()) for _ in params])
+    x_lu = sdo_lu.train(xs, x0, None, hog)
+    for a, b in zip(sdo_qr.regressors, sdo_lu.regressors):
+        assert a.solver.is_invertible and a.solver.rank == a.x.shape[0]
+        assert a.last_lambda == pytest.approx(b.last_lambda, rel=1e-6)
+    assert rel(x_qr, x_lu.astype(np.float64)) < 2e-5
+    assert np.array_equal(sdo_qr.test(x0, None, hog), sdo_qr.test(x0, None, hog))
+    # the default solver is back for the next user of the shared context
+    sdo_lu.train(xs, x0, None, hog)

@@ -217,3 +217,41 @@ def test_sdo_sin_erf_multi_y():  # :443-521
     y_ts = np.stack([v, v], 1)
     pred = sdo.test(np.full_like(y_ts, 0.5), y_ts, h)
     assert nlsr(pred, h_inv(y_ts)) == pytest.approx(0.0024807, abs=2.1e-6)
+
+
+# ---- ColPivHouseholderQRSolver (regressors.hpp:242-306; the reference has no test for it) ---------------------------------
+def test_col_piv_qr_solver_reproduces_the_lu_goldens():
+    """The same regularised normal equations as ND.cpp:174-195 through the column-pivoted QR: the coefficients the reference's
+    LU test pins (the solvers are interchangeable template arguments of LinearRegressor, regressors.hpp:318)."""
+    data = np.array([[1, 4, 2], [4, 9, 1], [6, 5, 2], [0, 6, 2], [6, 1, 9]], f32)
+    labels = np.array([[1, 1], [2, 5], [3, -2], [0, 5], [6, 3]], f32)
+    lr = o.LinearRegressor(o.Regulariser(o.Regulariser.MANUAL, 50.0, True), solver=o.ColPivHouseholderQRSolver())
+    lr.learn(data, labels)
+    want = np.array([[0.282755911, -0.0989616], [0.03607957, 0.330635577], [0.291039944, 0.217046738]], f32)
+    assert np.abs(lr.x - want).max() < 1e-6
+    assert lr.solver.rank == 3 and lr.solver.full_rank == 3
+
+
+def test_col_piv_qr_factorisation_properties():
+    """Q R = A P to float32 rounding, |R_kk| non-increasing (what column pivoting guarantees), the rank of a singular matrix by
+    Eigen's threshold, and the solution of a well-conditioned system against float64."""
+    rng = np.random.default_rng(7)
+    n = 40
+    B = rng.standard_normal((120, n)).astype(f32) * (1.0 + np.arange(n, dtype=f32))
+    A = (B.T @ B).astype(f32)
+    qr, tau, perm, rank = o.col_piv_householder_qr_f32(A)
+    assert rank == n
+    d = np.abs(np.diagonal(qr))
+    assert (d[:-1] >= d[1:] * (1 - 1e-5)).all()
+    Q = np.eye(n)
+    for k in range(n):                                     # Q = H_0 H_1 ... H_{n-1}
+        v = np.zeros(n); v[k] = 1.0; v[k + 1:] = qr[k + 1:, k]
+        Q = Q @ (np.eye(n) - float(tau[k]) * np.outer(v, v))
+    assert np.abs(Q @ np.triu(qr).astype(np.float64) - A[:, perm]).max() / np.abs(A).max() < 5e-6
+    A2 = A.copy(); A2[:, 9] = A2[:, 3]; A2[9, :] = A2[3, :]
+    assert o.col_piv_householder_qr_f32(A2)[3] == n - 1
+    data = rng.standard_normal((200, 12)).astype(f32); y = rng.standard_normal((200, 3)).astype(f32)
+    x = o.ColPivHouseholderQRSolver().solve(data, y, o.Regulariser(o.Regulariser.MANUAL, 0.5, True))
+    G = data.astype(np.float64).T @ data.astype(np.float64) + 0.5 * np.eye(12)
+    x64 = np.linalg.solve(G, data.astype(np.float64).T @ y.astype(np.float64))
+    assert np.linalg.norm(x - x64) / np.linalg.norm(x64) < 2e-6
