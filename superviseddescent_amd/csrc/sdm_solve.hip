@@ -641,9 +641,11 @@ trsm_tile_kernel(float* __restrict__ G, long long ldg, int k0, int tile_j0, int 
 // One persistent workgroup per tile row i (and per chunk of <= 5 right-hand-side column tiles).  Y_i lives in the matrix-core
 // accumulators of its 8 waves for the whole solve: for k = T-1 ... i+1 the workgroup waits for R_k (a flag in global memory,
 // published by workgroup k), multiplies it by U_ik (fetched into registers while the previous product ran) and subtracts; then
-// R_i = U_ii^-1 Y_i from the stored transposed inverse, stored, fenced, flagged.  Workgroups are numbered so that tile row
-// T-1 is dispatched first: a workgroup only ever waits for workgroups dispatched BEFORE it, so the kernel cannot deadlock even
-// when the grid does not fit the chip; the spin is bounded all the same (status bit 4 instead of a hung GPU).
+// R_i = U_ii^-1 Y_i from the stored transposed inverse, stored, fenced, flagged.  A workgroup takes its tile row from a ticket
+// drawn when it STARTS (one counter per column chunk): ticket 0 -> row T-1, ticket 1 -> row T-2, ...  A workgroup therefore only
+// ever waits for workgroups that were already running when it drew its ticket, whatever order the hardware dispatches blocks in
+// (HIP specifies none), so the kernel cannot deadlock even when the grid does not fit the chip; the spin is bounded
+// all the same (status bit 4 instead of a hung GPU).
 // Measured (rocprofv3 kernel trace, F = 8 801, 44 right-hand sides): 1.19 ms for the 69 steps = 17 us per step -- the release /
 // acquire round trip through memory, the R_k fetch and the two products -- against 69 launches x 19.9 us = 1.38 ms; F = 27 201,
 // 136 right-hand sides (two column chunks side by side): factor + solve 86.6 -> 83.1 ms.
@@ -660,7 +662,10 @@ backsolve_persistent_kernel(const float* __restrict__ G, long long ldg, int Tf, 
     float* Bk = sm + TILE * (TILE + 4);                // [128][ncb]: R_k, at the end Y_i
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 15, lq = lane >> 4;
-    const int i = Tf - 1 - (int)blockIdx.x;            // tile row of this workgroup
+    __shared__ int ticket_sh;
+    if (t == 0) ticket_sh = atomicAdd(flags + (size_t)gridDim.y * Tf + blockIdx.y, 1);      // (the counters sit behind the flags, cleared with them)
+    __syncthreads();
+    const int i = Tf - 1 - ticket_sh;                  // tile row of this workgroup
     const int col0 = (int)blockIdx.y * ncb;            // first right-hand-side column of this chunk
     int* flag = flags + (size_t)blockIdx.y * Tf;
     const long long i0 = (long long)i * TILE;
@@ -1090,10 +1095,10 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
         const int cap = 5;      // column tiles per workgroup (measured 42.3 / 43.7 / 47.4 / 56.2 ms at F = 27 201 for 5 / 3 / 2 / 1)
         const int nchunks = nj > 0 ? (nj + cap - 1) / cap : 0, NJ = nchunks ? (nj + nchunks - 1) / nchunks : 1;
         int* flags = (int*)(work + (size_t)Tf * TILE * TILE);
-        if (nchunks) (void)hipMemsetAsync(flags, 0, (size_t)nchunks * Tf * sizeof(int), stream);
+        if (nchunks) (void)hipMemsetAsync(flags, 0, ((size_t)nchunks * Tf + nchunks) * sizeof(int), stream);      // flags + one ticket counter per chunk
         static unsigned long long attr_bsp = 0;
         if (sdm_first_use_on_device(attr_bsp)) {
-#define BSPATTR(NJv) SDM_SET_ATTR((const void*)backsolve_persistent_kernel<NJv>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+#define BSPATTR(NJv) SDM_SET_ATTR((const void*)backsolve_persistent_kernel<NJv>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024)      /* (+ the static ticket word) */
             BSPATTR(1); BSPATTR(2); BSPATTR(3); BSPATTR(4); BSPATTR(5);
 #undef BSPATTR
         }
