@@ -507,6 +507,31 @@ def main():
     except (OSError, KeyError, ValueError, ZeroDivisionError):
         pass
 
+    # compute-side roofline of the same launch: what the vector-instruction issue alone would take (profiles/r04_issue_model.json,
+    # scripts/isa_issue_model.py: per-class instruction counts of the unrolled pass from the ISA x the issue clocks measured on
+    # this chip, + the f32 matrix instructions of the band folds, which slow the vector pipe of their SIMD 2.5x while they run)
+    compute_roof = None
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_issue_model.json")) as fh:
+            im = json.load(fh)
+        cells = [p[2] for p in ibug.SHIPPED_HOG_PARAMS]
+        if all(str(c) in im["levels"] for c in cells) and L == 22:
+            pred = []
+            for c in cells:
+                e = im["levels"][str(c)]
+                clocks = e["valu_clocks_row_loop_and_folds"] + 0.6 * e["mfma_clocks_per_pass"]      # (set-up not counted: a lower bound)
+                pred.append(args.batch * e["passes_per_face"] * clocks / 1024.0 / 2.4e9 * 1e3)
+            pred_ms = sum(pred) / len(pred)
+            compute_roof = {"bound": "valu_issue", "predicted_avg_launch_ms": pred_ms, "measured_avg_launch_ms": hog_avg_ms,
+                            "frac": pred_ms / hog_avg_ms if hog_avg_ms > 0 else None,
+                            "valu_clocks_per_pixel_row": [im["levels"][str(c)]["valu_clocks_per_row"] for c in cells],
+                            "note": "frac = (time the pass's vector instructions need at their measured issue rates, 1 024 SIMDs at 2.4 GHz) / "
+                                    "(measured launch time): the launch runs at this fraction of its instruction-issue bound; the rest is per-wave "
+                                    "set-up, the tail of the launch (6-12 % at this batch, scripts/r4_scaling.py) and stalls.  source: "
+                                    "profiles/r04_issue_model.json"}
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        pass
+
     F22 = ctx.feature_dim(0)
     T22 = (F22 + 127) // 128
     out = {
@@ -542,6 +567,7 @@ def main():
             "traffic": traffic,
             "traffic_source": traffic_src,
             "valu_issue": valu_issue,
+            "compute": compute_roof,
             "algorithmic_bytes_per_launch": bytes_per_launch,
             "feature_write": "dropped: sdm_detect_batch multiplies the descriptors by the regressor on the chip (csrc/sdm_desc.hip); the "
                              "launch writes raw cell histograms (800 B per patch, %.1f MB per launch) for that kernel instead of the "

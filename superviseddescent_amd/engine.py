@@ -663,6 +663,13 @@ class SupervisedDescentOptimiser:
         if hasattr(c, "set_reduce_scatter"):
             c.set_reduce_scatter(reduce_scatter if (solve_collectives is not None and rank is not None) else None)
         n_glob = n_train_global or c.N
+        try:
+            return self._train_levels(c, n_glob, on_training_epoch_callback)
+        finally:
+            if hasattr(c, "set_solver"):
+                c.set_solver(0)                                              # (the context may be shared: leave the default solver behind)
+
+    def _train_levels(self, c, n_glob, on_training_epoch_callback):
         for level, reg in enumerate(self.regressors):
             c.hog_features(level)                                            # superviseddescent.hpp:173-189
             c.gram_rhs(level)                                                # :199-205 + regressors.hpp:208,225
