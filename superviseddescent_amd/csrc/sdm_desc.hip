@@ -37,8 +37,17 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef DS_MINW
 #define DS_MINW 6
 #endif
+#ifndef DS_ABL
+#define DS_ABL 0      /* timing experiments: 1 = no product phase, 2 = no descriptor arithmetic (cells loaded, zeros staged) */
+#endif
 
 __host__ __device__ constexpr int desc_dim(int O, int variant) { return variant == 1 ? 3 * O + 4 : 4 * O; }
+// The fused launch stages the descriptors CELL-MAJOR: k' = cell * DP + f with DP = D rounded up to 8 (a lane owns one cell, so its
+// features are 16-byte runs: DP / 8 ds_write_b128 per piece instead of D two-byte stores), where the feature rows are f * C*C + ct.
+// A product sum_k A[m][k] B[k][n] does not care about the order of k as long as both operands use the same one: the regressor
+// planes are built in the same order (desc_planes_kernel), the padding features are zero on both sides.
+__host__ __device__ constexpr int desc_dp(int D) { return (D + 7) / 8 * 8; }
+__host__ __device__ constexpr int desc_pk(int CC, int D) { return CC * desc_dp(D); }
 __host__ __device__ constexpr int desc_kp(int P) { return (P + 31) / 32 * 32; }          // K padded to the matrix instruction's 32
 // stage row stride in halfs: P rounded up to 8 (16-byte rows) + 8, i.e. rows start 4 (mod 8) dwords apart and the sixteen rows a
 // fragment read (ds_read_b128, one row per lane li) touches fall into sixteen different 4-dword bank groups.  The last k-step reads
@@ -63,7 +72,8 @@ desc_kernel(const float* __restrict__ cells, const int* __restrict__ cut, int N,
             float* __restrict__ partial)
 {
     constexpr int O = TO, C = TC, CC = C * C, D = desc_dim(TO, VARIANT), P = CC * D;
-    constexpr int KP = desc_kp(P), KS = desc_ks(P), KSTEPS = KP / 32, MT = FB / 16;
+    constexpr int DP = desc_dp(D), PK = desc_pk(CC, D);              // fused: features per cell padded to 8, K of the staged operand
+    constexpr int KP = desc_kp(PK), KS = desc_ks(PK), KSTEPS = KP / 32, MT = FB / 16;
     static_assert(CC <= 32, "one cell per lane, two patches per wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned short* stage_hi = (unsigned short*)smem;                       // [FB][KS] float16 bits (first piece)
@@ -83,10 +93,10 @@ desc_kernel(const float* __restrict__ cells, const int* __restrict__ cut, int N,
     const bool is_cut = cut[l] != 0;
 
     if (FUSED) {      // the rows' padding (and the spare bytes behind the last row) is read by the last k-step: zero it once
-        constexpr int PADW = KS - P;
+        constexpr int PADW = KS - PK;
         for (int i = threadIdx.x; i < 2 * FB * PADW; i += W * 64) {
             const int piece = i / (FB * PADW), r = i - piece * (FB * PADW);
-            const int m = r / PADW, k = P + (r - m * PADW);
+            const int m = r / PADW, k = PK + (r - m * PADW);
             (piece ? stage_lo : stage_hi)[(size_t)m * KS + k] = 0;
         }
         if (threadIdx.x < 32) ((unsigned short*)smem)[(size_t)2 * FB * KS + threadIdx.x] = 0;
@@ -127,6 +137,10 @@ desc_kernel(const float* __restrict__ cells, const int* __restrict__ cut, int N,
 #pragma unroll
         for (int j = 0; j < 2 * O; ++j) h[j] = hn[j];
         if (it + 1 < NIT) load_cells(it + 1, hn);                        // the next patch's cells are in flight during this one's arithmetic
+        if (DS_ABL == 2 && FUSED) {
+            if (active) { float t = 0.0f; for (int j = 0; j < 2 * O; ++j) t += h[j]; stage_hi[(size_t)m * KS + cc * DP] = (unsigned short)(t == 12345.0f); }
+            continue;
+        }
         // cell norm (hog.c:875-890)
         float n = 0.0f;
 #pragma unroll
@@ -175,20 +189,28 @@ desc_kernel(const float* __restrict__ cells, const int* __restrict__ cut, int N,
                 if (has_bias && l == L - 1 && cell == 0) feat[(long long)face * ldf + (long long)L * P] = 1.0f;
             }
         } else if (active) {
-            unsigned short* sh = stage_hi + (size_t)m * KS + ct;
-            unsigned short* sl = stage_lo + (size_t)m * KS + ct;
+            // v 2^12 = h1 + h2: h1 = the leading 11 bits (exact in float16), h2 = float16(v 2^12 - h1)   (apply_split8); two features
+            // per conversion, eight per 16-byte store, the cell's DP features contiguous in the staged row
+            u32x4* sh = (u32x4*)(stage_hi + (size_t)m * KS + cc * DP);
+            u32x4* sl = (u32x4*)(stage_lo + (size_t)m * KS + cc * DP);
 #pragma unroll
-            for (int f = 0; f < D; ++f) {
-                // v 2^12 = h1 + h2: h1 = the leading 11 bits (exact in float16), h2 = float16(v 2^12 - h1)   (apply_split8)
-                const float a = o[f];
-                const float ah = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a) & 0xffffe000u);
-                const unsigned pk = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ah, a - ah));
-                sh[f * CC] = (unsigned short)(pk & 0xffffu);
-                sl[f * CC] = (unsigned short)(pk >> 16);
+            for (int q = 0; q < DP / 8; ++q) {
+                u32x4 vh, vl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int f0 = 8 * q + 2 * e;
+                    const float a0 = f0 < D ? o[f0 < D ? f0 : 0] : 0.0f, a1 = f0 + 1 < D ? o[f0 + 1 < D ? f0 + 1 : 0] : 0.0f;
+                    const float h0 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a0) & 0xffffe000u);
+                    const float h1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a1) & 0xffffe000u);
+                    vh[e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h0, h1));
+                    vl[e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a0 - h0, a1 - h1));
+                }
+                sh[q] = vh; sl[q] = vl;
             }
         }
     }
     if (!FUSED) return;
+    if (DS_ABL == 1) { if (threadIdx.x == 0 && stage_hi[5] == 0x1234) partial[0] = 1.0f; return; }
 
     __syncthreads();
     // ---- [FB x P] x [P x 2L] ------------------------------------------------------------------------------------------------------
@@ -272,8 +294,10 @@ desc_kernel(const float* __restrict__ cells, const int* __restrict__ cut, int N,
 }
 
 // regressor Rt[Mp][ldr] (row j = output column j, K contiguous) -> planes[L][k-steps][NT][2 pieces][64 lanes] of 8 float16:
-// lane (li = lane & 15, lq = lane >> 4) of fragment (l, ks, nt) holds R[l P + 32 ks + 8 lq + 0..7][16 nt + li] * 2^(14 - e(col))
-__global__ void __launch_bounds__(256) desc_planes_kernel(const float* __restrict__ Rt, long long ldr, int L, int P, int KSTEPS, int NT,
+// lane (li = lane & 15, lq = lane >> 4) of fragment (l, ks, nt) holds the staged operand's k' = 32 ks + 8 lq + 0..7 of column
+// 16 nt + li, times 2^(14 - e(col)): k' = cell * DP + f (cell row-major) is the regressor row l P + f C*C + ct(cell) (Matlab cell
+// order, adaptive_vlhog.hpp:166-175); padding features (f >= D) and k' beyond the last cell are zero
+__global__ void __launch_bounds__(256) desc_planes_kernel(const float* __restrict__ Rt, long long ldr, int L, int P, int C, int D, int DP, int KSTEPS, int NT,
                                                           const unsigned* __restrict__ rmax, f16x8* __restrict__ planes)
 {
     const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -284,10 +308,13 @@ __global__ void __launch_bounds__(256) desc_planes_kernel(const float* __restric
     const int col = 16 * nt + (lane & 15), k0 = 32 * ks + 8 * (lane >> 4);
     const float scale = __builtin_ldexpf(1.0f, 14 - desc_f16_exponent(rmax[col]));
     const float* src = Rt + (long long)col * ldr + (long long)l * P;
+    const int CC = C * C;
     f16x8 p1, p2;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const float v = (k0 + j < P) ? src[k0 + j] * scale : 0.0f;
+        const int kk = k0 + j, cell = kk / DP, f = kk - cell * DP;
+        const int y = cell / C, x = cell - y * C, ct = x * C + y;
+        const float v = (cell < CC && f < D) ? src[f * CC + ct] * scale : 0.0f;
         const _Float16 h1 = (_Float16)v;
         p1[j] = h1; p2[j] = (_Float16)(v - (float)h1);
     }
@@ -299,8 +326,7 @@ template <int TO, int VARIANT, bool FUSED, int FB, int W = DS_WAVES>
 void launch_desc(const float* cells, const int* cut, int N, int L, float* feat, long long ldf, int has_bias, const void* planes, int NT,
                  const unsigned* rmax, const float* Rt, long long ldr, float* partial, hipStream_t stream)
 {
-    constexpr int P = 25 * desc_dim(TO, VARIANT);
-    const size_t lds = FUSED ? desc_stage_bytes(P, FB) : 0;
+    const size_t lds = FUSED ? desc_stage_bytes(desc_pk(25, desc_dim(TO, VARIANT)), FB) : 0;
     const unsigned grid = (unsigned)(((long long)N + FB - 1) / FB * L);
     static unsigned long long seen = 0;
     if (FUSED && sdm_first_use_on_device(seen))
@@ -329,15 +355,16 @@ void sdm_launch_desc_store(const HogLevelDev& lv, const float* cells, const int*
 
 size_t sdm_desc_planes_bytes(const HogLevelDev& lv, int L, int M)
 {
-    const int KSTEPS = desc_kp(lv.P) / 32, NT = (M + 15) / 16;
+    const int KSTEPS = desc_kp(desc_pk(lv.C * lv.C, desc_dim(lv.O, lv.variant))) / 32, NT = (M + 15) / 16;
     return ((size_t)L * KSTEPS + 1) * NT * 2 * 64 * 16;      // (+ one k-step: a short k-part's look-behind fetch)
 }
 
 void sdm_launch_desc_planes(const HogLevelDev& lv, const float* Rt, long long ldr, int L, int M, const unsigned* rmax, void* planes, hipStream_t stream)
 {
-    const int KSTEPS = desc_kp(lv.P) / 32, NT = (M + 15) / 16;
+    const int D = desc_dim(lv.O, lv.variant), DP = desc_dp(D);
+    const int KSTEPS = desc_kp(desc_pk(lv.C * lv.C, D)) / 32, NT = (M + 15) / 16;
     const long long total = (long long)L * KSTEPS * NT * 64;
-    hipLaunchKernelGGL(desc_planes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, Rt, ldr, L, lv.P, KSTEPS, NT, rmax, (f16x8*)planes);
+    hipLaunchKernelGGL(desc_planes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, Rt, ldr, L, lv.P, lv.C, D, DP, KSTEPS, NT, rmax, (f16x8*)planes);
     hipError_t e = hipMemsetAsync((unsigned char*)planes + (size_t)L * KSTEPS * NT * 2 * 64 * 16, 0, (size_t)NT * 2 * 64 * 16, stream); (void)e;      // the look-behind padding
 }
 
