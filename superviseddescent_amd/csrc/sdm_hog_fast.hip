@@ -1047,7 +1047,9 @@ hog_fast_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float* 
 // and stored as soon as its last column has been folded; its histogram slot is then free for the patch three further on.
 // Same integer decisions and the same f32 operations per accumulator as hog_patch_fast<ACC_COLUMNS>, except that the cells
 // of a cut patch are the sum of two partial folds.
+#ifndef HP_WAVES
 #define HP_WAVES 4
+#endif
 #ifndef HP_ST
 #define HP_ST 66                    /* column-row stride: 64 pixel columns + 2 (2 * 66 = 4 mod 32 dwords: the sixteen bin rows of a fold read fall into 8 banks) */
 #endif
