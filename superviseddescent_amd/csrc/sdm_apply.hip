@@ -642,8 +642,7 @@ void sdm_launch_apply(const float* feat, long long ldf, int N, int F, const floa
             ATATTR(1); ATATTR(2); ATATTR(3); ATATTR(4, 128); ATATTR(5, 128); ATATTR(6, 128); ATATTR(7, 128); ATATTR(8, 128); ATATTR(9, 128);
 #undef ATATTR
         }
-        static const bool f32_only = getenv("SDM_APPLY_F32") && getenv("SDM_APPLY_F32")[0] == '1';      // (A/B: the f32 matrix-core kernel)
-        if (planes && rmax && !f32_only) {
+        if (planes && rmax) {      // (no planes: the f32 matrix-core kernel -- rows that are not plain HOG output, or SDM_APPLY_F32=1 at sdm_create)
             static unsigned long long attr16 = 0;
             if (sdm_first_use_on_device(attr16)) {
 #define AFATTR(...) SDM_SET_ATTR((const void*)apply_tiled_f16_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)

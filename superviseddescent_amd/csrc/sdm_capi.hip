@@ -71,7 +71,7 @@ struct sdm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    SolveAux solve_aux = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // second queue of the Cholesky look-ahead (+ the scratch of its float16 updates, set per solve)
+    SolveAux solve_aux = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};   // second queue of the Cholesky look-ahead (+ the scratch of its float16 updates, set per solve)
     DevBuf<unsigned char> upd_planes;    // one panel group as float16 planes (sdm_update_f16_plane_bytes)
     DevBuf<unsigned> upd_maxdiag;
 
@@ -97,6 +97,12 @@ struct sdm_ctx {
     bool fuse_apply = true;         // SDM_DETECT_UNFUSED=1: sdm_detect_batch through the feature matrix + apply GEMM (A/B)
     bool fuse_wide = false;         // sdm_debug_set_detect_path(fused = 2): fuse also when 2L > 64 (tests of the wide launch)
     bool packing = true;            // sdm_debug_set_hog_packing / SDM_HOG_NO_PACK=1: run the one-patch-per-wave kernel instead
+    // A/B switches of the environment, all read ONCE in sdm_create (no getenv inside a launch path)
+    bool env_fuse_wide = false;     // SDM_DETECT_FUSE_WIDE=1: fuse descriptor + apply also when 2L > 64
+    bool env_apply_f32 = false;     // SDM_APPLY_F32=1: sdm_apply always on the f32 matrix-core kernel
+    bool env_gram_f32 = false;      // SDM_GRAM_F32=1: Gram matrix on the f32 matrix-core kernel of rounds 1-2
+    bool env_gram_bf16 = false;     // SDM_GRAM_BF16X3=1: Gram matrix always in the three-bf16-piece form
+    int env_shard_emulate = 0;      // SDM_SOLVE_SHARD_EMULATE: timing harness of the sharded factorisation (scripts/sharded_solve_timing.py)
     int hog_mode = SDM_HOG_COLUMNS;
     int Fmax = 0;
     long long ldf = 0;      // feature row stride: round_up(Fmax,128) + 128*rhs_tiles (tail tiles = training targets)
@@ -396,8 +402,8 @@ int do_apply(sdm_ctx* c, int level)
         Timer t(c, SDM_T_APPLY);
         sdm_launch_apply(c->feat.p, c->ldf, c->N, F, c->Rt[level].p, c->ldf, c->M, c->x[c->cur].p,
                          c->x[c->cur ^ 1].p, c->L, c->eyes, c->partial.p, splits, c->stream,
-                         c->feat_bounded ? c->Rp[level].p : nullptr,
-                         (c->feat_bounded && c->Rp[level].p) ? c->Rmax.p + (size_t)level * Mp_of(c->M) : nullptr);
+                         (c->feat_bounded && !c->env_apply_f32) ? c->Rp[level].p : nullptr,
+                         (c->feat_bounded && !c->env_apply_f32 && c->Rp[level].p) ? c->Rmax.p + (size_t)level * Mp_of(c->M) : nullptr);
     }
     HIP_TRY(hipGetLastError());
     c->cur ^= 1;
@@ -411,8 +417,7 @@ bool fused_ok(const sdm_ctx* c, int level)
     // slice of the regressor from L2 -- 77 KB at 2L = 44, 230 KB at 2L = 136, where that traffic (4 GB per level at 8 192 samples)
     // makes the launch slower than writing the rows and running the GEMM (RCR-68 detect: 0.53 against 0.25 ms per level;
     // SDM_DETECT_FUSE_WIDE=1 fuses anyway)
-    static const bool fuse_wide = getenv("SDM_DETECT_FUSE_WIDE") && getenv("SDM_DETECT_FUSE_WIDE")[0] == '1';
-    return c->fuse_apply && (Mp_of(c->M) <= 64 || fuse_wide || c->fuse_wide) && split_ok(c, level) && c->have_R[level] && c->Rd[level].p &&
+    return c->fuse_apply && (Mp_of(c->M) <= 64 || c->env_fuse_wide || c->fuse_wide) && split_ok(c, level) && c->have_R[level] && c->Rd[level].p &&
            c->Rp[level].p && c->tmpl_N == 0;
 }
 // A cascade level of detect, fused: cells -> (descriptors x regressor slices) -> landmark update; the feature matrix is not
@@ -504,6 +509,13 @@ sdm_ctx* sdm_create(int device)
     { const char* np = getenv("SDM_HOG_NO_PACK"); c->packing = !(np && np[0] == '1'); }
     { const char* np = getenv("SDM_HOG_SPLIT_STORE"); c->split_store = np && np[0] == '1'; }
     { const char* np = getenv("SDM_DETECT_UNFUSED"); c->fuse_apply = !(np && np[0] == '1'); }
+    auto env_on = [](const char* name) { const char* v = getenv(name); return v && v[0] == '1'; };
+    c->env_fuse_wide = env_on("SDM_DETECT_FUSE_WIDE");
+    c->env_apply_f32 = env_on("SDM_APPLY_F32");
+    c->env_gram_f32 = env_on("SDM_GRAM_F32");
+    c->env_gram_bf16 = env_on("SDM_GRAM_BF16X3");
+    c->solve_aux.upd_f32_only = env_on("SDM_UPDATE_F32") ? 1 : 0;
+    { const char* v = getenv("SDM_SOLVE_SHARD_EMULATE"); c->env_shard_emulate = v ? atoi(v) : 0; }
     return c;
 }
 
@@ -1056,8 +1068,7 @@ int sdm_gram_rhs(sdm_ctx* c, int level)
     // float16 pieces (x 2^12), three piece products per product; should an operand leave float16's range -- a training target beyond
     // 14 inter-eye distances -- the launch is repeated with three bf16 pieces (float32's range, six products).  SDM_GRAM_F32=1: the
     // f32 matrix-core kernel of rounds 1-2 (A/B); SDM_GRAM_BF16X3=1: always the three-bf16 form.
-    static const bool gram_f32 = getenv("SDM_GRAM_F32") && getenv("SDM_GRAM_F32")[0] == '1';
-    static const bool gram_bf16 = getenv("SDM_GRAM_BF16X3") && getenv("SDM_GRAM_BF16X3")[0] == '1';
+    const bool gram_f32 = c->env_gram_f32, gram_bf16 = c->env_gram_bf16;
     // Scratch: the float16 form needs two planes (4 bytes per feature-matrix element); the third (bf16 repeat) is
     // allocated only when a launch actually overflowed.  If the scratch cannot be had (the feature matrix of 100 000 x 27 392 is
     // 11 GB, its planes another 11 / 16 GB) the f32 matrix-core kernel forms the Gram matrix from the rows in place.
@@ -1328,8 +1339,7 @@ int sdm_solve(sdm_ctx* c, int level, int reg_type, float reg_param, int regulari
             if ((rc = c->shard_stage.ensure(stage_need))) return rc;
             shard.rank = c->shard_rank; shard.world = c->shard_world; shard.stage = c->shard_stage.p; shard.stage_floats = stage_need; shard.self = c;
             shard.bcast = shard_bcast_thunk; shard.allgather = shard_allgather_thunk;
-            static const int emulate = getenv("SDM_SOLVE_SHARD_EMULATE") ? atoi(getenv("SDM_SOLVE_SHARD_EMULATE")) : 0;
-            shard.emulate_chain = emulate;
+            shard.emulate_chain = c->env_shard_emulate;
         }
         if (c->solver_kind == SDM_SOLVER_COLPIV_QR) {
             if (sharded || c->g_scattered) return fail(SDM_ERR_INVALID, "sdm_solve: the column-pivoted QR solver is not sharded over ranks");

@@ -807,8 +807,6 @@ __device__ void hog_patch_fast(const ImageSetDev& imgs, int im_in, const float* 
         const float* bp = wt + lq * 16 + li;
         // (ST is a multiple of 8: an even number of k steps, two per trip, one accumulator each; a plain counted loop keeps
         // the accumulators in place -- guarding unrolled steps individually makes the compiler shuttle them through VGPRs)
-        // (ST is a multiple of 8: an even number of k steps, two per trip, one accumulator each; a plain counted loop keeps
-        // the accumulators in place -- guarding unrolled steps individually makes the compiler shuttle them through VGPRs)
         for (int kp = 0; kp < KST / 8; ++kp) {
             const float bw0 = bp[0], bw1 = bp[64];
 #pragma unroll

@@ -250,6 +250,7 @@ struct SolveAux {
     // and three scale words (largest diagonal entry, largest right-hand-side entry of the group x two slots); null = every trailing update on the f32 matrix-core kernel
     void* upd_planes; unsigned* upd_maxdiag;      // (upd_maxdiag: 4 words -- largest diagonal entry, two right-hand-side scale slots, smallest diagonal entry)
     int* range_fallbacks;                          // host counter: factorisations whose diagonal spanned > 2^20 and therefore ran their updates in f32 (may be null)
+    int upd_f32_only;                              // A/B (SDM_UPDATE_F32=1, read at sdm_create): every trailing update on the f32 matrix-core kernel
 };
 size_t sdm_update_f16_plane_bytes(int rows_max, int ncols);
 void sdm_launch_diag_absmax(const float* G, long long ldg, int F, unsigned* scales, hipStream_t stream);

@@ -978,7 +978,7 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
     // sides; the back substitution is replicated.
     const int LAZY = 4;
     const bool overlap = aux && aux->stream && Tf > 2 * LAZY;
-    static const bool upd_f32_only = getenv("SDM_UPDATE_F32") && getenv("SDM_UPDATE_F32")[0] == '1';      // (A/B: every trailing update on the f32 kernel)
+    const bool upd_f32_only = aux && aux->upd_f32_only;      // (A/B: every trailing update on the f32 kernel)
     const int upd_min_tiles = 40;      // trailing tiles from which the float16-piece update pays (its split pre-pass is per panel group)
     bool upd_f16 = aux && aux->upd_planes && aux->upd_maxdiag && !upd_f32_only;
     if (upd_f16) {
