@@ -48,3 +48,24 @@ def test_bench_under_torchrun(built):
     out = json.loads(line)
     assert out["n_gpus"] == n and out["value"] > 0 and out["scaling"] == "weak"
     assert "RCCL" in out["train"]["collective"] and out["train"]["solve"].startswith("sharded")
+
+
+@pytest.mark.gpu
+def test_bench_several_gpu_order_and_watchdog(built):
+    """With more than one GPU bench.py runs its RCR-68 legs BEHIND the headline measurement and under a watchdog that emits the
+    headline line if their collectives hang.  The order is exercised here on the visible GPUs (SDM_BENCH_DEFER_RCR68=1), and the
+    watchdog by a deadline of zero seconds: the line must still be one valid JSON object with the headline and the legs marked."""
+    import json
+    import torch
+    n = min(torch.cuda.device_count(), 2)
+    common = ("--gpus", str(n), "--steps", "2", "--warmup", "1", "--batch", "256", "--train-rows", "800", "--rcr68-shard", "256", "--no-cpu")
+    r = _torchrun(n, os.path.join(ROOT, "bench.py"), *common, SDM_BENCH_DEFER_RCR68="1")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["value"] > 0 and out["rcr68_train"]["sec_per_cascade"] > 0 and out["rcr68_detect_shard"]["value"] > 0
+    r = _torchrun(n, os.path.join(ROOT, "bench.py"), *common, SDM_BENCH_DEFER_RCR68="1", SDM_BENCH_RCR68_DEADLINE_S="0")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["value"] > 0 and out["n_gpus"] == n and "error" in out["rcr68_train"] and out["roofline"]["frac"] > 0
