@@ -146,13 +146,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the measured path")
+    # SDM_BENCH_BACKEND=gloo (tests): the several-GPU path run by several real processes on however many GPUs there are -- gloo moves
+    # device tensors through the host, so two ranks may share one GPU, which RCCL refuses.  The ranks then share devices round-robin.
+    backend = os.environ.get("SDM_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     # launched by torch.distributed.run (RANK/WORLD_SIZE/MASTER_* in the env): the collective path is taken even
     # at WORLD_SIZE=1, so that one GPU exercises exactly the code N GPUs run
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     re, le = ibug.eye_indices(ids)
     params = [HoGParam(*p) for p in ibug.SHIPPED_HOG_PARAMS]   # apps/rcr/rcr-train.cpp:447

@@ -69,3 +69,35 @@ def test_bench_several_gpu_order_and_watchdog(built):
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["value"] > 0 and out["n_gpus"] == n and "error" in out["rcr68_train"] and out["roofline"]["frac"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_training_collectives_with_real_processes(built, world):
+    """World sizes > 1 through the product's exchange callbacks with REAL processes: torch.distributed's gloo backend moves device
+    tensors through the host, so the ranks may share the one GPU of the test box (RCCL refuses two ranks per device).  The worker
+    trains with the all-reduce, with the sharded factorisation (broadcast + all-gather per step / group) and with the
+    reduce-scatter exchange, and checks: identical regressors on every rank in all three forms, sharded == replicated bit for bit,
+    the expected number of collectives, and the regressors (5e-5; measured 2e-5) and landmarks (1e-6; measured 2e-8) of single-process training on all rows."""
+    r = _torchrun(world, os.path.join(ROOT, "tests", "_rccl_worker.py"), SDM_TEST_BACKEND="gloo")
+    assert r.returncode == 0 and "RCCL_WORKER_OK world=%d" % world in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.gpu
+def test_bench_with_two_real_processes(built):
+    """bench.py --gpus 2 as two real processes (gloo, sharing the GPU): the several-GPU order -- headline first, then the legs with
+    collectives under the watchdog -- the RCR-22 all-reduce training, and the RCR-68 leg with the reduce-scatter exchange and the
+    factorisation sharded over the two ranks."""
+    import json
+    r = _torchrun(2, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "512", "--train-rows", "4000",
+                  "--rcr68-shard", "256", "--no-cpu", SDM_BENCH_BACKEND="gloo", timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    assert "all-reduce" in out["train"]["collective"] and out["train"]["sec_per_cascade"] > 0
+    assert out["rcr68_train"]["solve"].startswith("sharded") and "reduce-scatter" in out["rcr68_train"]["collective"]
+    nl = out["rcr68_train"]["nlsr_per_level_rank0"]
+    assert len(nl) == 4 and all(b < a for a, b in zip(nl, nl[1:]))              # the cascade trained by two ranks converges
+    assert out["rcr68_detect_shard"]["value"] > 0
