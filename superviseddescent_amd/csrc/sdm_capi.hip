@@ -83,7 +83,7 @@ struct sdm_ctx {
     std::vector<int> fast_kernel;   // per level: fused S<=64 kernel usable
     std::vector<int> fast_bins;     // per level: un-normalised arg-max verified on all 511x511 gradients
     // per level: lane-packed launch plan (sdm_hog_fast.hip::hog_packed_kernel), device tables owned here
-    struct Plan { bool ok = false; HogPlanDev dev{}; DevBuf<unsigned> lane_tab; DevBuf<float> wb; DevBuf<int> pass_info; DevBuf<int> cut; DevBuf<int> taps; };
+    struct Plan { bool ok = false; HogPlanDev dev{}; DevBuf<unsigned> lane_tab; DevBuf<float> wb; DevBuf<unsigned short> wb16; DevBuf<int> pass_info; DevBuf<int> cut; DevBuf<int> taps; };
     std::vector<Plan> plans;
     // round 4: the packed launch stops at the raw cell histograms (cells[N][L][2][2O][C*C]); sdm_desc.hip normalises them into the
     // feature rows, or -- sdm_detect_batch -- multiplies the descriptors by the regressor without writing the feature matrix
@@ -540,7 +540,7 @@ void sdm_destroy(sdm_ctx* c)
     c->cells.release(); c->qr_work.release();
     c->Rmax.release();
     for (auto& r : c->Rt) r.release();
-    for (auto& q : c->plans) { q.lane_tab.release(); q.wb.release(); q.pass_info.release(); q.cut.release(); q.taps.release(); }
+    for (auto& q : c->plans) { q.lane_tab.release(); q.wb.release(); q.wb16.release(); q.pass_info.release(); q.cut.release(); q.taps.release(); }
     if (c->own_stream) e = hipStreamDestroy(c->stream);
     delete c;
 }
@@ -665,14 +665,14 @@ int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int*
     // early returns leaked them), the context's previous tables after the swap at the commit
     struct PlanGuard {
         std::vector<sdm_ctx::Plan>& v;
-        ~PlanGuard() { for (auto& q : v) { q.lane_tab.release(); q.wb.release(); q.pass_info.release(); q.cut.release(); q.taps.release(); } }
+        ~PlanGuard() { for (auto& q : v) { q.lane_tab.release(); q.wb.release(); q.wb16.release(); q.pass_info.release(); q.cut.release(); q.taps.release(); } }
     } plan_guard{n_plans};
     for (int l = 0; l < n_levels; ++l) {
         HogPlanHost hp;
         if (!n_fast_kernel[l] || n_fast_bins[l] != 2 || !sdm_hog_plan_build(n_levels_dev[l], L, hp)) continue;
         sdm_ctx::Plan& pl = n_plans[l];
         int rcp;
-        if ((rcp = pl.lane_tab.ensure(hp.lane_tab.size())) || (rcp = pl.wb.ensure(hp.wb.size())) ||
+        if ((rcp = pl.lane_tab.ensure(hp.lane_tab.size())) || (rcp = pl.wb.ensure(hp.wb.size())) || (rcp = pl.wb16.ensure(hp.wb16.size())) ||
             (rcp = pl.pass_info.ensure(hp.pass_info.size())) || (rcp = pl.cut.ensure(hp.cut.size())))
             return rcp;
         HIP_TRY(hipMemcpyAsync(pl.cut.p, hp.cut.data(), hp.cut.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
@@ -680,11 +680,12 @@ int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int*
         sdm_launch_taps_table(n_levels_dev[l], pl.taps.p, c->stream);
         HIP_TRY(hipMemcpyAsync(pl.lane_tab.p, hp.lane_tab.data(), hp.lane_tab.size() * sizeof(unsigned), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(pl.wb.p, hp.wb.data(), hp.wb.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(pl.wb16.p, hp.wb16.data(), hp.wb16.size() * sizeof(unsigned short), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(pl.pass_info.p, hp.pass_info.data(), hp.pass_info.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));      // (the host vectors go out of scope)
         pl.dev.G = hp.G; pl.dev.P = hp.P; pl.dev.n_main = hp.n_main; pl.dev.Gt = hp.Gt; pl.dev.Pt = hp.Pt; pl.dev.hist_slots = hp.hist_slots;
         pl.dev.raw_sqrt = n_raw_sqrt[l];
-        pl.dev.lane_tab = pl.lane_tab.p; pl.dev.wb = pl.wb.p; pl.dev.pass_info = pl.pass_info.p; pl.dev.taps = pl.taps.p;
+        pl.dev.lane_tab = pl.lane_tab.p; pl.dev.wb = pl.wb.p; pl.dev.wb16 = pl.wb16.p; pl.dev.pass_info = pl.pass_info.p; pl.dev.taps = pl.taps.p;
         pl.ok = true;
     }
     // ---- commit ----

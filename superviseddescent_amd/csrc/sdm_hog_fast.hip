@@ -1242,6 +1242,12 @@ __host__ __device__ constexpr int packed_band_of(int d, int cell)
 #ifndef HP_PAIRFOLD
 #define HP_PAIRFOLD 1               /* CELLS, 4 orientations: the last two bands of a pass in one set of matrix-core products */
 #endif
+#ifndef HP_F16FOLD
+#define HP_F16FOLD 1                /* 4 orientations, specialised instances: band folds on the 16-bit matrix cores (column sums x 8 and weights x 2^10 as two float16 pieces each, four piece products) */
+#endif
+#ifndef HP_F16FOLD_PRODUCTS
+#define HP_F16FOLD_PRODUCTS 4       /* 3: without low x low */
+#endif
 #ifndef HP_SPLIT_PASSES
 #define HP_SPLIT_PASSES 1           /* CELLS: one pass per wave instead of one group of patches per wave */
 #endif
@@ -1350,7 +1356,8 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
     } else if (lane < S + 2) rowtab[lane] = row_ent;
     // (every wave of the workgroup writes the same values; a wave's own LDS accesses execute in order, so it reads what it -- or
     //  a neighbour, identically -- wrote: no workgroup barrier)
-    if (SPEC && lane < S) wstab[lane] = (f32x2){lv.row_tab[lane][0], lv.row_tab[lane][1]};
+    constexpr bool F16F = TO == 4 && CELL > 0 && HP_F16FOLD;      // (column sums carry a factor 8: exact, undone with the weights' 2^10 after the fold)
+    if (SPEC && lane < S) wstab[lane] = (f32x2){lv.row_tab[lane][0], lv.row_tab[lane][1]} * (F16F ? 8.0f : 1.0f);
     if (!SPEC && S + 2 > 64 && lane < S + 2 - 64) {
         i32x4 last;
 #pragma unroll
@@ -1401,9 +1408,10 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
         // rows above or below the image fall outside the buffer's num_records: the hardware range check returns 0 (black canvas)
         const int vb = pl + y0 * istride;
         // ---- fold weights of the pass (matrix-core B operand) and the histogram cell column this lane receives ------------------
-        f32x4 wq[4];
+        f32x4 wq[4];      // (F16F: the same sixteen registers hold the float16 pieces, [k-block][piece] x 8 halfs)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wq[i] = ((const f32x4*)(plan.wb + ((size_t)pt * 64 + lane) * 16))[i];
+        for (int i = 0; i < 4; ++i)
+            wq[i] = F16F ? ((const f32x4*)(plan.wb16 + ((size_t)pt * 64 + lane) * 32))[i] : ((const f32x4*)(plan.wb + ((size_t)pt * 64 + lane) * 16))[i];
         const int* pinfo = plan.pass_info + pt * 4;
         const int sg = li < C ? 0 : (li < 2 * C ? 1 : (li < 3 * C ? 2 : 3));
         const int seg_slot = sg == 0 ? pinfo[0] : (sg == 1 ? pinfo[1] : (sg == 2 ? pinfo[2] : -1));
@@ -1473,6 +1481,38 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
                 if (pair) { bin_i = li & 7; sl_i = (li >> 3) ? (sl ^ 1) : sl; }
                 ap[mt] = colrows + ((ROTB ? (int)HP_ROW_OF_BIN(bin_i) : bin_i) * ST + lq) * 2 + sl_i;
             }
+            if constexpr (F16F) {
+                // 16-bit matrix cores: A[row][k = 32 kb + 8 lq + j] = this lane's row of column sums at eight consecutive pixel columns
+                // (stride two floats: the other band slot lies between), split into two float16 pieces; B = the weights' pieces
+                typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+                const float* arow = colrows + (ROTB ? (int)HP_ROW_OF_BIN(pair ? (li & 7) : (li < 2 * O ? li : 2 * O - 1)) : (pair ? (li & 7) : (li < 2 * O ? li : 2 * O - 1))) * ST * 2
+                                    + ((pair && (li >> 3)) ? (sl ^ 1) : sl) + 16 * lq;
+                f32x4 facc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = arow[64 * kb + 2 * j];
+                    unsigned hp_[4], lp_[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float h0 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v[2 * e]) & 0xffffe000u);
+                        const float h1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v[2 * e + 1]) & 0xffffe000u);
+                        hp_[e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h0, h1));
+                        lp_[e] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v[2 * e] - h0, v[2 * e + 1] - h1));
+                    }
+                    typedef unsigned u32x4f __attribute__((ext_vector_type(4)));
+                    const f16x8 ah = __builtin_bit_cast(f16x8, (u32x4f){hp_[0], hp_[1], hp_[2], hp_[3]});
+                    const f16x8 al = __builtin_bit_cast(f16x8, (u32x4f){lp_[0], lp_[1], lp_[2], lp_[3]});
+                    const f16x8 bh = __builtin_bit_cast(f16x8, wq[2 * kb]), bl = __builtin_bit_cast(f16x8, wq[2 * kb + 1]);
+                    if (HP_F16FOLD_PRODUCTS == 4) facc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bl, facc, 0, 0, 0);
+                    facc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, facc, 0, 0, 0);
+                    facc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, facc, 0, 0, 0);
+                    facc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, facc, 0, 0, 0);
+                }
+                fa0[0] = facc * (1.0f / 8192.0f);      // 8 (column sums) x 2^10 (weights)
+                // fa1[0] stays zero: the stores below add the two accumulators
+            } else {
             // the operand reads run two k-step pairs ahead of the products (the scheduling barriers keep that order: with the
             // reads serialised behind the products every fold cost eight LDS round trips)
             float a0v[MT][3], a1v[MT][3];
@@ -1500,6 +1540,7 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+            }
             }
             // every lane clears the slot(s) of its own pixel column (the LDS unit executes this wave's accesses in order)
             if (pair) {
@@ -1792,6 +1833,7 @@ bool sdm_hog_plan_build(const HogLevelDev& lv, int L, HogPlanHost& out)
     }
     out.lane_tab.assign((size_t)NP * 64, 0u);
     out.wb.assign((size_t)NP * 64 * 16, 0.0f);
+    out.wb16.assign((size_t)NP * 64 * 32, 0);
     out.pass_info.assign((size_t)NP * 4, -1);
     for (int pt = 0; pt < NP; ++pt) {
         const std::vector<PlanLane>& pl = pt < out.P ? main_p[pt] : tail_p[pt - out.P];
@@ -1824,6 +1866,19 @@ bool sdm_hog_plan_build(const HogLevelDev& lv, int L, HogPlanHost& out)
         if (nseg > out.hist_slots) out.hist_slots = nseg;
         for (int l = 0; l < 64; ++l)
             for (int ks = 0; ks < 16; ++ks) out.wb[((size_t)pt * 64 + l) * 16 + ks] = W[4 * ks + (l >> 4)][l & 15];
+        // the same weights as two float16 pieces (x 2^10: the second piece of the smallest weight 1 / 24 stays a normal number) in the
+        // B-operand layout of v_mfma_f32_16x16x32_f16: lane (li, lq) holds k = 32 kb + 8 lq + 0..7 of column li
+        for (int l = 0; l < 64; ++l)
+            for (int kb = 0; kb < 2; ++kb)
+                for (int j = 0; j < 8; ++j) {
+                    const float w = W[32 * kb + 8 * (l >> 4) + j][l & 15] * 1024.0f;
+                    const _Float16 h1 = (_Float16)w;
+                    const _Float16 h2 = (_Float16)(w - (float)h1);
+                    unsigned short b1, b2;
+                    memcpy(&b1, &h1, 2); memcpy(&b2, &h2, 2);
+                    out.wb16[(((size_t)pt * 64 + l) * 2 + kb) * 16 + j] = b1;
+                    out.wb16[(((size_t)pt * 64 + l) * 2 + kb) * 16 + 8 + j] = b2;
+                }
     }
     return true;
 }

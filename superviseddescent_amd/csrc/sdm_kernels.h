@@ -100,6 +100,7 @@ struct HogPlanDev {
     int raw_sqrt;              // v_sqrt_f32 found exact-or-one-ulp-low on all 511^2 gradients on THIS device (else: repaired root)
     const unsigned* lane_tab;
     const float* wb;
+    const unsigned short* wb16; // [pass][lane][2 k-blocks][2 pieces][8] float16 bits: the same weights x 2^10 as two float16 pieces in the layout of v_mfma_f32_16x16x32_f16's B operand (HP_F16FOLD)
     const int* pass_info;
     const int* taps;           // [SDM_SCALE_TAB half-widths][64 coordinates][8] cv::resize taps of the level (sdm_launch_taps_table); null = computed per wave
 };
@@ -109,6 +110,7 @@ struct HogPlanHost {
     int G = 0, P = 0, n_main = 0, Gt = 0, Pt = 0, hist_slots = 2;
     std::vector<unsigned> lane_tab;
     std::vector<float> wb;
+    std::vector<unsigned short> wb16;
     std::vector<int> pass_info;
     std::vector<int> cut;      // [L] 1: the landmark's patch is cut by a pass boundary (its raw cells arrive in two parts)
 };
