@@ -282,7 +282,7 @@ def main():
                 "solve_ms": (timing68["factor_solve"][0] + timing68["backsolve"][0]) / n_levels,
                 "nlsr_per_level_rank0": list(nlsr68),
             }}
-        return rcr68, ctx68, F68, L68, M68
+        return rcr68, ctx68, F68, L68, M68, sdo68
 
     # With ONE GPU the leg runs here, as in every round so far.  With several it runs BEHIND the headline measurement and under a
     # watchdog (below): its exchange -- a reduce-scatter + 213 broadcasts + 54 all-gathers per level through RCCL -- has only ever
@@ -290,7 +290,7 @@ def main():
     # take the headline of the scaling run with it.
     rcr68 = None
     if args.rcr68_shard > 0 and not defer68:
-        rcr68, ctx68, F68, L68, M68 = train_rcr68()
+        rcr68, ctx68, F68, L68, M68, sdo68 = train_rcr68()
 
     # ---- workload: this rank's shard of synthetic faces, resident in HBM --------------------------------
     x_star, x0, _ = synth.make_samples(boxes[:args.batch], gt[:args.batch], ids, 0, seed=synth.SEED + 17 * rank + 1)
@@ -472,7 +472,7 @@ def main():
         train_s = time.time() - t0
         sdo_d.ctx.close()
         if args.rcr68_shard > 0:
-            rcr68, ctx68, F68, L68, M68 = train_rcr68()
+            rcr68, ctx68, F68, L68, M68, sdo68 = train_rcr68()
 
     # ---- BASELINE config 4: RCR-68 detect on this rank's shard (65 536 faces over 8 GPUs = 8 192 per GPU), the cascade just
     # trained, inputs resident; same timing discipline as the headline (barrier + synchronize, max over ranks) ------------------
@@ -582,7 +582,7 @@ def main():
 
     # compute-side roofline of the same launch: what the vector-instruction issue alone would take (profiles/r04_issue_model.json,
     # scripts/isa_issue_model.py: per-class instruction counts of the unrolled pass from the ISA x the issue clocks measured on
-    # this chip, + the f32 matrix instructions of the band folds, which slow the vector pipe of their SIMD 2.5x while they run)
+    # this chip, + the vector clocks lost while the band folds' matrix instructions run on the same SIMD)
     compute_roof = None
     try:
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_issue_model.json")) as fh:
@@ -592,7 +592,7 @@ def main():
             pred = []
             for c in cells:
                 e = im["levels"][str(c)]
-                clocks = e["valu_clocks_row_loop_and_folds"] + 0.6 * e["mfma_clocks_per_pass"]      # (set-up not counted: a lower bound)
+                clocks = e["valu_clocks_row_loop_and_folds"] + e["valu_clocks_lost_beside_mfma_per_pass"]      # (set-up not counted: a lower bound)
                 pred.append(args.batch * e["passes_per_face"] * clocks / 1024.0 / 2.4e9 * 1e3)
             pred_ms = sum(pred) / len(pred)
             compute_roof = {"bound": "valu_issue", "predicted_avg_launch_ms": pred_ms, "measured_avg_launch_ms": hog_avg_ms,

@@ -26,7 +26,7 @@ def cls(op):
 src = open(ASM).read()
 # geometry of the shipped levels: (cell, S, passes per face with the one-pass-per-wave plan)
 LEVELS = {11: (55, 22), 10: (50, 18), 8: (40, 15), 6: (30, 11)}
-out = {"rates_clocks_per_wave_instruction": RATE, "mfma_f32_16x16x4_clocks": 32, "levels": {}}
+out = {"rates_clocks_per_wave_instruction": RATE, "mfma_clocks": {"f32_16x16x4": 32, "f16_16x16x32": 17}, "levels": {}}
 for m in re.finditer(r"^(_Z\S*hog_packed_kernelILi4ELi5ELi(\d+)ELb1ELb1E\S*):", src, re.M):
     cell = int(m.group(2))
     if cell not in LEVELS: continue
@@ -48,11 +48,17 @@ for m in re.finditer(r"^(_Z\S*hog_packed_kernelILi4ELi5ELi(\d+)ELb1ELb1E\S*):", 
     lc, lvalu = price(loop)
     sc, svalu = price(setup)
     S, ppf = LEVELS[cell]
-    # the pair fold site and the two single-fold sites it replaces are both in the code; a pass executes 3 single folds + 1 pair fold = 64 matrix instructions
-    mfma_exec = 64
+    # the pair fold site and the two single-fold sites it replaces are both in the code (5 sites); a pass executes 3 single folds + 1 pair
+    # fold = 4/5 of the static matrix instructions.  f32 16x16x4: 32 clocks each, the vector pipe of the SIMD runs at 40 % meanwhile;
+    # f16 16x16x32 (round 4: the folds on float16 pieces): 17 clocks, vector pipe at 58 % (profiles/r04_ubench_mfma_valu_overlap.txt)
+    f16 = sum(1 for o in loop if o.startswith("v_mfma_f32_16x16x32_f16"))
+    f32 = sum(1 for o in loop if o.startswith("v_mfma_f32_16x16x4_f32") or o.startswith("v_mfma_f32_16x16x4f32"))
+    mfma_clocks = (f16 * 17 + f32 * 32) * 4 // 5
+    valu_loss = (f16 * 17 * 0.42 + f32 * 32 * 0.60) * 4 / 5
     out["levels"][str(cell)] = {"rows": S, "passes_per_face": ppf, "row_loop_and_folds": lc, "setup_static": sc,
                                 "valu_clocks_row_loop_and_folds": lvalu, "valu_clocks_per_row": lvalu / S,
-                                "valu_clocks_setup_static_upper_bound": svalu, "mfma_clocks_per_pass": mfma_exec * 32}
+                                "valu_clocks_setup_static_upper_bound": svalu, "mfma_clocks_per_pass": mfma_clocks,
+                                "valu_clocks_lost_beside_mfma_per_pass": valu_loss, "mfma_static": {"f16_16x16x32": f16, "f32_16x16x4": f32}}
 json.dump(out, open(os.path.join(ROOT, "profiles", "r04_issue_model.json"), "w"), indent=1)
 for k, v in out["levels"].items():
     print(k, {kk: vv for kk, vv in v.items() if not isinstance(vv, dict)}, v["row_loop_and_folds"])
