@@ -1248,6 +1248,9 @@ __host__ __device__ constexpr int packed_band_of(int d, int cell)
 #ifndef HP_F16FOLD_PRODUCTS
 #define HP_F16FOLD_PRODUCTS 4       /* 3: without low x low */
 #endif
+#ifndef HP_ALIGNBIT_CODE
+#define HP_ALIGNBIT_CODE 1
+#endif
 #ifndef HP_SPLIT_PASSES
 #define HP_SPLIT_PASSES 1           /* CELLS: one pass per wave instead of one group of patches per wave */
 #endif
@@ -1633,7 +1636,12 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
                 if constexpr (HP_ABL == 9) pend_p = (lds_f32x2*)(size_t)cadr0;
                 else if constexpr (ROTB && HP_SIGNBITS) {
                     // the octant code straight from the three sign bits (shifts and shift-ors instead of three compares and three selects)
+#if HP_ALIGNBIT_CODE
+                    // v_alignbit_b32(hi, lo, 31) = (hi << 1) | (lo >> 31): one instruction per further sign bit
+                    const unsigned code = __builtin_amdgcn_alignbit(__builtin_amdgcn_alignbit(rot_ux >> 31, rot_uy, 31), rot_uw, 31);
+#else
                     const unsigned code = ((((rot_ux >> 31) << 1) | (rot_uy >> 31)) << 1) | (rot_uw >> 31);
+#endif
                     pend_p = (lds_f32x2*)(size_t)(cadr0 + code * bin_stride);
                 } else if constexpr (TO == 4)
                     pend_p = (lds_f32x2*)(size_t)((b0 ? cadr1 : cadr0) + ((b1 ? 2u * bin_stride : 0u) + (b2 ? 4u * bin_stride : 0u)));
