@@ -181,3 +181,29 @@ def test_apply_of_rows_that_are_not_hog_output(ctx):
     ied = 1.0 / orc.InterEyeDistanceNormalisation(RE22, LE22)(x0)[:, :1].astype(np.float64)
     want = x0.astype(np.float64) - ((feat.astype(np.float64) - tmpl.astype(np.float64)) @ R.astype(np.float64)) * ied
     assert np.abs(x1 - want).max() / np.abs(want - x0).max() < 1e-5
+
+
+@pytest.mark.parametrize("level", [0, 3])
+def test_band_folds_at_the_largest_possible_column_sums(ctx, level):
+    """The band folds run on float16 pieces of the column sums x 8 (csrc/sdm_hog_fast.hip, HP_F16FOLD): the largest sum a band slot
+    can hold is cell x 255 sqrt(2) (a full-contrast checkerboard under the triangular row weights) = 3 967 at cell 11, x 8 = 31 736 <
+    65 504.  Images of 0 / 255 noise and of a one-pixel checkerboard drive the sums to that corner: features finite and as close to
+    the oracle as on natural images."""
+    rng = np.random.default_rng(7)
+    n = 24
+    images, boxes, gt = synth.make_faces(n, seed=371)
+    images = images.copy()
+    images[: n // 2] = (rng.integers(0, 2, images[: n // 2].shape) * 255).astype(np.uint8)
+    yy, xx = np.mgrid[0:images.shape[1], 0:images.shape[2]]
+    images[n // 2:] = (((yy + xx) & 1) * 255).astype(np.uint8)[None]
+    _, x0, _ = synth.make_samples(boxes, gt, IDS22, n_perturb=0, seed=372)
+    ctx.set_model_geometry(22, RE22, LE22, SHIPPED)
+    ctx.upload_images(images)
+    ctx.set_sample_image_index(None)
+    ctx.set_x(x0)
+    ofeat = orc.hog_features_batch(images, None, x0, RE22, LE22, O_SHIPPED[level], n_threads=NT)
+    for split in (False, True):
+        ctx.set_detect_path(split_store=split)
+        f = ctx.hog_features(level, fetch=True)
+        assert np.isfinite(f).all()
+        assert np.abs(f - ofeat).max() <= 1e-6 and rel_l2(f, ofeat) <= 5e-7
