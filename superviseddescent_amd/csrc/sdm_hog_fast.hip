@@ -1359,7 +1359,8 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
     } else if (lane < S + 2) rowtab[lane] = row_ent;
     // (every wave of the workgroup writes the same values; a wave's own LDS accesses execute in order, so it reads what it -- or
     //  a neighbour, identically -- wrote: no workgroup barrier)
-    constexpr bool F16F = TO == 4 && CELL > 0 && HP_F16FOLD;      // (column sums carry a factor 8: exact, undone with the weights' 2^10 after the fold)
+    constexpr bool F16F = TO == 4 && CELL > 0 && HP_F16FOLD;
+    static_assert(!F16F || CELL * 361 * 8 < 65504, "float16 folds: a band slot's column sum (<= cell x 255 sqrt 2) x 8 must stay a float16 number");      // (column sums carry a factor 8: exact, undone with the weights' 2^10 after the fold)
     if (SPEC && lane < S) wstab[lane] = (f32x2){lv.row_tab[lane][0], lv.row_tab[lane][1]} * (F16F ? 8.0f : 1.0f);
     if (!SPEC && S + 2 > 64 && lane < S + 2 - 64) {
         i32x4 last;
