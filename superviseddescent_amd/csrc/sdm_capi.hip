@@ -156,6 +156,14 @@ struct sdm_ctx {
     DevBuf<float> Rsol;    // [Fp][Mp_ld]
     DevBuf<float> winv;    // [Fp/128][128][128] transposed inverses of the diagonal factor tiles
     DevBuf<int> gram_flag;               // raised by the float16 split when an operand leaves float16's range
+    // exchange behind the Gram kernel (round 4): with the factorisation sharded and a reduce-scatter installed, the Gram matrix is
+    // multiplied in up to SDM_XBLOCKS ranges of tile columns; an event behind each range lets the second queue ship that range's
+    // tiles (pack -> reduce-scatter -> unpack) while the next range is being multiplied
+    static const int XBLOCKS_MAX = 8;
+    hipEvent_t gram_ev[XBLOCKS_MAX] = {}; hipEvent_t gram_xdone = nullptr;
+    int gram_blocks = 0;                 // ranges of the Gram matrix in G (0: one launch, no events recorded)
+    int gram_block_c[XBLOCKS_MAX + 1] = {};      // their boundaries in OWNED column numbers (tile column = rank + world * number)
+    int env_xblocks = -1;                // SDM_GRAM_XBLOCKS: -1 = automatic (4 from 128 tile columns on), 1 = never, n = always n
     int gram_fallbacks = 0;              // launches repeated with three bf16 pieces (sdm_debug_gram_fallbacks)
     int update_range_fallbacks = 0;      // factorisations that ran their trailing updates in f32 because the diagonal spanned > 2^20
     int gram_f32_fallbacks = 0;          // launches that ran on the f32 matrix-core kernel because the planes could not be allocated
@@ -510,6 +518,10 @@ sdm_ctx* sdm_create(int device)
     { const char* np = getenv("SDM_HOG_SPLIT_STORE"); c->split_store = np && np[0] == '1'; }
     { const char* np = getenv("SDM_DETECT_UNFUSED"); c->fuse_apply = !(np && np[0] == '1'); }
     auto env_on = [](const char* name) { const char* v = getenv(name); return v && v[0] == '1'; };
+    for (int b = 0; b < sdm_ctx::XBLOCKS_MAX; ++b)
+        if (hipEventCreateWithFlags(&c->gram_ev[b], hipEventDisableTiming) != hipSuccess) { fail(SDM_ERR_HIP, "hipEventCreate failed"); delete c; return nullptr; }
+    if (hipEventCreateWithFlags(&c->gram_xdone, hipEventDisableTiming) != hipSuccess) { fail(SDM_ERR_HIP, "hipEventCreate failed"); delete c; return nullptr; }
+    { const char* v = getenv("SDM_GRAM_XBLOCKS"); c->env_xblocks = v ? atoi(v) : -1; }
     c->env_fuse_wide = env_on("SDM_DETECT_FUSE_WIDE");
     c->env_apply_f32 = env_on("SDM_APPLY_F32");
     c->env_gram_f32 = env_on("SDM_GRAM_F32");
@@ -527,6 +539,8 @@ void sdm_destroy(sdm_ctx* c)
     if (c->solve_aux.stream) {
         e = hipStreamSynchronize(c->solve_aux.stream);
         e = hipEventDestroy(c->solve_aux.chain_done); e = hipEventDestroy(c->solve_aux.tail_done);
+        for (int b = 0; b < sdm_ctx::XBLOCKS_MAX; ++b) if (c->gram_ev[b]) e = hipEventDestroy(c->gram_ev[b]);
+        if (c->gram_xdone) e = hipEventDestroy(c->gram_xdone);
         e = hipStreamDestroy(c->solve_aux.stream);
     }
     drain_timing(c);
@@ -1061,6 +1075,7 @@ int sdm_gram_rhs(sdm_ctx* c, int level)
     int rc = c->G.ensure((size_t)ncols * ncols);
     if (rc) return rc;
     c->g_scattered = false;
+    c->gram_blocks = 0;
     Timer t(c, SDM_T_GRAM);
     // the tail tile of every feature row holds b; clear it first (columns beyond 2L must be 0)
     HIP_TRY(hipMemset2DAsync(c->feat.p + Fp, (size_t)c->ldf * sizeof(float), 0, 128 * c->rhs_tiles * sizeof(float), c->N, c->stream));
@@ -1079,6 +1094,50 @@ int sdm_gram_rhs(sdm_ctx* c, int level)
     else if (form == 2) {
         if ((rc = c->gram_flag.ensure(1))) return rc;
         HIP_TRY(hipMemsetAsync(c->gram_flag.p, 0, sizeof(int), c->stream));
+        // Ranges for the exchange behind the kernel: only when the level's exchange will be the reduce-scatter of owned tile columns
+        // (sdm_allreduce_gram_rhs decides by the same conditions).  Boundaries in owned column numbers, at equal shares of the tiles
+        // (the tiles of the first c columns grow with c^2).
+        const int Ttot = ncols / 128, Wx = c->shard_world;
+        const bool will_scatter = Wx >= 2 && (c->shard_comm || c->shard_bcast) && Wx == c->world_size &&
+                                  (c->reduce_scatter || (c->rccl_reduce_scatter && c->rccl_comm)) && c->solver_kind == SDM_SOLVER_CHOLESKY;
+        int nb = 1;
+        if (will_scatter) nb = c->env_xblocks > 0 ? c->env_xblocks : (c->env_xblocks < 0 && Ttot >= 128 ? 4 : 1);
+        const int ncolw = will_scatter ? (Ttot + Wx - 1) / Wx : 0;
+        if (nb > sdm_ctx::XBLOCKS_MAX) nb = sdm_ctx::XBLOCKS_MAX;
+        if (nb > ncolw) nb = ncolw > 0 ? ncolw : 1;
+        if (nb > 1) {
+            sdm_launch_gram_f16_split(c->feat.p, c->ldf, c->N, ncols, c->gram_planes.p, c->stream, c->gram_flag.p);
+            int over = 0;
+            HIP_TRY(hipMemcpyAsync(&over, c->gram_flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));      // (behind the split only: the products below are queued without a host wait)
+            if (!over) {
+                c->gram_block_c[0] = 0;
+                for (int b = 1; b < nb; ++b) {
+                    int cb = (int)(ncolw * sqrt((double)b / nb) + 0.5);
+                    if (cb <= c->gram_block_c[b - 1]) cb = c->gram_block_c[b - 1] + 1;
+                    c->gram_block_c[b] = cb < ncolw ? cb : ncolw;
+                }
+                c->gram_block_c[nb] = ncolw;
+                int off = 0;
+                for (int b = 0; b < nb; ++b) {
+                    const int j_lo = c->gram_block_c[b] * Wx, j_hi = b + 1 < nb ? c->gram_block_c[b + 1] * Wx : Ttot;
+                    off += sdm_launch_gram_f16_product(c->gram_planes.p, c->N, ncols, c->G.p, ncols, j_lo, j_hi < Ttot ? j_hi : Ttot, off, c->stream);
+                    HIP_TRY(hipEventRecord(c->gram_ev[b], c->stream));
+                }
+                HIP_TRY(hipGetLastError());
+                c->gram_blocks = nb;
+                c->g_ncols = ncols; c->g_fp = Fp; c->g_level = level;
+                return SDM_OK;
+            }
+            // (an operand left float16's range: the bf16 repeat below, in one piece)
+            c->gram_fallbacks += 1;
+            if (c->gram_planes.ensure(sdm_gram_bf16x3_plane_bytes(c->N, ncols, 3))) { (void)hipGetLastError(); form = 0; c->gram_f32_fallbacks += 1; }
+            else sdm_launch_gram_bf16x3(c->feat.p, c->ldf, c->N, ncols, c->gram_planes.p, c->G.p, ncols, c->stream);
+            if (form == 0) sdm_launch_syrk_tn(c->feat.p, c->ldf, c->N, ncols, c->G.p, ncols, 1.0f, 0, 0, c->stream);
+            HIP_TRY(hipGetLastError());
+            c->g_ncols = ncols; c->g_fp = Fp; c->g_level = level;
+            return SDM_OK;
+        }
         sdm_launch_gram_bf16x3(c->feat.p, c->ldf, c->N, ncols, c->gram_planes.p, c->G.p, ncols, c->stream, c->gram_flag.p);
         // (one 4-byte read-back per level: the only host wait of sdm_train_level; the queue is idle for ~0.1 ms of a 40 ... 300 ms level)
         int over = 0;
@@ -1220,21 +1279,52 @@ int sdm_allreduce_gram_rhs(sdm_ctx* c)
     const bool can_rs = c->reduce_scatter || (c->rccl_reduce_scatter && c->rccl_comm);
     if (sharded && can_rs) {
         const int W = c->shard_world, me = c->shard_rank;
-        const size_t chunk = sdm_owned_chunk_tiles(F, c->rhs_tiles, W) * 128 * 128;
-        int rc = c->gpack.ensure((size_t)(W + 1) * chunk);
-        if (rc) return rc;
+        int rc;
         if ((rc = c->gsmall.ensure((size_t)F + 1)) || (rc = c->fro.ensure((size_t)F + 1))) return rc;
+        int rcn = 0;
+        auto scatter = [&](float* send, float* recv, size_t count, hipStream_t st) {
+            if (c->rccl_reduce_scatter)   // ncclReduceScatter(sendbuff, recvbuff, recvcount, ncclFloat32 = 7, ncclSum = 0, comm, stream)
+                return c->rccl_reduce_scatter(send, recv, count, 7, 0, c->rccl_comm, st);
+            return c->reduce_scatter(send, recv, count, (void*)st, c->reduce_scatter_user);
+        };
+        if (c->gram_blocks > 1 && c->solve_aux.stream) {
+            // The Gram matrix was multiplied in ranges of tile columns with an event behind each (sdm_gram_rhs): the second queue ships
+            // range b -- pack, reduce-scatter of the ranks' chunks of that range, unpack of the own chunk -- as soon as ITS products are
+            // done, while the kernel is still busy with the ranges behind it.  The per-element sums are those of the one-piece exchange.
+            const int nb = c->gram_blocks;
+            size_t total = 0, chunk_b[sdm_ctx::XBLOCKS_MAX];
+            for (int b = 0; b < nb; ++b) {
+                chunk_b[b] = sdm_owned_chunk_tiles(F, c->rhs_tiles, W, c->gram_block_c[b], c->gram_block_c[b + 1]) * 128 * 128;
+                total += (size_t)(W + 1) * chunk_b[b];
+            }
+            if ((rc = c->gpack.ensure(total))) return rc;
+            hipStream_t xs = c->solve_aux.stream;
+            float* base = c->gpack.p;
+            for (int b = 0; b < nb && rcn == 0; ++b) {
+                float* send = base;
+                float* recv = base + (size_t)W * chunk_b[b];
+                base += (size_t)(W + 1) * chunk_b[b];
+                HIP_TRY(hipStreamWaitEvent(xs, c->gram_ev[b], 0));
+                if (chunk_b[b] == 0) continue;
+                sdm_launch_tiles_pack_owned(c->G.p, c->g_ncols, F, c->rhs_tiles, W, me, send, 0, xs, c->gram_block_c[b], c->gram_block_c[b + 1]);
+                rcn = scatter(send, recv, chunk_b[b], xs);
+                if (rcn == 0) sdm_launch_tiles_pack_owned(c->G.p, c->g_ncols, F, c->rhs_tiles, W, me, recv, 1, xs, c->gram_block_c[b], c->gram_block_c[b + 1]);
+            }
+            HIP_TRY(hipEventRecord(c->gram_xdone, xs));
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->gram_xdone, 0));      // (also on the error path: the caller's stream owns G again)
+            if (rcn != 0) return fail(SDM_ERR_COMM, "reduce-scatter failed with status " + std::to_string(rcn));
+            HIP_TRY(hipGetLastError());
+        } else {
+        const size_t chunk = sdm_owned_chunk_tiles(F, c->rhs_tiles, W) * 128 * 128;
+        if ((rc = c->gpack.ensure((size_t)(W + 1) * chunk))) return rc;
         float* send = c->gpack.p;
         float* recv = c->gpack.p + (size_t)W * chunk;
         sdm_launch_tiles_pack_owned(c->G.p, c->g_ncols, F, c->rhs_tiles, W, me, send, 0, c->stream);
         HIP_TRY(hipGetLastError());
-        int rcn;
-        if (c->rccl_reduce_scatter)   // ncclReduceScatter(sendbuff, recvbuff, recvcount, ncclFloat32 = 7, ncclSum = 0, comm, stream)
-            rcn = c->rccl_reduce_scatter(send, recv, chunk, 7, 0, c->rccl_comm, c->stream);
-        else
-            rcn = c->reduce_scatter(send, recv, chunk, (void*)c->stream, c->reduce_scatter_user);
+        rcn = scatter(send, recv, chunk, c->stream);
         if (rcn != 0) return fail(SDM_ERR_COMM, "reduce-scatter failed with status " + std::to_string(rcn));
         sdm_launch_tiles_pack_owned(c->G.p, c->g_ncols, F, c->rhs_tiles, W, me, recv, 1, c->stream);
+        }
         // the small exchange: [diagonal of the owned columns, 0 elsewhere | this rank's share of ||G||_F^2]
         sdm_launch_diag_owned(c->G.p, c->g_ncols, F, W, me, c->gsmall.p, 0, c->stream);
         sdm_launch_fro2_upper(c->G.p, c->g_ncols, F, c->fro.p, c->stream, me, W);

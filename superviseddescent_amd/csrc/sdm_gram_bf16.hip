@@ -523,12 +523,15 @@ syrk_update_f16_kernel(const bf16x8* __restrict__ planes, int NG, int ncols2, in
 // (super-row I, tile column j >= 2 I) pairs of the 256 x 128 kernels in the order the workgroups take them: listed block by block
 // (4 super-rows x 8 columns: one workgroup per CU, 32 per XCD), the list cut into eight consecutive chunks, chunk x served by the
 // workgroups w with w % 8 == x -- the ones the dispatcher places on XCD x, so that an XCD's L2 serves neighbouring panels.
-static const std::vector<int>& gram_tile_order_w(int T)
+// (j_lo, j_hi: only the tiles of tile columns j_lo <= j < j_hi -- the block-wise Gram launch of the overlapped exchange; the
+//  relative order of a block's tiles is the full list's)
+static const std::vector<int>& gram_tile_order_w(int T, int j_lo = 0, int j_hi = -1)
 {
     static std::mutex mu;
-    static std::map<int, std::vector<int>> cache;
+    static std::map<long long, std::vector<int>> cache;
     std::lock_guard<std::mutex> lock(mu);
-    std::vector<int>& o = cache[T];
+    if (j_hi < 0 || j_hi > T) j_hi = T;
+    std::vector<int>& o = cache[((long long)T << 40) | ((long long)j_lo << 20) | (long long)j_hi];
     if (!o.empty()) return o;
     const int TI = (T + 1) / 2;
     const int BH = 4, BW = 8;      // block shape (super-rows x tile columns): moves the fabric traffic by 1.5x and the time not at all (profiles/r03_gram_pmc.txt)
@@ -537,9 +540,9 @@ static const std::vector<int>& gram_tile_order_w(int T)
         for (int bj = 0; bj * BW < T; ++bj)
             for (int I = bi * BH; I < (bi + 1) * BH && I < TI; ++I)
                 for (int j = bj * BW; j < (bj + 1) * BW && j < T; ++j)
-                    if (j >= 2 * I) seq.push_back(I | (j << 16));
+                    if (j >= 2 * I && j >= j_lo && j < j_hi) seq.push_back(I | (j << 16));
     const int nt = (int)seq.size(), chunk = (nt + 7) / 8;
-    o.assign((size_t)8 * chunk, -1);
+    o.assign((size_t)8 * (chunk > 0 ? chunk : 1), -1);      // (an empty range keeps eight -1 entries: the cache tells 'built' by non-emptiness)
     for (int w = 0; w < 8 * chunk; ++w) {
         const int idx = (w % 8) * chunk + w / 8;
         if (idx < nt) o[w] = seq[idx];
@@ -547,7 +550,7 @@ static const std::vector<int>& gram_tile_order_w(int T)
     return o;
 }
 
-static size_t gram_order_bytes(int ncols) { const int T = ncols / GB_TILE; return ((size_t)(T * (T + 1) / 2 + 8) * sizeof(int) + 255) & ~(size_t)255; }
+static size_t gram_order_bytes(int ncols) { const int T = ncols / GB_TILE; return ((size_t)(T * (T + 1) / 2 + 8 + 8 * 16) * sizeof(int) + 255) & ~(size_t)255; }      // (+ the padding of up to 16 ranges)
 
 size_t sdm_gram_bf16x3_plane_bytes(int N, int ncols, int pieces)
 {
@@ -580,6 +583,32 @@ void sdm_launch_gram_bf16x3(const float* A, long long lda, int N, int ncols, voi
     else
         hipLaunchKernelGGL((syrk_tn_bf16x3_w_kernel<3, 3, false>), dim3((unsigned)ow.size()), dim3(1024), (size_t)3 * (3 * 2 * 384) * 16, stream,
                            (const bf16x8*)planes, NG, ncols2, ncols, C, ldc, d_ow, (int)ow.size());
+}
+
+// The float16 form in two steps (round 4, the exchange overlapped with the Gram kernel): the planes once, then the products of a
+// range of tile columns per call -- behind each range the caller records an event and a second queue ships that range's tiles
+// while the next range is being multiplied.  order_off: entries of the order-table region already used by earlier ranges of this
+// Gram matrix; returns the entries this range used.
+void sdm_launch_gram_f16_split(const float* A, long long lda, int N, int ncols, void* planes, hipStream_t stream, int* f16_flag)
+{
+    if (N <= 0 || ncols <= 0) return;
+    const int NG = ((N + 31) / 32) * 4, ncols2 = ((ncols + 255) / 256) * 256;
+    hipLaunchKernelGGL(split_planes_f16_kernel, dim3((ncols2 + 255) / 256, NG), dim3(256), 0, stream, A, lda, N, ncols, ncols2, NG, (f16x8*)planes, f16_flag);
+}
+
+int sdm_launch_gram_f16_product(const void* planes, int N, int ncols, float* C, long long ldc, int j_lo, int j_hi, int order_off, hipStream_t stream)
+{
+    if (N <= 0 || ncols <= 0) return 0;
+    const int NG = ((N + 31) / 32) * 4, ncols2 = ((ncols + 255) / 256) * 256;
+    static unsigned long long attr = 0;
+    if (sdm_first_use_on_device(attr))
+        SDM_SET_ATTR((const void*)syrk_tn_split_w8p_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const std::vector<int>& ow = gram_tile_order_w(ncols / GB_TILE, j_lo, j_hi);
+    int* d_ow = (int*)((unsigned char*)planes + 2 * (size_t)NG * (size_t)ncols2 * 16) + order_off;
+    (void)hipMemcpyAsync(d_ow, ow.data(), ow.size() * sizeof(int), hipMemcpyHostToDevice, stream);
+    hipLaunchKernelGGL(syrk_tn_split_w8p_kernel<4>, dim3((unsigned)ow.size()), dim3(512), (size_t)4 * (2 * 2 * 384) * 16, stream,
+                       (const bf16x8*)planes, NG, ncols2, ncols, C, ldc, d_ow, (int)ow.size());
+    return (int)ow.size();
 }
 
 // ---- trailing update of the blocked Cholesky on the float16 matrix cores (see syrk_update_f16_kernel) ----

@@ -208,6 +208,11 @@ size_t sdm_gram_bf16x3_plane_bytes(int N, int ncols, int pieces = 3);      // pi
 void sdm_launch_gram_bf16x3(const float* A, long long lda, int N, int ncols, void* planes, float* C, long long ldc, hipStream_t stream,
                             int* f16_flag = nullptr);
 
+// the float16 form in two steps: the planes once (flag as above), then the products of the tile columns j_lo <= j < j_hi per call
+// (order_off: order-table entries used by earlier ranges of this matrix; returns the entries used)
+void sdm_launch_gram_f16_split(const float* A, long long lda, int N, int ncols, void* planes, hipStream_t stream, int* f16_flag);
+int sdm_launch_gram_f16_product(const void* planes, int N, int ncols, float* C, long long ldc, int j_lo, int j_hi, int order_off, hipStream_t stream);
+
 // Frobenius norm^2 (double) of the symmetric matrix whose upper triangle (incl. diagonal) of the
 // leading F x F block is stored in G; result accumulated into *out (must be zeroed).
 // upper Gram tiles + RHS tile columns <-> one contiguous exchange buffer of sdm_packed_tiles_count() floats
@@ -215,8 +220,9 @@ size_t sdm_packed_tiles_count(int F, int rhs_tiles);
 void sdm_launch_tiles_pack(float* G, long long ldg, int F, int rhs_tiles, float* P, int unpack, hipStream_t stream);
 void sdm_launch_fro2_upper(const float* G, long long ldg, int F, double* part_and_out, hipStream_t stream, int own_rank = 0, int own_world = 1);
 // reduce-scatter exchange of the Gram matrix (tiles grouped by owner, sdm_solve.hip)
-size_t sdm_owned_chunk_tiles(int F, int rhs_tiles, int W);
-void sdm_launch_tiles_pack_owned(float* G, long long ldg, int F, int rhs_tiles, int W, int me, float* P, int unpack, hipStream_t stream);
+size_t sdm_owned_chunk_tiles(int F, int rhs_tiles, int W, int c_lo = 0, int c_hi = -1);      // (a range of owned column numbers: the block-wise exchange)
+void sdm_launch_tiles_pack_owned(float* G, long long ldg, int F, int rhs_tiles, int W, int me, float* P, int unpack, hipStream_t stream,
+                                 int c_lo = 0, int c_hi = -1);
 void sdm_launch_diag_owned(float* G, long long ldg, int F, int W, int me, float* d, int scatter, hipStream_t stream);
 void sdm_launch_small_exchange_pack(const double* fro2, float* d_tail, int unpack, double* fro2_out, hipStream_t stream);
 void sdm_launch_add_diag(float* G, long long ldg, int F, const double* fro2, int reg_type, float param,

@@ -845,14 +845,18 @@ __host__ __device__ inline long long owned_tiles_before(int c, int r, int W, int
     return (long long)cf * (r + 1) + (long long)W * cf * (cf - 1) / 2 + (long long)(c - cf) * T;
 }
 
+// (round 4: also for a RANGE [c_lo, c_hi) of owned column numbers -- the block-wise exchange that runs behind the Gram kernel:
+//  a block's chunk of rank r holds the tiles of its owned columns number c_lo .. c_hi - 1 only)
+__host__ __device__ inline int owned_columns(int r, int W, int T, int TR) { return r < T + TR ? (T + TR - r + W - 1) / W : 0; }
 __global__ __launch_bounds__(256) void tiles_pack_owned_kernel(float* G, long long ldg, int T, int TR, int W, float* P, long long chunk_tiles,
-                                                               int unpack, int only_rank)
+                                                               int unpack, int only_rank, int c_lo)
 {
-    // grid (owned column number, tile row, rank): pack fills all W chunks, unpack reads the one chunk a rank received
-    const int c = blockIdx.x, ti = blockIdx.y, r = unpack ? only_rank : (int)blockIdx.z;
+    // grid (owned column number - c_lo, tile row, rank): pack fills all W chunks, unpack reads the one chunk a rank received
+    const int c = c_lo + (int)blockIdx.x, ti = blockIdx.y, r = unpack ? only_rank : (int)blockIdx.z;
     const int tj = r + W * c;
     if (tj >= T + TR || (tj < T && ti > tj)) return;
-    const long long tile = (unpack ? 0 : (long long)r * chunk_tiles) + owned_tiles_before(c, r, W, T) + ti;
+    const int nown = owned_columns(r, W, T, TR);
+    const long long tile = (unpack ? 0 : (long long)r * chunk_tiles) + owned_tiles_before(c, r, W, T) - owned_tiles_before(c_lo < nown ? c_lo : nown, r, W, T) + ti;
     float4* p = (float4*)(P + tile * TILE * TILE);
     for (int e = threadIdx.x; e < TILE * TILE / 4; e += 256) {
         const int rr = e / (TILE / 4), c4 = e % (TILE / 4);
@@ -900,26 +904,30 @@ void sdm_launch_tiles_pack(float* G, long long ldg, int F, int rhs_tiles, float*
 }
 
 
-size_t sdm_owned_chunk_tiles(int F, int rhs_tiles, int W)
+size_t sdm_owned_chunk_tiles(int F, int rhs_tiles, int W, int c_lo, int c_hi)
 {
-    // tiles of the largest per-rank chunk
+    // tiles of the largest per-rank chunk (owned column numbers c_lo .. c_hi - 1; c_hi < 0: all)
     const int T = (F + TILE - 1) / TILE;
     long long most = 0;
     for (int r = 0; r < W; ++r) {
-        const int ncol = r < T + rhs_tiles ? (T + rhs_tiles - r + W - 1) / W : 0;
-        const long long n = owned_tiles_before(ncol, r, W, T);
+        const int ncol = owned_columns(r, W, T, rhs_tiles);
+        const int hi = (c_hi < 0 || c_hi > ncol) ? ncol : c_hi, lo = c_lo < hi ? c_lo : hi;
+        const long long n = owned_tiles_before(hi, r, W, T) - owned_tiles_before(lo, r, W, T);
         if (n > most) most = n;
     }
     return (size_t)most;
 }
 
-void sdm_launch_tiles_pack_owned(float* G, long long ldg, int F, int rhs_tiles, int W, int me, float* P, int unpack, hipStream_t stream)
+void sdm_launch_tiles_pack_owned(float* G, long long ldg, int F, int rhs_tiles, int W, int me, float* P, int unpack, hipStream_t stream,
+                                 int c_lo, int c_hi)
 {
     const int T = (F + TILE - 1) / TILE;
-    const long long chunk = (long long)sdm_owned_chunk_tiles(F, rhs_tiles, W);
     const int ncol = (T + rhs_tiles + W - 1) / W;
+    if (c_hi < 0 || c_hi > ncol) c_hi = ncol;
+    if (c_lo >= c_hi) return;
+    const long long chunk = (long long)sdm_owned_chunk_tiles(F, rhs_tiles, W, c_lo, c_hi);
     if (!unpack) (void)hipMemsetAsync(P, 0, (size_t)W * chunk * TILE * TILE * sizeof(float), stream);      // (the padding of the shorter chunks is summed too)
-    hipLaunchKernelGGL(tiles_pack_owned_kernel, dim3(ncol, T, unpack ? 1 : W), dim3(256), 0, stream, G, ldg, T, rhs_tiles, W, P, chunk, unpack, me);
+    hipLaunchKernelGGL(tiles_pack_owned_kernel, dim3(c_hi - c_lo, T, unpack ? 1 : W), dim3(256), 0, stream, G, ldg, T, rhs_tiles, W, P, chunk, unpack, me, c_lo);
 }
 
 void sdm_launch_diag_owned(float* G, long long ldg, int F, int W, int me, float* d, int scatter, hipStream_t stream)

@@ -72,14 +72,16 @@ def test_bench_several_gpu_order_and_watchdog(built):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3, 4])
-def test_training_collectives_with_real_processes(built, world):
+@pytest.mark.parametrize("world,xblocks", [(2, None), (3, None), (4, None), (2, 3), (3, 4)])
+def test_training_collectives_with_real_processes(built, world, xblocks):
     """World sizes > 1 through the product's exchange callbacks with REAL processes: torch.distributed's gloo backend moves device
     tensors through the host, so the ranks may share the one GPU of the test box (RCCL refuses two ranks per device).  The worker
     trains with the all-reduce, with the sharded factorisation (broadcast + all-gather per step / group) and with the
     reduce-scatter exchange, and checks: identical regressors on every rank in all three forms, sharded == replicated bit for bit,
     the expected number of collectives, and the regressors (5e-5; measured 2e-5) and landmarks (1e-6; measured 2e-8) of single-process training on all rows."""
-    r = _torchrun(world, os.path.join(ROOT, "tests", "_rccl_worker.py"), SDM_TEST_BACKEND="gloo")
+    # xblocks: the reduce-scatter exchange block-wise behind the Gram kernel (SDM_GRAM_XBLOCKS; automatic only from 128 tile columns on)
+    extra = {"SDM_GRAM_XBLOCKS": str(xblocks)} if xblocks else {}
+    r = _torchrun(world, os.path.join(ROOT, "tests", "_rccl_worker.py"), SDM_TEST_BACKEND="gloo", **extra)
     assert r.returncode == 0 and "RCCL_WORKER_OK world=%d" % world in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 

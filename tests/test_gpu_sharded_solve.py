@@ -382,3 +382,60 @@ def test_reduce_scatter_exchange_feeds_the_sharded_factorisation(built, world, g
     # a ring all-reduce moves 2 (W-1)/W x its buffer per rank, a ring reduce-scatter (W-1)/W x its buffer: the padded owner-ordered
     # buffer is within a few tiles of the all-reduce's
     assert sent_rs < 1.1 * sent_ar
+
+
+@pytest.mark.parametrize("world,geometry,blocks", [(2, "rcr22", 3), (3, "rcr22", 4), (2, "rcr68", 4)])
+def test_exchange_behind_the_gram_kernel_is_the_one_piece_exchange(built, monkeypatch, world, geometry, blocks):
+    """Round 4: with the reduce-scatter exchange the Gram matrix is multiplied in ranges of tile columns, an
+    event behind each, and a second queue packs / reduce-scatters / unpacks a range while the kernel multiplies the next one
+    (automatic from 128 tile columns on = RCR-68; forced here by SDM_GRAM_XBLOCKS at geometries the one-GPU box can train).  The
+    per-element sums are those of the one-piece exchange: regressors, lambda and landmarks must have the SAME BITS, every rank,
+    with `blocks` reduce-scatters per level instead of one and the same number of floats on the wire up to the ranges' padding."""
+    from superviseddescent_amd import HogTransform, LinearRegressor, Regulariser, SupervisedDescentOptimiser, parallel
+    if geometry == "rcr22":
+        ids, params, n_img, per = ibug.RCR22_IDS, [HoGParam(*ibug.SHIPPED_HOG_PARAMS[0]), HoGParam(*ibug.SHIPPED_HOG_PARAMS[1])], 60, 5
+    else:
+        ids, params, n_img, per = ibug.IBUG68_IDS, [HoGParam(1, 3, 12, 4, 0.9)], 60, 3
+    images, boxes, gt = synth.make_faces(n_img, seed=7401)
+    x_star, x0, idx = synth.make_samples(boxes, gt, ids, n_perturb=per, seed=7402)
+    N = x0.shape[0]
+    reg = lambda: Regulariser(Regulariser.RegularisationType.MatrixNorm, 1.5, False)
+
+    def run(nblocks):
+        monkeypatch.setenv("SDM_GRAM_XBLOCKS", str(nblocks))      # (read once, when the contexts below are created)
+        group = LocalGroup(world)
+        out, errors = [None] * world, [None] * world
+
+        def work(rank):
+            try:
+                a, b = parallel.shard_range(N, rank, world)
+                imgs = sorted(set(int(i) for i in idx[a:b]))
+                remap = {g: k for k, g in enumerate(imgs)}
+                local_idx = np.array([remap[int(i)] for i in idx[a:b]], np.int32)
+                sdo = SupervisedDescentOptimiser([LinearRegressor(reg()) for _ in params])
+                hog = HogTransform(images[imgs], params, ids, ibug.RIGHT_EYE_IDS, ibug.LEFT_EYE_IDS, local_idx)
+                x = sdo.train(x_star[a:b], x0[a:b], None, hog, allreduce=_counting_allreduce(group, rank), world_size=world,
+                              n_train_global=N, rank=rank, solve_collectives=(group.bcast(rank), group.allgather(rank)),
+                              reduce_scatter=_reduce_scatter_of(group, rank))
+                out[rank] = (x, [r.x.copy() for r in sdo.regressors], [r.last_lambda for r in sdo.regressors])
+                sdo.ctx.close()
+            except Exception as e:  # noqa: BLE001
+                errors[rank] = e
+                group.barrier.abort()
+        threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert errors == [None] * world, errors
+        return out, group.calls
+
+    ref, ref_calls = run(1)
+    got, calls = run(blocks)
+    for rank in range(world):
+        assert calls[rank]["reduce_scatter"] == blocks * len(params) and ref_calls[rank]["reduce_scatter"] == len(params)
+        for l in range(len(params)):
+            assert np.array_equal(got[rank][1][l].view(np.uint32), ref[rank][1][l].view(np.uint32)), (rank, l)
+            assert got[rank][2][l] == ref[rank][2][l]
+        assert np.array_equal(got[rank][0], ref[rank][0])
+    assert calls[0]["reduce_scatter_floats"] <= 1.15 * ref_calls[0]["reduce_scatter_floats"]
