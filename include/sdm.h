@@ -216,7 +216,10 @@ int sdm_set_solve_sharding_rccl(sdm_ctx* ctx, void* nccl_comm, int rank, int wor
  * (the summed diagonal and the ranks' shares of ||G||_F^2) through the callback / communicator registered with sdm_set_allreduce*.
  *   reduce_scatter: every rank contributes world_size * count_f32 floats at send_ptr (chunk r destined for rank r); recv_ptr
  *                   receives the element-wise sum over the ranks of this rank's chunk (count_f32 floats); stream-ordered
- * Without it, or with a replicated solve, the exchange stays the all-reduce.  NULL / enable = 0 removes it. */
+ * Without it, or with a replicated solve, the exchange stays the all-reduce.  NULL / enable = 0 removes it.
+ * From 128 tile columns on (RCR-68) the callback is invoked once per RANGE of tile columns (four ranges), on the handle's second queue,
+ * while sdm_gram_rhs' kernel is still multiplying the ranges behind it (round 4: the exchange runs behind the Gram kernel); the sums are
+ * those of the one-piece exchange, bit for bit.  SDM_GRAM_XBLOCKS=1 in the environment keeps the single call. */
 typedef int (*sdm_reduce_scatter_fn)(const void* send_ptr, void* recv_ptr, size_t count_f32, void* hip_stream, void* user);
 int sdm_set_reduce_scatter(sdm_ctx* ctx, sdm_reduce_scatter_fn fn, void* user);
 /* The same through RCCL on the communicator given to sdm_set_allreduce_rccl; the address may be NULL (looked up as ncclReduceScatter). */
