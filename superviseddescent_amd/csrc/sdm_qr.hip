@@ -129,28 +129,32 @@ __global__ void __launch_bounds__(1024) qr_pivot_kernel(float* __restrict__ G, l
     }
 }
 
-// step k, part 2: H_k = I - tau v v^T applied to the remaining columns of the matrix and to the right-hand sides
+// step k, part 2: H_k = I - tau v v^T applied to the remaining columns of the matrix and to the right-hand sides.  A workgroup takes CW
+// columns with 1024 / CW row lanes each (CW = 64: a wave reads 256 contiguous bytes per row; CW = 32, chosen when 64-column strips would
+// leave compute units without a workgroup: twice the workgroups, 128-byte rows)
+template <int CW>
 __global__ void __launch_bounds__(1024) qr_apply_kernel(float* __restrict__ G, long long ldg, int F, int k, int rhs0, int nrhs,
                                                         float* __restrict__ cn, const float* __restrict__ v, const float* __restrict__ scal)
 {
-    __shared__ float red[16][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + tx, nmat = F - k - 1;
+    constexpr int RL = 1024 / CW;
+    __shared__ float red[RL][CW];
+    const int tx = threadIdx.x % CW, ty = threadIdx.x / CW;
+    const int c = blockIdx.x * CW + tx, nmat = F - k - 1;
     const bool valid = c < nmat + nrhs;
     const int j = c < nmat ? k + 1 + c : rhs0 + (c - nmat);
     const float tk = scal[1];
     float* col = G + j;
     float d = 0.0f;
     if (valid && tk != 0.0f)
-        for (int i = k + ty; i < F; i += 16) d += v[i] * col[(long long)i * ldg];
+        for (int i = k + ty; i < F; i += RL) d += v[i] * col[(long long)i * ldg];
     red[ty][tx] = d;
     __syncthreads();
     d = 0.0f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) d += red[r][tx];
+    for (int r = 0; r < RL; ++r) d += red[r][tx];
     d *= tk;
     if (valid && tk != 0.0f)
-        for (int i = k + ty; i < F; i += 16) col[(long long)i * ldg] -= d * v[i];
+        for (int i = k + ty; i < F; i += RL) col[(long long)i * ldg] -= d * v[i];
     if (valid && ty == 0 && c < nmat) {          // (row k of this column was written by this very thread: i = k + 0)
         const float a = col[(long long)k * ldg];
         cn[j] -= a * a;
@@ -234,8 +238,10 @@ void sdm_launch_colpiv_qr_solve(float* G, long long ldg, int F, int rhs0, int nr
     for (int k = 0; k < F; ++k) {
         hipLaunchKernelGGL(qr_pivot_kernel, dim3(1), dim3(1024), 0, stream, G, ldg, F, k, cn, perm, v, tau, scal);
         const int ncol = F - k - 1 + nrhs;
-        if (ncol > 0)
-            hipLaunchKernelGGL(qr_apply_kernel, dim3((unsigned)((ncol + 63) / 64)), dim3(1024), 0, stream, G, ldg, F, k, rhs0, nrhs, cn, v, scal);
+        if (ncol > 64 * 256)      // (enough 64-column strips for every compute unit)
+            hipLaunchKernelGGL(qr_apply_kernel<64>, dim3((unsigned)((ncol + 63) / 64)), dim3(1024), 0, stream, G, ldg, F, k, rhs0, nrhs, cn, v, scal);
+        else if (ncol > 0)
+            hipLaunchKernelGGL(qr_apply_kernel<32>, dim3((unsigned)((ncol + 31) / 32)), dim3(1024), 0, stream, G, ldg, F, k, rhs0, nrhs, cn, v, scal);
     }
     hipLaunchKernelGGL(qr_rank_kernel, dim3(1), dim3(1024), 0, stream, G, ldg, F, scal, rank_dev);
     (void)hipMemsetAsync(R_out, 0, (size_t)r_rows * ldr * sizeof(float), stream);
