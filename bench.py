@@ -33,7 +33,6 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3   # f32-input MFMA dense peak
-PREROLL_STEPS = 40         # untimed steps before the warm-up steps (GPU clocks back up after the host-side set-up)
 RCR68_DEADLINE_S = float(os.environ.get("SDM_BENCH_RCR68_DEADLINE_S", "420"))      # several GPUs: watchdog of the RCR-68 legs (they take ~10 s on one GPU)
 MFMA_F16_PEAK_TF = 2500.0  # f16 / bf16-input MFMA dense peak (the Gram launch: four float16 piece products per f32 product)
 
@@ -108,8 +107,28 @@ def parse():
     return ap.parse_args()
 
 
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` started WITHOUT a launcher (no RANK / WORLD_SIZE in the environment) replaces itself by
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>`: one rank per GPU, as the driver
+    launches the N > 1 lines.  Without this the process would run ONE rank and print n_gpus = 1."""
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), SDM_BENCH_RELAUNCHED="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execvpe(sys.executable, cmd, env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        if os.environ.get("SDM_BENCH_RELAUNCHED") == "1":
+            raise SystemExit("bench.py: relaunched under torch.distributed.run but no WORLD_SIZE arrived")
+        relaunch_under_torchrun(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -176,14 +195,25 @@ def main():
     reg = lambda: Regulariser(Regulariser.RegularisationType.MatrixNorm, 1.5, False)   # rcr-train.cpp:440-443
     sdo = SupervisedDescentOptimiser([LinearRegressor(reg()) for _ in params], device=local_rank, stream=stream)
     hog = HogTransform(timg, params, ids, ibug.RIGHT_EYE_IDS, ibug.LEFT_EYE_IDS, tidx, images_resident=True)   # (uploaded by the first pass)
-    allreduce = parallel.make_torch_allreduce(local_rank) if use_dist else None
+    # The exchange.  Backend nccl (= RCCL): the LIBRARY issues the collectives itself -- ncclAllReduce / ncclReduceScatter /
+    # ncclBroadcast / ncclAllGather on its own HIP streams, through a communicator of this process's own (parallel.RcclCommunicator:
+    # ncclCommInitRank from a unique id carried by torch.distributed; sdm_set_allreduce_rccl, sdm_set_reduce_scatter_rccl,
+    # sdm_set_solve_sharding_rccl).  No Python runs between two kernels of a training level: the 1 reduce-scatter (x 4 ranges) +
+    # 213 broadcasts + 55 all-gathers of an RCR-68 level are queued by the same host loop that queues the kernels (VERDICT r04 item
+    # 6).  The torch.distributed callbacks (ctypes -> Python -> torch) remain for backends without RCCL -- the gloo runs of the
+    # tests -- and as SDM_BENCH_COLLECTIVES=torch for an A/B.
+    native = use_dist and backend == "nccl" and os.environ.get("SDM_BENCH_COLLECTIVES", "rccl") != "torch"
+    rccl = parallel.RcclCommunicator(rank, world) if native else None
+    allreduce = parallel.make_torch_allreduce(local_rank) if (use_dist and not native) else None
     # SDM_BENCH_SHARD_SOLVE=1: the summed system is factored by all ranks together (tile-column ownership).  Off by
     # default: at the bench's F = 8 801 the factorisation is bound by its chain of 69 single-workgroup panel steps, which
     # sharding does not shorten (profiles/r02_sharded_solve_timing.json); it pays at F = 27 201 (RCR-68)
     shard_solve = use_dist and os.environ.get("SDM_BENCH_SHARD_SOLVE", "0") == "1"
-    solve_collectives = parallel.make_torch_solve_collectives(local_rank) if shard_solve else None
+    solve_collectives = parallel.make_torch_solve_collectives(local_rank) if (shard_solve and not native) else None
     # with a sharded solve the exchange is a reduce-scatter of the owned tile columns + a small all-reduce (half the ring traffic)
-    reduce_scatter = parallel.make_torch_reduce_scatter(local_rank) if use_dist else None
+    reduce_scatter = parallel.make_torch_reduce_scatter(local_rank) if (use_dist and not native) else None
+    via = ("RCCL called by the library on its own streams (sdm_set_*_rccl, own ncclCommInitRank)" if native else
+           "torch.distributed %s through the sdm_set_* callbacks" % backend)
     def train_rcr22(collective, sdo=sdo, hog=hog):
         """Two passes of sdo.train (the second one timed).  collective=False: every rank on its own rows, no exchange -- the
         model the detect legs run with several GPUs (see defer below)."""
@@ -195,7 +225,11 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            if collective:
+            if collective and native:
+                sdo.train(txs, tx0, None, hog, world_size=world, n_train_global=n_train_global, rccl=rccl, rccl_shard_solve=shard_solve,
+                          on_training_epoch_callback=(lambda cur: nlsr_.append(float(np.linalg.norm(cur - txs) / np.linalg.norm(txs))))
+                          if rep == 0 else None)
+            elif collective:
                 sdo.train(txs, tx0, None, hog, allreduce=allreduce, world_size=world, n_train_global=n_train_global,
                           rank=rank if shard_solve else None, solve_collectives=solve_collectives,
                           reduce_scatter=reduce_scatter if shard_solve else None,
@@ -216,6 +250,7 @@ def main():
             wall_[-1] = float(tt.item())
         sdo.ctx.set_allreduce(None, 1)
         sdo.ctx.set_solve_sharding(0, 0, None, None)
+        sdo.ctx.set_reduce_scatter(None)
         return list(nlsr_), wall_, timing_
 
     # Several GPUs: everything that needs a collective -- the RCR-22 training exchange, the RCR-68 legs -- runs BEHIND the headline
@@ -237,7 +272,7 @@ def main():
         sdo68 = SupervisedDescentOptimiser([LinearRegressor(reg()) for _ in params], device=local_rank, stream=stream)
         hog68 = HogTransform(timg, params, ids68, ibug.RIGHT_EYE_IDS, ibug.LEFT_EYE_IDS, tidx68, images_resident=True)
         shard68 = use_dist and world > 1 and os.environ.get("SDM_BENCH_SHARD_SOLVE", "1") == "1"
-        coll68 = parallel.make_torch_solve_collectives(local_rank) if shard68 else None
+        coll68 = parallel.make_torch_solve_collectives(local_rank) if (shard68 and not native) else None
         nlsr68, wall68 = [], []
         for rep in range(2):
             sdo68.ctx.enable_timing(True)
@@ -246,10 +281,14 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            sdo68.train(txs68, tx068, None, hog68, allreduce=allreduce, world_size=world, n_train_global=n_train_global,
-                        rank=rank if shard68 else None, solve_collectives=coll68, reduce_scatter=reduce_scatter if shard68 else None,
-                        on_training_epoch_callback=(lambda cur: nlsr68.append(float(np.linalg.norm(cur - txs68) / np.linalg.norm(txs68))))
-                        if rep == 0 else None)
+            cb68 = (lambda cur: nlsr68.append(float(np.linalg.norm(cur - txs68) / np.linalg.norm(txs68)))) if rep == 0 else None
+            if native:
+                sdo68.train(txs68, tx068, None, hog68, world_size=world, n_train_global=n_train_global, rccl=rccl, rccl_shard_solve=shard68,
+                            on_training_epoch_callback=cb68)
+            else:
+                sdo68.train(txs68, tx068, None, hog68, allreduce=allreduce, world_size=world, n_train_global=n_train_global,
+                            rank=rank if shard68 else None, solve_collectives=coll68, reduce_scatter=reduce_scatter if shard68 else None,
+                            on_training_epoch_callback=cb68)
             if use_dist:
                 dist.barrier()
             torch.cuda.synchronize()
@@ -262,6 +301,7 @@ def main():
         ctx68 = sdo68.ctx
         ctx68.set_allreduce(None, 1)
         ctx68.set_solve_sharding(0, 0, None, None)
+        ctx68.set_reduce_scatter(None)
         F68 = ctx68.feature_dim(0)
         T68, r68 = (F68 + 127) // 128, (((M68 + 15) // 16) * 16 + 127) // 128
         n_rows68 = int(txs68.shape[0])
@@ -273,9 +313,8 @@ def main():
                             "MatrixNorm 1.5, synthetic 256x256 faces" % (F68, M68, n_train_global, world),
                 "rows_total": int(n_train_global), "rows_per_gpu": n_rows68,
                 "sec_per_cascade": wall68[-1] / n_levels, "scaling": "strong",
-                "collective": ("one reduce-scatter of the owned tile columns of {A^T A, A^T b} + an all-reduce of F + 1 floats per level "
-                               "(torch.distributed nccl = RCCL)" if shard68 else
-                               "one all-reduce of {A^T A, A^T b} per level (torch.distributed nccl = RCCL)" if use_dist else "none (1 GPU)"),
+                "collective": ("one reduce-scatter of the owned tile columns of {A^T A, A^T b} + an all-reduce of F + 1 floats per level; " + via
+                               if shard68 else "one all-reduce of {A^T A, A^T b} per level; " + via if use_dist else "none (1 GPU)"),
                 "solve": ("sharded over the ranks by tile column" if shard68 else "replicated on every rank" if use_dist else "single GPU"),
                 "stage_ms_per_level_rank0": {k: v[0] / n_levels for k, v in timing68.items()},
                 "gram": gram_report(gram_exec, n_rows68 * float(F68) * (F68 + 1) + 2.0 * n_rows68 * F68 * M68, gram_ms),
@@ -340,21 +379,8 @@ def main():
         return (pl["n_main"] * cuts(range(pl["P"])) + cuts(range(pl["P"], pl["P"] + pl["Pt"]))) / float(nl)
     cut_frac = float(np.mean([cut_fraction(p.cell_size) for p in params]))
 
-    # ---- the driver's view without the pre-roll: W warm-up steps straight after the host-side set-up, then K timed steps ------
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    dt_no_preroll = time.perf_counter() - t0
-
-    # clock pre-roll: the host-side preparation above leaves the GPU idle for a few hundred milliseconds and its clocks drop; the W
-    # warm-up steps of a short run (7 ms at W = 5) do not bring them back (measured: 1.443 ms per step at W = 5 / K = 20 against
-    # 1.419-1.422 at W = 40 or K = 200).  PREROLL untimed steps of the same work run before the W warm-up steps; reported in `config`.
-    for _ in range(PREROLL_STEPS):
-        step()
+    # ---- W untimed warm-up steps, then exactly K timed steps between barrier + synchronize on both sides.  (Rounds 2-4 ran 40
+    # untimed "pre-roll" steps first; round 4's own A/B showed no effect -- 3.61 M against 3.55 M faces/s without it -- so it is gone.)
     for _ in range(args.warmup):
         step()
     ctx.enable_timing(True)
@@ -537,6 +563,8 @@ def main():
         watchdog.cancel()
 
     if rank != 0:
+        if rccl is not None:
+            rccl.destroy()
         if use_dist:
             dist.destroy_process_group()
         return
@@ -551,14 +579,17 @@ def main():
 
     # HBM bytes and instruction counts per launch from the PMC passes (rocprofv3 --pmc cannot run inside this process): the
     # committed measurement of this same command (scripts/profile_bench.sh), valid for the batch it was taken at
-    traffic, traffic_src, valu_issue = None, None, None
+    traffic, traffic_src, valu_issue, traffic_by_kernel = None, None, None, None
     hog_kernel = "hog_packed_kernel"
     try:
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")) as fh:
             tj = json.load(fh)
         ent = tj["kernels"][hog_kernel]
         if int(tj.get("batch", 0)) == args.batch:
-            traffic, traffic_src = float(ent["bytes_per_launch"]), "committed-profile: profiles/hbm_traffic.json (" + tj["source"] + ")"
+            # the PAIR that replaced round 3's single launch: the pixel kernel writes raw cell histograms, the
+            # descriptor kernel reads them back -- that round trip is part of what a level moves through the memory system
+            traffic_by_kernel = {k: float(tj["kernels"][k]["bytes_per_launch"]) for k in (hog_kernel, "desc_kernel") if k in tj["kernels"]}
+            traffic, traffic_src = sum(traffic_by_kernel.values()), "committed-profile: profiles/hbm_traffic.json (" + tj["source"] + ")"
             # vector-unit occupancy of the launch from the same PMC passes: SQ_ACTIVE_INST_VALU counts quad-cycles summed over the
             # waves; x 4 / (1024 SIMDs x launch cycles) = the fraction of SIMD cycles with a vector instruction executing
             simd_cycles = 256 * 4 * 2.4e9 * hog_avg_ms * 1e-3
@@ -570,13 +601,12 @@ def main():
                           "frac": (4.0 * float(ent["SQ_ACTIVE_INST_VALU"]) / simd_cycles) if "SQ_ACTIVE_INST_VALU" in ent else None,
                           "lds_bank_conflict_ratio": (float(ent["SQ_LDS_BANK_CONFLICT"]) / float(ent["SQ_LDS_IDX_ACTIVE"]))
                           if "SQ_LDS_IDX_ACTIVE" in ent and ent["SQ_LDS_IDX_ACTIVE"] else None,
-                          "note": "compute-side picture of the launch, from the committed PMC passes of this command: frac = 4 x "
+                          "note": "counter view of the same launch, from the committed PMC passes of this command: frac = 4 x "
                                   "SQ_ACTIVE_INST_VALU / (1024 SIMDs x 2.4 GHz x this run's average launch time) = share of SIMD cycles with a "
-                                  "vector instruction executing; mfma_f32_busy_frac = the band folds' f32 matrix instructions (they slow the "
-                                  "vector pipe of the same SIMD 2.5x while they run: profiles/r04_ubench_mfma_valu_overlap.txt); lds_busy_frac = "
-                                  "LDS array cycles.  The round-4 ablations (profiles/r04_hog_ablations.txt) price the phases: image-load path "
-                                  "24 %, band folds 20 %, per-row LDS table reads 11 %, binning 8 %, ALL resize arithmetic 4 % -- the launch is "
-                                  "bound by dependent memory / LDS round trips per pixel row, not by instruction count"}
+                                  "vector instruction executing (the vector pipe is the busy unit); mfma_f32_busy_frac = the band folds' matrix "
+                                  "instructions; lds_busy_frac = LDS array cycles.  Consistent with `compute`: the launch is bound by "
+                                  "vector-instruction issue; the ablations of profiles/r04_hog_ablations.txt price WHICH instructions "
+                                  "(image-load path 24 %, band folds 20 %, per-row LDS table reads 11 %, binning 8 %, resize arithmetic 4 %)"}
     except (OSError, KeyError, ValueError, ZeroDivisionError):
         pass
 
@@ -607,6 +637,7 @@ def main():
 
     F22 = ctx.feature_dim(0)
     T22 = (F22 + 127) // 128
+    pair_ms = hog_avg_ms + app_ms / max(app_n, 1)
     out = {
         "metric": "faces/sec RCR-22 detect (batch 4096)",
         "value": faces_per_s,
@@ -628,7 +659,6 @@ def main():
             "batch_per_gpu": args.batch,
             "levels": n_levels,
             "sharding": "faces sharded by rank, no collective on the detect path",
-            "preroll_steps": PREROLL_STEPS,      # untimed, before the `warmup` steps: GPU clocks back up after the host-side set-up
         },
         "roofline": {
             "kernel": hog_kernel,
@@ -638,7 +668,15 @@ def main():
             "unit": "GB/s",
             "frac": achieved_gbs / HBM_PEAK_GBS,
             "traffic": traffic,
+            "traffic_by_kernel": traffic_by_kernel,
             "traffic_source": traffic_src,
+            "pair": {"kernels": "hog_packed_kernel + desc_kernel<FUSED> + apply_reduce_kernel (one cascade level of sdm_detect_batch)",
+                     "avg_level_ms": pair_ms,
+                     "achieved": bytes_per_launch / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0,
+                     "frac": bytes_per_launch / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if pair_ms > 0 else 0.0,
+                     "traffic_over_algorithmic": (traffic / bytes_per_launch) if (traffic and bytes_per_launch) else None,
+                     "note": "the same algorithmic bytes over the whole level (pixel kernel + descriptor / product / update launches): "
+                             "what the round-3 single launch + GEMM was replaced by"},
             "valu_issue": valu_issue,
             "compute": compute_roof,
             "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -648,14 +686,13 @@ def main():
                              % (args.batch * L * 800.0 * (1.0 + cut_frac) / 1e6, sum(4.0 * args.batch * ctx.feature_dim(l) for l in range(n_levels)) / n_levels / 1e6),
             "achieved_with_round3_byte_count": (hog_bytes / n_levels) / (hog_avg_ms * 1e-3) / 1e9 if hog_avg_ms > 0 else 0.0,
             "note": "pixel kernel of the split launch (crop + cv::resize + gradient + orientation binning + column sums + band folds -> raw "
-                    "cells).  Not HBM bound: it reads every patch byte once (traffic ~1.1 x algorithmic) at a rate set by per-pixel-row "
-                    "dependent work; see valu_issue for the compute-side numbers",
+                    "cells).  Not HBM bound: `traffic` (pixel + descriptor kernel, counters) is ~1.9 x the algorithmic bytes because the raw "
+                    "cells make a round trip through memory, and even that is ~15 % of what HBM delivers in the level's time; the launch is "
+                    "bound by the vector instructions a pixel row must issue -- `compute` is its issue-bound roofline, valu_issue the counters",
             "avg_launch_ms": hog_avg_ms,
             "launches": hog_n,
         },
         "fused_apply": fused_apply_report(args.batch, L, 400, M, cut_frac, app_ms / max(app_n, 1)),
-        "no_preroll": {"value": args.batch * args.steps / dt_no_preroll, "unit": "faces/s", "ms_per_step": dt_no_preroll / args.steps * 1e3,
-                       "note": "the same K steps timed after only the W warm-up steps (GPU clocks still ramping after the host-side set-up); rank 0"},
         "e2e_with_h2d": e2e,
         "train": {
             "metric": "train sec/cascade (RCR-22, MatrixNorm 1.5, bias unregularised)",
@@ -663,9 +700,8 @@ def main():
             "rows_per_gpu": int(txs.shape[0]),
             "sec_per_cascade": train_wall[-1] / n_levels,
             "scaling": "strong",
-            "collective": ("one reduce-scatter of the owned tile columns of {A^T A, A^T b} + an all-reduce of F + 1 floats per level "
-                           "(torch.distributed nccl = RCCL)" if shard_solve else
-                           "one all-reduce of {A^T A, A^T b} per level (torch.distributed nccl = RCCL)" if use_dist else "none (1 GPU)"),
+            "collective": ("one reduce-scatter of the owned tile columns of {A^T A, A^T b} + an all-reduce of F + 1 floats per level; " + via
+                           if shard_solve else "one all-reduce of {A^T A, A^T b} per level; " + via if use_dist else "none (1 GPU)"),
             "solve": ("sharded over the ranks by tile column: one <= 4-tile broadcast per 128-column step, one all-gather per 4 steps"
                       if shard_solve else "replicated on every rank" if use_dist else "single GPU"),
             "stage_ms_per_level_rank0": {k: v[0] / n_levels for k, v in train_timing.items()},
@@ -759,29 +795,32 @@ def main():
             per_face = np.linalg.norm(d, axis=1) / np.linalg.norm(xo.astype(np.float64), axis=1)
             return {"rel_l2_landmarks_vs_oracle": float(np.linalg.norm(d) / np.linalg.norm(xo.astype(np.float64))),
                     "max_per_face_rel_error": float(per_face.max()), "faces_above_1e-4": int((per_face > 1e-4).sum())}
-        # the oracle with cv::gemm's double accumulation (SURVEY a-6; oracle/sdm_oracle.py LinearRegressor.accumulate_double)
-        oregs64 = []
+        # The oracle's predict restates cv::gemm's DOUBLE accumulation (SURVEY a-6; the default of oracle/sdm_oracle.py since round 5).
+        # The labelled alternative -- a float32-accumulating BLAS sgemm, what an OpenCV built on a BLAS back-end would run -- beside it:
+        oregs32 = []
         for l in range(n_levels):
-            r = orc.LinearRegressor(accumulate_double=True)
+            r = orc.LinearRegressor(accumulate_double=False)
             r.x = regressors[l]
-            oregs64.append(r)
-        ohog64 = orc.HogTransform(images[:ns], oparams, re, le, None, n_threads=cores)
-        ohog64.keep_idx = True
-        ox64 = orc.SupervisedDescentOptimiser(oregs64, orc.InterEyeDistanceNormalisation(re, le)).test(x0[:ns], None, ohog64)
+            oregs32.append(r)
+        ohog32 = orc.HogTransform(images[:ns], oparams, re, le, None, n_threads=cores)
+        ohog32.keep_idx = True
+        ox32 = orc.SupervisedDescentOptimiser(oregs32, orc.InterEyeDistanceNormalisation(re, le)).test(x0[:ns], None, ohog32)
         idx_keep = ohog.idx_per_level
-        ohog.idx_per_level = ohog64.idx_per_level
-        ox_keep, ox = ox, ox64
-        par64 = compare(*gpu_cascade(_lib.SDM_HOG_COLUMNS))
+        ohog.idx_per_level = ohog32.idx_per_level
+        ox_keep, ox = ox, ox32
+        par32 = compare(*gpu_cascade(_lib.SDM_HOG_COLUMNS))
         ox, ohog.idx_per_level = ox_keep, idx_keep
         out["parity"] = dict(par, faces_checked=ns, tolerance=1e-4, levels=n_levels,
+                             oracle_predict="double-accumulating (cv::gemm, SURVEY a-6)",
                              exact_order_mode=par_exact,
-                             detect_batch_fused=dict(compare_x(x_fused, ox), vs_double_accumulating_oracle=compare_x(x_fused, ox64),
+                             detect_batch_fused=dict(compare_x(x_fused, ox), vs_sgemm_accumulating_oracle=compare_x(x_fused, ox32),
                                                      note="sdm_detect_batch as timed (descriptors x regressor slices on the chip)"),
-                             vs_double_accumulating_oracle=par64,
+                             vs_sgemm_accumulating_oracle=par32,
                              note="free-running 4-level cascade; a face 'differs in integer decisions' when a cvRound'ed patch centre or the "
                                   "patch half-width at any level differs from the oracle's (a landmark within float rounding of x.5): from "
-                                  "there on it is a different, equally valid trajectory.  The oracle's predict accumulates in float32 (BLAS "
-                                  "sgemm) by default; vs_double_accumulating_oracle = the same comparison against cv::gemm's double accumulation")
+                                  "there on it is a different, equally valid trajectory.  The oracle's predict accumulates in double and rounds "
+                                  "to float, as cv::gemm does; vs_sgemm_accumulating_oracle = the same comparison against a float32-accumulating "
+                                  "sgemm (the oracle's default until round 4; its own rounding moves a few knife-edge faces)")
 
         # ---- RCR-68 (BASELINE configs 4 / 5): the detect shard's first faces against the oracle, regressors as trained on the GPU ----
         if rcr68 is not None:
@@ -827,6 +866,20 @@ def main():
             torch.cuda.synchronize(); gpu_level = time.perf_counter() - t0
             tg = sdo_s.ctx.get_timing(reset=True)
         Rg = sdo_s.regressors[0].x
+        # what the regressor difference means in landmarks: both regressors applied to the SAME (CPU) feature rows, one update step
+        ied = 1.0 / orc.InterEyeDistanceNormalisation(re, le)(tx0[:nt]).astype(np.float64)
+        x1_cpu = tx0[:nt].astype(np.float64) - (A.astype(np.float64) @ Rcpu.astype(np.float64)) * ied
+        x1_gpu = tx0[:nt].astype(np.float64) - (A.astype(np.float64) @ Rg.astype(np.float64)) * ied
+        rows_heldout = slice(nt, min(2 * nt, int(txs.shape[0])))
+        lm_heldout = None
+        if rows_heldout.stop - rows_heldout.start >= 100:
+            n_h = int(tidx[rows_heldout].max()) + 1
+            h_hog = orc.HogTransform(timg[:n_h], oparams[:1], re, le, tidx[rows_heldout], n_threads=cores)
+            Ah = np.asarray(h_hog(tx0[rows_heldout], 0), np.float64)
+            iedh = 1.0 / orc.InterEyeDistanceNormalisation(re, le)(tx0[rows_heldout]).astype(np.float64)
+            xh_cpu = tx0[rows_heldout].astype(np.float64) - (Ah @ Rcpu.astype(np.float64)) * iedh
+            xh_gpu = tx0[rows_heldout].astype(np.float64) - (Ah @ Rg.astype(np.float64)) * iedh
+            lm_heldout = float(np.linalg.norm(xh_gpu - xh_cpu) / np.linalg.norm(xh_cpu))
         out["cpu_baseline_train"] = {
             "workload": "level 0 of the RCR-22 training cascade on the first %d training rows (sub-sampled: the full 100 000-row A^T A is "
                         "1.5 x 10^13 flop per level), MatrixNorm 1.5, bias unregularised" % nt,
@@ -837,9 +890,17 @@ def main():
             "gpu_same_rows_stage_ms": {k: v[0] for k, v in tg.items() if v[1] > 0},
             "gpu_same_rows_wall_ms": gpu_level * 1e3,
             "regressor_rel_l2_gpu_vs_cpu": float(np.linalg.norm(Rg - Rcpu) / np.linalg.norm(Rcpu)),
+            "landmarks_rel_l2_gpu_vs_cpu_regressor": {"training_rows": float(np.linalg.norm(x1_gpu - x1_cpu) / np.linalg.norm(x1_cpu)),
+                                                      "held_out_rows": lm_heldout,
+                                                      "note": "one update step with either regressor on the same feature rows: with "
+                                                              "2 000 rows for 8 801 unknowns the system is under-determined up to the "
+                                                              "regulariser, so two float32 solvers (LU on the CPU, Cholesky on the GPU) "
+                                                              "differ in directions the data does not see -- the landmarks do not move"},
             "note": "CPU stages as the reference's VerbosePartialPivLUSolver prints them (verbose_solver.hpp:66-97): Eigen's f32 GEMM / "
                     "PartialPivLU restated with numpy sgemm / LAPACK sgetrf on all cores; never extrapolated to the full row count"}
     print(json.dumps(out))
+    if rccl is not None:
+        rccl.destroy()
     if use_dist:
         dist.destroy_process_group()
 

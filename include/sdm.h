@@ -234,7 +234,11 @@ int sdm_solve(sdm_ctx* ctx, int level, int reg_type, float reg_param, int regula
  *   SDM_SOLVER_CHOLESKY   (default) PartialPivLUSolver's role, regressors.hpp:199-234 -- blocked Cholesky, the SPD system needs no pivoting;
  *   SDM_SOLVER_COLPIV_QR  ColPivHouseholderQRSolver, regressors.hpp:242-306 -- Householder QR with column pivoting of AtA + reg on the
  *                         device (csrc/sdm_qr.hip), x = P R^-1 Q^T (At b); "much MUCH slower" there too (level-2 work, 2 F launches), and the
- *                         one that can tell a singular system: sdm_last_rank.  Replicated only (not with sdm_set_solve_sharding), F <= 38 400. */
+ *                         one that can tell a singular system: sdm_last_rank.  As Eigen's solve() / inverse() the back substitution stops at the last
+ *                         nonzero pivot (largest remaining squared column norm below max ||a_j||^2 eps^2 / F * (F - k), or zero) and
+ *                         returns zero coefficients for the remaining columns: a singular system gives a finite regressor ("we continued
+ *                         learning", regressors.hpp:291).  Always replicated (installed sharding does not concern it; its levels take
+ *                         the all-reduce, never the reduce-scatter), F <= 38 400. */
 #define SDM_SOLVER_CHOLESKY 0
 #define SDM_SOLVER_COLPIV_QR 1
 int sdm_set_solver(sdm_ctx* ctx, int solver);

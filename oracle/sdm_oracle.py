@@ -321,8 +321,11 @@ def col_piv_householder_qr_f32(A: np.ndarray):
     largest (down-dated) squared norm is swapped to position k (lowest index among equals), the Householder vector of column k
     below the diagonal is v = a / (a_kk - beta), beta = -sign(a_kk) ||a_k:||, tau = (beta - a_kk) / beta, the reflection
     I - tau v v^T is applied to the remaining columns and their norms are down-dated by the new row-k entries.  Returns
-    (qr, tau, perm, rank): R on and above the diagonal of qr, the vectors below it; rank = #{|R_kk| > eps * n * max |R_kk|}
-    (Eigen's default threshold, what rank() / isInvertible() at regressors.hpp:289-290 use)."""
+    (qr, tau, perm, rank, nonzero_pivots): R on and above the diagonal of qr, the vectors below it; rank = #{k < nonzero_pivots:
+    |R_kk| > eps * n * max |R_kk|} (Eigen's default threshold, what rank() / isInvertible() at regressors.hpp:289-290 use).
+    nonzero_pivots: Eigen stops the elimination at the first step whose largest remaining (down-dated) squared column norm falls
+    below max_j ||a_j||^2 * eps^2 / n * (n - k) (3.2: "terminate to avoid generating nan/inf values") or is exactly zero (3.3);
+    solve() / inverse() then use the leading nonzero_pivots x nonzero_pivots block only and return zero rows for the rest."""
     f32 = np.float32
     qr = np.array(A, dtype=f32, order="C")
     n = qr.shape[0]
@@ -332,8 +335,14 @@ def col_piv_householder_qr_f32(A: np.ndarray):
     for i in range(n):                                        # (rows ascending: the order a plain loop over the column takes)
         cn += qr[i] * qr[i]
     maxpiv = f32(0.0)
+    thr_helper = f32(f32(cn.max() if n else 0.0) * f32(np.finfo(f32).eps) * f32(np.finfo(f32).eps) / f32(n)) if n else f32(0.0)
+    nzp = n
     for k in range(n):
         p = k + int(np.argmax(cn[k:]))                        # first of the maxima
+        if cn[p] < f32(thr_helper * f32(n - k)) or cn[p] == 0:
+            nzp = k                                           # (no further reflections: tau = 0, nothing below the diagonal)
+            qr[k:, k:] = np.triu(qr[k:, k:])
+            break
         if p != k:
             qr[:, [k, p]] = qr[:, [p, k]]
             cn[[k, p]] = cn[[p, k]]
@@ -359,29 +368,29 @@ def col_piv_householder_qr_f32(A: np.ndarray):
             qr[k + 1:, k + 1:] = (qr[k + 1:, k + 1:] - np.outer(v, d).astype(f32)).astype(f32)
             cn[k + 1:] = (cn[k + 1:] - qr[k, k + 1:] * qr[k, k + 1:]).astype(f32)
     thr = f32(np.finfo(f32).eps) * f32(n) * maxpiv
-    rank = int(np.sum(np.abs(np.diagonal(qr)) > thr))
-    return qr, tau, perm, rank
+    rank = int(np.sum(np.abs(np.diagonal(qr)[:nzp]) > thr))
+    return qr, tau, perm, rank, nzp
 
 
-def _qr_solve_f32(qr, tau, perm, B):
-    """A^-1 B through the factorisation: Q^T B, back substitution with R, inverse column permutation (float32)."""
+def _qr_solve_f32(qr, tau, perm, B, nzp=None):
+    """A^-1 B through the factorisation as Eigen's ColPivHouseholderQR::solve does it: the first nonzero_pivots reflections applied
+    to B, back substitution with the leading nonzero_pivots x nonzero_pivots block of R, zero rows for the remaining (permuted)
+    unknowns, inverse column permutation (float32).  A singular system therefore gives a FINITE solution ("we continued learning",
+    regressors.hpp:291)."""
     f32 = np.float32
     from scipy.linalg import solve_triangular
     n = qr.shape[0]
+    nzp = n if nzp is None else nzp
     B = np.array(B, dtype=f32, order="C")
-    for k in range(n):
+    for k in range(nzp):
         v = qr[k + 1:, k]
         d = ((B[k] + (v @ B[k + 1:]).astype(f32)).astype(f32) * tau[k]).astype(f32)
         B[k] = (B[k] - d).astype(f32)
         if k + 1 < n:
             B[k + 1:] = (B[k + 1:] - np.outer(v, d).astype(f32)).astype(f32)
-    if np.all(np.diagonal(qr) != 0):
-        Y = solve_triangular(np.triu(qr), B, lower=False, check_finite=False).astype(f32)
-    else:      # a singular R: Eigen divides regardless ("may return garbage", regressors.hpp:291) -- inf / nan, no exception
-        Y = B.copy()
-        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
-            for i in range(n - 1, -1, -1):
-                Y[i] = ((Y[i] - (qr[i, i + 1:] @ Y[i + 1:]).astype(f32)) / qr[i, i]).astype(f32)
+    Y = np.zeros_like(B)
+    if nzp > 0:
+        Y[:nzp] = solve_triangular(np.triu(qr[:nzp, :nzp]), B[:nzp], lower=False, check_finite=False).astype(f32)
     X = np.empty_like(Y)
     X[perm] = Y
     return X
@@ -404,25 +413,27 @@ class ColPivHouseholderQRSolver:
         if not regulariser.regularise_last_row:
             diag[-1] = 0.0
         AtA[np.diag_indices_from(AtA)] += diag                   # :279-285
-        qr, tau, perm, rank = col_piv_householder_qr_f32(AtA)    # :288
+        qr, tau, perm, rank, nzp = col_piv_householder_qr_f32(AtA)    # :288
         self.rank, self.full_rank = rank, AtA.shape[0]           # :289-293 (the reference prints a warning when rank < F)
-        inv = _qr_solve_f32(qr, tau, perm, np.eye(AtA.shape[0], dtype=np.float32))      # :294
+        self.nonzero_pivots = nzp
+        inv = _qr_solve_f32(qr, tau, perm, np.eye(AtA.shape[0], dtype=np.float32), nzp)      # :294
         # :297, evaluated left to right as Eigen does: (inverse * At) * b
-        with np.errstate(invalid="ignore", over="ignore"):       # (a singular system: inf / nan travel, as in Eigen)
+        with np.errstate(invalid="ignore", over="ignore"):
             return np.ascontiguousarray(((inv @ A.T).astype(np.float32) @ b).astype(np.float32))
 
 
 class LinearRegressor:
     """regressors.hpp:318-400."""
 
-    def __init__(self, regulariser: Optional[Regulariser] = None, accumulate_double: bool = False, solver=None):
+    def __init__(self, regulariser: Optional[Regulariser] = None, accumulate_double: bool = True, solver=None):
         self.solver = solver                                      # None: PartialPivLUSolver (the reference's default template argument)
         self.x: Optional[np.ndarray] = None
         self.regulariser = regulariser or Regulariser()
-        # `values * x` is cv::gemm on CV_32F (regressors.hpp:377-381).  OpenCV's generic f32 kernel is known to accumulate the
-        # dot products in double and round the result to float (SURVEY.md row a-6; OpenCV itself is absent from the reference
-        # checkout, so this cannot be pinned here): accumulate_double=True restates that; False (the default the gtest goldens of
-        # tests/test_oracle_regressors.py were pinned with) accumulates in float32 as a BLAS sgemm does.  Parity reports use both.
+        # `values * x` is cv::gemm on CV_32F (regressors.hpp:377-381).  OpenCV's generic f32 kernel accumulates the dot products in
+        # double and rounds the result to float (SURVEY.md row a-6; OpenCV itself is absent from the reference checkout, so this
+        # cannot be pinned here): accumulate_double=True -- the default since round 5 (VERDICT r04 item 7) -- restates that;
+        # accumulate_double=False is the labelled alternative, a BLAS sgemm accumulating in float32 (what an OpenCV built against
+        # a BLAS back-end would run).  The reference's gtest goldens (tests/test_oracle_regressors.py) hold for both.
         self.accumulate_double = accumulate_double
 
     def learn(self, data: np.ndarray, labels: np.ndarray) -> bool:

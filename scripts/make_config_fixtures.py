@@ -14,7 +14,8 @@ geometry on 10 000 rows; rcr68t = RCR-68 training at a CPU-feasible 4 000 rows):
   3. CPU solver-vs-solver DRIFT, free-running: a second cascade that uses Cholesky32 at every level and sees only its own
      landmarks from level 1 on -- what "two float32 solvers, free-running" amounts to without any GPU in the picture.
 
-Numbers go to profiles/r03_cpu_solver_drift.json.
+Numbers go to profiles/r05_cpu_solver_drift.json (round 5: regenerated with the oracle's double-accumulating predict; round 3's
+run with a float32-accumulating sgemm stays as profiles/r03_cpu_solver_drift.json).
 
     python scripts/make_config_fixtures.py [config3 rcr22 rcr68t] [--no-f64]
 """
@@ -72,8 +73,13 @@ def run(name, out, fix, want_f64):
         b = ((x - x_star) * n).astype(np.float32)                        # superviseddescent.hpp:199-205
         inv_n = (np.float32(1.0) / n).astype(np.float32)
 
+        def predict(Am, Rm):
+            lr = orc.LinearRegressor()          # LinearRegressor::predict as the oracle restates it (regressors.hpp:377-381: cv::gemm
+            lr.x = Rm.astype(np.float32)        # accumulates in double -- the oracle's default since round 5)
+            return lr.predict(Am)
+
         def step(Rm, A=A, inv_n=inv_n, x=x):
-            return (x - (A @ Rm.astype(np.float32)).astype(np.float32) * inv_n).astype(np.float32)   # :209-215
+            return (x - predict(A, Rm) * inv_n).astype(np.float32)   # :209-215
         # (1) the oracle proper
         R_lu = orc.partial_piv_lu_solve(A, b, R)
         x_next = step(R_lu)
@@ -102,7 +108,7 @@ def run(name, out, fix, want_f64):
             add_diag(Gc, lamc, R)
             Rc = cho_solve(cho_factor(Gc, check_finite=False, overwrite_a=True), Bc, check_finite=False)
             del Gc
-            xc_next = (xc - (Ac @ Rc.astype(np.float32)).astype(np.float32) * (np.float32(1.0) / nc).astype(np.float32)).astype(np.float32)
+            xc_next = (xc - predict(Ac, Rc) * (np.float32(1.0) / nc).astype(np.float32)).astype(np.float32)
             del Ac
         fr_chol.append(rel(xc_next, x_next))
         nlsr_lu.append(rel(x_next, x_star))
@@ -134,7 +140,7 @@ def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     want_f64 = "--no-f64" not in sys.argv
     which = args or ["rcr68t", "rcr22", "config3"]
-    out_json = os.path.join(ROOT, "profiles", "r03_cpu_solver_drift.json")
+    out_json = os.path.join(ROOT, "profiles", "r05_cpu_solver_drift.json")
     out_npz = os.path.join(ROOT, "tests", "golden", "config_oracle_full.npz")
     out = json.load(open(out_json)) if os.path.exists(out_json) else {}
     fix = dict(np.load(out_npz)) if os.path.exists(out_npz) else {}

@@ -71,7 +71,7 @@ struct sdm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    SolveAux solve_aux = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};   // second queue of the Cholesky look-ahead (+ the scratch of its float16 updates, set per solve)
+    SolveAux solve_aux = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0};   // second queue of the Cholesky look-ahead (+ the scratch of its float16 updates, set per solve)
     DevBuf<unsigned char> upd_planes;    // one panel group as float16 planes (sdm_update_f16_plane_bytes)
     DevBuf<unsigned> upd_maxdiag;
 
@@ -85,7 +85,7 @@ struct sdm_ctx {
     // per level: lane-packed launch plan (sdm_hog_fast.hip::hog_packed_kernel), device tables owned here
     struct Plan { bool ok = false; HogPlanDev dev{}; DevBuf<unsigned> lane_tab; DevBuf<float> wb; DevBuf<unsigned short> wb16; DevBuf<int> pass_info; DevBuf<int> cut; DevBuf<int> taps; };
     std::vector<Plan> plans;
-    // round 4: the packed launch stops at the raw cell histograms (cells[N][L][2][2O][C*C]); sdm_desc.hip normalises them into the
+    // round 4: the packed launch stops at the raw cell histograms (cells[N][L][2 parts][C*C][2O]); sdm_desc.hip normalises them into the
     // feature rows, or -- sdm_detect_batch -- multiplies the descriptors by the regressor without writing the feature matrix
     DevBuf<float> cells;
     int solver_kind = SDM_SOLVER_CHOLESKY;      // sdm_set_solver
@@ -97,6 +97,13 @@ struct sdm_ctx {
     bool fuse_apply = true;         // SDM_DETECT_UNFUSED=1: sdm_detect_batch through the feature matrix + apply GEMM (A/B)
     bool fuse_wide = false;         // sdm_debug_set_detect_path(fused = 2): fuse also when 2L > 64 (tests of the wide launch)
     bool packing = true;            // sdm_debug_set_hog_packing / SDM_HOG_NO_PACK=1: run the one-patch-per-wave kernel instead
+    // Round 5 experiment (SDM_DETECT_HALVES=1|2): sdm_detect_batch runs the batch as two halves on two queues of
+    // its own, each half its own chain of cascade levels, the second half started one pixel kernel behind the first -- so that the
+    // short descriptor / product / update launches of one half and the ramp-up and tail of its pixel kernel run beside the other
+    // half's pixel kernel.  2: the descriptor / update launches on two further queues of the highest priority.
+    int env_halves = 0;
+    hipStream_t half_stream[4] = {nullptr, nullptr, nullptr, nullptr};      // pixel queue of half 0 / 1, descriptor queue of half 0 / 1
+    hipEvent_t half_ev[8] = {};                                             // per half: pixel done, level done; + fork, join (2 x 2 + 2 + spare)
     // A/B switches of the environment, all read ONCE in sdm_create (no getenv inside a launch path)
     bool env_fuse_wide = false;     // SDM_DETECT_FUSE_WIDE=1: fuse descriptor + apply also when 2L > 64
     bool env_apply_f32 = false;     // SDM_APPLY_F32=1: sdm_apply always on the f32 matrix-core kernel
@@ -129,7 +136,11 @@ struct sdm_ctx {
     int tmpl_F = 0, tmpl_N = 0;
     bool have_targets = false;
     DevBuf<float> feat;
-    int feat_level = -1;
+    int feat_level = -1;            // level whose rows are resident (-1: none) -- only the "features of this level extracted" check
+    // what the rows may still hold from EARLIER launches: the widest feature row and the most rows written since the
+    // buffer was last cleared.  A level with a narrower row clears them first, whatever ran in between (a fused detect level, a
+    // different sample count): the Gram kernel multiplies whole 128-column tiles and add_diag assumes the padding is zero.
+    int feat_wide_F = 0, feat_wide_N = 0;
     // The float16-piece apply (sdm_apply.hip) scales every feature by 2^12 before the split: exact for |feature| < 16, which HOG
     // descriptors (<= 0.4) satisfy by construction.  Rows that are NOT plain HOG output -- templates subtracted, or the caller holds
     // the device pointer (sdm_features_device_ptr) and may have written them -- go through the f32 matrix-core kernel.
@@ -298,7 +309,7 @@ int ensure_sample_buffers(sdm_ctx* c, int N)
     if (nf > c->feat.cap) {
         // zero once: the padding columns must stay exactly 0 for the GEMMs that read full tiles
         if ((rc = c->feat.ensure(nf, true, c->stream))) return rc;
-        c->feat_level = -1;
+        c->feat_level = -1; c->feat_wide_F = 0; c->feat_wide_N = 0;
     }
     if ((rc = c->patch_idx.ensure((size_t)N * (1 + 2 * c->L)))) return rc;
     return SDM_OK;
@@ -347,9 +358,12 @@ int launch_cells(sdm_ctx* c, int level)
 int do_hog(sdm_ctx* c, int level)
 {
     { const int rci = hog_checks(c, level); if (rci) return rci; }
-    if (c->feat_level >= 0 && level_F(c, c->feat_level) != level_F(c, level)) {
-        // a different level geometry leaves stale columns beyond its own F: clear the rows once
-        HIP_TRY(hipMemsetAsync(c->feat.p, 0, (size_t)c->N * c->ldf * sizeof(float), c->stream));
+    if (c->feat_wide_F > level_F(c, level)) {
+        // an earlier launch wrote wider rows: its columns beyond this level's F would be stale -- clear every row written since the
+        // last clear, once
+        const size_t rows = (size_t)(c->feat_wide_N > c->N ? c->feat_wide_N : c->N);
+        HIP_TRY(hipMemsetAsync(c->feat.p, 0, rows * c->ldf * sizeof(float), c->stream));
+        c->feat_wide_F = 0; c->feat_wide_N = 0;
         c->ev_fresh = false;      // (untimed work: the next timed stage records its own start)
     }
     {
@@ -378,6 +392,8 @@ int do_hog(sdm_ctx* c, int level)
     }
     HIP_TRY(hipGetLastError());
     c->feat_level = level;
+    if (level_F(c, level) > c->feat_wide_F) c->feat_wide_F = level_F(c, level);
+    if (c->N > c->feat_wide_N) c->feat_wide_N = c->N;
     c->feat_bounded = c->tmpl_N == 0;
     c->have_patch_idx = true;
     return SDM_OK;
@@ -459,6 +475,62 @@ int detect_level_fused(sdm_ctx* c, int l)
     return SDM_OK;
 }
 
+// The whole cascade with the batch as two halves on two queues (SDM_DETECT_HALVES; see sdm_ctx::env_halves).  Same kernels, same
+// per-sample arithmetic as detect_level_fused level by level: every buffer is indexed by sample, a half is a pointer offset.
+int detect_cascade_halves(sdm_ctx* c)
+{
+    const int NL = (int)c->levels.size(), Mp = Mp_of(c->M), N = c->N;
+    int rc;
+    size_t cells_max = 0;
+    for (int q = 0; q < NL; ++q) { const size_t n = sdm_cells_floats(c->levels[q], N, c->L); if (n > cells_max) cells_max = n; }
+    if ((rc = c->cells.ensure(cells_max)) || (rc = c->partial.ensure((size_t)c->L * N * Mp))) return rc;
+    const int n0[2] = {0, N / 2}, nh[2] = {N / 2, N - N / 2};
+    hipEvent_t fork = c->half_ev[4], join0 = c->half_ev[5], join1 = c->half_ev[6], stagger = c->half_ev[7];
+    HIP_TRY(hipEventRecord(fork, c->stream));
+    const bool prio = c->env_halves >= 2;
+    int cur = c->cur;
+    for (int hf = 0; hf < 2; ++hf) {
+        HIP_TRY(hipStreamWaitEvent(c->half_stream[hf], fork, 0));
+        if (prio) HIP_TRY(hipStreamWaitEvent(c->half_stream[2 + hf], fork, 0));
+    }
+    for (int l = 0; l < NL; ++l) {
+        const HogLevelDev& lv = c->levels[l];
+        const size_t cells_per_sample = (sdm_cells_floats(lv, N, c->L) - 4) / (size_t)N;
+        for (int hf = 0; hf < 2; ++hf) {
+            if (nh[hf] <= 0) continue;
+            hipStream_t sp = c->half_stream[hf], sd = prio ? c->half_stream[2 + hf] : sp;
+            hipEvent_t pixel_done = c->half_ev[2 * hf], level_done = c->half_ev[2 * hf + 1];
+            ImageSetDev is = image_set(c);
+            const int* idx = c->idx_identity ? nullptr : c->img_idx.p + n0[hf];
+            if (c->idx_identity) { is.offset += n0[hf]; is.w += n0[hf]; is.h += n0[hf]; is.stride += n0[hf]; is.n_images -= n0[hf]; }
+            const float* xin = c->x[cur].p + (size_t)n0[hf] * c->M;
+            float* xout = c->x[cur ^ 1].p + (size_t)n0[hf] * c->M;
+            float* cells = c->cells.p + (size_t)n0[hf] * cells_per_sample;
+            float* partial = c->partial.p + (size_t)c->L * n0[hf] * Mp;
+            if (l == 0 && hf == 1) HIP_TRY(hipStreamWaitEvent(sp, stagger, 0));      // the second half starts one pixel kernel behind the first
+            if (prio && l > 0) HIP_TRY(hipStreamWaitEvent(sp, level_done, 0));
+            sdm_launch_hog_cells(is, idx, xin, nh[hf], c->L, c->eyes, lv, c->plans[l].dev, cells, c->patch_idx.p + (size_t)n0[hf] * (1 + 2 * c->L),
+                                 c->status.p, sp);
+            if (l == 0 && hf == 0) HIP_TRY(hipEventRecord(stagger, sp));
+            if (prio) { HIP_TRY(hipEventRecord(pixel_done, sp)); HIP_TRY(hipStreamWaitEvent(sd, pixel_done, 0)); }
+            sdm_launch_desc_apply(lv, cells, c->plans[l].cut.p, nh[hf], c->L, c->M, c->Rd[l].p, c->Rmax.p + (size_t)l * Mp, c->Rt[l].p, c->ldf,
+                                  partial, sd);
+            sdm_launch_apply_reduce(partial, c->L, nh[hf], c->M, xin, xout, c->L, c->eyes, sd);
+            if (prio) HIP_TRY(hipEventRecord(level_done, sd));
+        }
+        cur ^= 1;
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(join0, prio ? c->half_stream[2] : c->half_stream[0]));
+    HIP_TRY(hipEventRecord(join1, prio ? c->half_stream[3] : c->half_stream[1]));
+    HIP_TRY(hipStreamWaitEvent(c->stream, join0, 0));
+    HIP_TRY(hipStreamWaitEvent(c->stream, join1, 0));
+    c->cur = cur;
+    c->feat_level = -1;
+    c->have_patch_idx = true;
+    return SDM_OK;
+}
+
 // one cascade level of detect: fused when the level qualifies, else feature rows + apply GEMM
 int detect_level(sdm_ctx* c, int l)
 {
@@ -508,13 +580,25 @@ sdm_ctx* sdm_create(int device)
     // at F = 8801; moving the chain to a highest-priority queue of its own on top of that: 7.3, not kept)
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    int mid_prio = 0;
+    { const char* v = getenv("SDM_SOLVE_MID_PRIO"); if (v && v[0] == 'l') mid_prio = prio_least; else if (v && v[0] == 'h') mid_prio = prio_greatest; }
     if (hipStreamCreateWithPriority(&c->solve_aux.stream, hipStreamNonBlocking, prio_least) != hipSuccess ||
         hipEventCreateWithFlags(&c->solve_aux.chain_done, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->solve_aux.tail_done, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->solve_aux.tail_done, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithPriority(&c->solve_aux.mid_stream, hipStreamNonBlocking, mid_prio) != hipSuccess ||
+        hipEventCreateWithFlags(&c->solve_aux.mid_done, hipEventDisableTiming) != hipSuccess) {
         fail(SDM_ERR_HIP, "hipStreamCreate failed"); delete c; return nullptr;
     }
     if (c->status.ensure(1, true, c->stream) || c->lambda_dev.ensure(1, true, c->stream)) { delete c; return nullptr; }
     { const char* np = getenv("SDM_HOG_NO_PACK"); c->packing = !(np && np[0] == '1'); }
+    { const char* v = getenv("SDM_DETECT_HALVES"); c->env_halves = v ? atoi(v) : 0; }
+    if (c->env_halves > 0) {
+        bool ok = true;
+        for (int q = 0; q < 4 && ok; ++q)
+            ok = hipStreamCreateWithPriority(&c->half_stream[q], hipStreamNonBlocking, q < 2 ? 0 : prio_greatest) == hipSuccess;
+        for (int q = 0; q < 8 && ok; ++q) ok = hipEventCreateWithFlags(&c->half_ev[q], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { fail(SDM_ERR_HIP, "hipStreamCreate failed"); delete c; return nullptr; }
+    }
     { const char* np = getenv("SDM_HOG_SPLIT_STORE"); c->split_store = np && np[0] == '1'; }
     { const char* np = getenv("SDM_DETECT_UNFUSED"); c->fuse_apply = !(np && np[0] == '1'); }
     auto env_on = [](const char* name) { const char* v = getenv(name); return v && v[0] == '1'; };
@@ -527,6 +611,9 @@ sdm_ctx* sdm_create(int device)
     c->env_gram_f32 = env_on("SDM_GRAM_F32");
     c->env_gram_bf16 = env_on("SDM_GRAM_BF16X3");
     c->solve_aux.upd_f32_only = env_on("SDM_UPDATE_F32") ? 1 : 0;
+    { const char* v = getenv("SDM_SOLVE_HEAD_SPLIT"); c->solve_aux.head_split = (v && v[0] == '1'); }
+    { const char* v = getenv("SDM_SOLVE_UPD_MIN_TILES"); c->solve_aux.upd_min_tiles = v ? atoi(v) : 0; }
+    { const char* v = getenv("SDM_SOLVE_LAZY"); const int lz = v ? atoi(v) : 0; c->solve_aux.lazy = (lz == 2 || lz == 4 || lz == 6 || lz == 8) ? lz : 0; }
     { const char* v = getenv("SDM_SOLVE_SHARD_EMULATE"); c->env_shard_emulate = v ? atoi(v) : 0; }
     return c;
 }
@@ -542,8 +629,12 @@ void sdm_destroy(sdm_ctx* c)
         for (int b = 0; b < sdm_ctx::XBLOCKS_MAX; ++b) if (c->gram_ev[b]) e = hipEventDestroy(c->gram_ev[b]);
         if (c->gram_xdone) e = hipEventDestroy(c->gram_xdone);
         e = hipStreamDestroy(c->solve_aux.stream);
+        if (c->solve_aux.mid_stream) { e = hipStreamSynchronize(c->solve_aux.mid_stream); e = hipStreamDestroy(c->solve_aux.mid_stream); }
+        if (c->solve_aux.mid_done) e = hipEventDestroy(c->solve_aux.mid_done);
     }
     drain_timing(c);
+    for (int q = 0; q < 4; ++q) if (c->half_stream[q]) { e = hipStreamSynchronize(c->half_stream[q]); e = hipStreamDestroy(c->half_stream[q]); }
+    for (int q = 0; q < 8; ++q) if (c->half_ev[q]) e = hipEventDestroy(c->half_ev[q]);
     for (auto ev : c->pool) { e = hipEventDestroy(ev); }
     c->img_owned.release(); c->img_off.release(); c->img_w.release(); c->img_h.release();
     c->img_stride.release(); c->img_idx.release(); c->x[0].release(); c->x[1].release();
@@ -718,7 +809,7 @@ int sdm_set_model_geometry(sdm_ctx* c, int L, const int* re, int nre, const int*
     c->Rd.assign(n_levels, DevBuf<unsigned char>());
     c->cells.release();
     c->have_R.assign(n_levels, false);
-    c->feat.release(); c->feat_level = -1; c->have_patch_idx = false;
+    c->feat.release(); c->feat_level = -1; c->feat_wide_F = 0; c->feat_wide_N = 0; c->have_patch_idx = false;
     c->N = 0; c->have_targets = false; c->g_level = -1;
     return SDM_OK;
 }
@@ -1038,6 +1129,10 @@ int sdm_detect_batch(sdm_ctx* c, float* x_host)
     HIP_TRY(hipSetDevice(c->device));
     c->chain_timers = true; c->ev_fresh = false;
     int rc = SDM_OK;
+    bool halves = c->env_halves > 0 && c->N >= 512 && !c->timing;
+    for (int l = 0; l < (int)c->levels.size() && halves; ++l) halves = fused_ok(c, l);
+    if (halves) { rc = hog_checks(c, 0); if (!rc) rc = detect_cascade_halves(c); }
+    else
     for (int l = 0; l < (int)c->levels.size() && !rc; ++l) rc = detect_level(c, l);
     c->chain_timers = false; c->ev_fresh = false;
     if (rc) return rc;
@@ -1256,7 +1351,7 @@ int sdm_set_solve_sharding_rccl(sdm_ctx* c, void* nccl_comm, int rank, int world
 int solve_update_scratch(sdm_ctx* c, int ncols)
 {
     int rc;
-    if ((rc = c->upd_planes.ensure(sdm_update_f16_plane_bytes(512, ncols))) || (rc = c->upd_maxdiag.ensure(4))) return rc;
+    if ((rc = c->upd_planes.ensure(sdm_update_f16_plane_bytes(128 * (c->solve_aux.lazy > 0 ? c->solve_aux.lazy : 4), ncols))) || (rc = c->upd_maxdiag.ensure(4))) return rc;
     c->solve_aux.upd_planes = c->upd_planes.p;
     c->solve_aux.upd_maxdiag = c->upd_maxdiag.p;
     c->solve_aux.range_fallbacks = &c->update_range_fallbacks;
@@ -1277,7 +1372,8 @@ int sdm_allreduce_gram_rhs(sdm_ctx* c)
     // float16 updates' scale is taken from its largest entry) and the ranks' shares of ||G||_F^2 (MatrixNorm).
     const bool sharded = c->shard_world >= 1 && (c->shard_comm || c->shard_bcast) && c->shard_world == c->world_size;
     const bool can_rs = c->reduce_scatter || (c->rccl_reduce_scatter && c->rccl_comm);
-    if (sharded && can_rs) {
+    // (the column-pivoted QR is replicated: its levels take the all-reduce of the whole matrix, as sdm_gram_rhs assumed -- ADVICE r04)
+    if (sharded && can_rs && c->solver_kind == SDM_SOLVER_CHOLESKY) {
         const int W = c->shard_world, me = c->shard_rank;
         int rc;
         if ((rc = c->gsmall.ensure((size_t)F + 1)) || (rc = c->fro.ensure((size_t)F + 1))) return rc;
@@ -1401,6 +1497,11 @@ int sdm_solve(sdm_ctx* c, int level, int reg_type, float reg_param, int regulari
     const int F = level_F(c, level), M = c->M, Mp = Mp_of(M);
     const int Fp = round_up(F, 128), ncols = c->g_ncols;
     int rc;
+    // The column-pivoted QR runs replicated on the whole summed matrix: installed sharding does not concern it (every rank holds
+    // the all-reduced system), a reduce-scattered matrix cannot serve it -- said BEFORE the regulariser is added to G (a
+    // retry must not regularise twice).
+    if (c->solver_kind == SDM_SOLVER_COLPIV_QR && c->g_scattered)
+        return fail(SDM_ERR_INVALID, "sdm_solve: the column-pivoted QR solver needs the whole summed Gram matrix (it was reduce-scattered over the ranks)");
     if ((rc = c->fro.ensure((size_t)F + 1))) return rc;
     if ((rc = c->Rsol.ensure((size_t)Fp * Mp))) return rc;
     if ((rc = c->winv.ensure((size_t)Fp * 128 + sdm_backsolve_flag_floats(Fp) /* + the back substitution's flags */))) return rc;
@@ -1416,15 +1517,17 @@ int sdm_solve(sdm_ctx* c, int level, int reg_type, float reg_param, int regulari
         Timer t(c, SDM_T_FACTOR);
         // factor + forward substitution (the back substitution is part of the same launcher)
         SolveShard shard{};
-        const bool sharded = c->shard_world >= 1 && (c->shard_comm || c->shard_bcast);
-        if (c->g_scattered && !(sharded && c->shard_world == c->world_size))
+        const bool sharded = c->shard_world >= 1 && (c->shard_comm || c->shard_bcast) && c->solver_kind == SDM_SOLVER_CHOLESKY;
+        if (c->g_scattered && !(sharded && c->shard_world == c->world_size)) {
+            c->g_level = -1;      // (the regulariser is already on the diagonal: sdm_gram_rhs has to run again)
             return fail(SDM_ERR_INVALID, "sdm_solve: the Gram matrix was reduce-scattered over the ranks; the factorisation must be sharded over the same ranks");
+        }
         if (sharded) {
             // The staging size is a function of (ncols, 2L, world) only and is what the launcher decides by -- not the buffer's
             // capacity, which a reused context may hold larger than its peers (one rank would then take the all-gather of
             // the sharded back substitution and the others not).  Sized so that the sharded back substitution always fits.
             const size_t nj_rhs = (size_t)(Mp / 16), bs_per = (nj_rhs + c->shard_world - 1) / c->shard_world;
-            size_t stage_need = sdm_solve_shard_stage_tiles(ncols, c->shard_world) * 128 * 128;
+            size_t stage_need = sdm_solve_shard_stage_tiles(ncols, c->shard_world, c->solve_aux.lazy) * 128 * 128;
             const size_t bs_need = (size_t)(c->shard_world + 1) * (size_t)Fp * 16 * bs_per;
             if (bs_need > stage_need) stage_need = bs_need;
             if ((rc = c->shard_stage.ensure(stage_need))) return rc;
@@ -1433,7 +1536,6 @@ int sdm_solve(sdm_ctx* c, int level, int reg_type, float reg_param, int regulari
             shard.emulate_chain = c->env_shard_emulate;
         }
         if (c->solver_kind == SDM_SOLVER_COLPIV_QR) {
-            if (sharded || c->g_scattered) return fail(SDM_ERR_INVALID, "sdm_solve: the column-pivoted QR solver is not sharded over ranks");
             if ((rc = qr_solve(c, c->G.p, ncols, F, Fp, Mp, c->Rsol.p))) { c->g_level = -1; return rc; }
         } else {
         if ((rc = solve_update_scratch(c, ncols))) return rc;
@@ -1594,6 +1696,8 @@ int sdm_debug_hog_profile(sdm_ctx* c, int level, unsigned long long* out8)
     HIP_TRY(hipStreamSynchronize(c->stream));
     d.release();
     c->feat_level = level;
+    if (level_F(c, level) > c->feat_wide_F) c->feat_wide_F = level_F(c, level);
+    if (c->N > c->feat_wide_N) c->feat_wide_N = c->N;
     return SDM_OK;
 }
 

@@ -1936,7 +1936,7 @@ void sdm_launch_hog_packed(const ImageSetDev& imgs, const int* img_idx, const fl
     launch_hog_packed<false>(imgs, img_idx, x, N, L, eyes, lv, plan, feat, ldf, idx_out, status, stream);
 }
 
-// the same launch stopping at the raw cell histograms: cells[N][L][2 parts][2O][C*C] floats (see hog_packed_kernel, CELLS)
+// the same launch stopping at the raw cell histograms: cells[N][L][2 parts][C*C][2O] floats (see hog_packed_kernel, CELLS)
 void sdm_launch_hog_cells(const ImageSetDev& imgs, const int* img_idx, const float* x, int N, int L,
                           const EyeIdxDev& eyes, const HogLevelDev& lv, const HogPlanDev& plan, float* cells,
                           int* idx_out, int* status, hipStream_t stream)

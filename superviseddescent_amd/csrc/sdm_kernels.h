@@ -121,7 +121,7 @@ void sdm_launch_hog_packed(const ImageSetDev& imgs, const int* img_idx, const fl
                            const EyeIdxDev& eyes, const HogLevelDev& lv, const HogPlanDev& plan, float* feat, long long ldf,
                            int* idx_out, int* status, hipStream_t stream);
 
-// The packed launch stopping at the raw cell histograms (round 4): cells[N][L][2 parts][2O][C*C] f32; part 1 is written only
+// The packed launch stopping at the raw cell histograms (round 4): cells[N][L][2 parts][C*C][2O] f32 (a cell's 2O bins are consecutive: what the producer's band folds store and sdm_desc.hip's lane per cell loads); part 1 is written only
 // for landmarks with plan cut[l] = 1 (patch cut by a pass boundary); sdm_desc.hip turns them into descriptors.
 void sdm_launch_hog_cells(const ImageSetDev& imgs, const int* img_idx, const float* x, int N, int L,
                           const EyeIdxDev& eyes, const HogLevelDev& lv, const HogPlanDev& plan, float* cells,
@@ -259,6 +259,10 @@ struct SolveAux {
     void* upd_planes; unsigned* upd_maxdiag;      // (upd_maxdiag: 4 words -- largest diagonal entry, two right-hand-side scale slots, smallest diagonal entry)
     int* range_fallbacks;                          // host counter: factorisations whose diagonal spanned > 2^20 and therefore ran their updates in f32 (may be null)
     int upd_f32_only;                              // A/B (SDM_UPDATE_F32=1, read at sdm_create): every trailing update on the f32 matrix-core kernel
+    // round 5: third queue + event for the "mid" rows of a group-end update (the tile rows of the next group the chain does not need
+    // at once); head_split = 0 keeps the whole next group on the chain's queue (A/B: SDM_SOLVE_HEAD_SPLIT=0); lazy = panels per group (0 = 4)
+    hipStream_t mid_stream; hipEvent_t mid_done; int head_split; int lazy;
+    int upd_min_tiles;                             // A/B (SDM_SOLVE_UPD_MIN_TILES): trailing tiles from which the float16 update runs (0 = 40)
 };
 size_t sdm_update_f16_plane_bytes(int rows_max, int ncols);
 void sdm_launch_diag_absmax(const float* G, long long ldg, int F, unsigned* scales, hipStream_t stream);
@@ -281,7 +285,7 @@ struct SolveShard {
     // that one context on one GPU spends the time a rank of a real run spends waiting for the owner's potrf
     int emulate_chain;
 };
-inline size_t sdm_solve_shard_stage_tiles(int ncols, int world) { return (size_t)(world + 1) * 4 * (size_t)(ncols / 128 / world + 1); }
+inline size_t sdm_solve_shard_stage_tiles(int ncols, int world, int lazy = 4) { return (size_t)(world + 1) * (size_t)(lazy > 4 ? lazy : 4) * (size_t)(ncols / 128 / world + 1); }
 // returns 0, or the non-zero result of a failed collective
 inline size_t sdm_backsolve_flag_floats(int Fp) { return (size_t)9 * (size_t)(Fp / 128) + 64; }      // (<= 144 right-hand sides = 9 column tiles: <= 9 chunks)
 int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs, float* R_out,

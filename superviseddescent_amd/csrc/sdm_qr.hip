@@ -42,13 +42,15 @@ __global__ void __launch_bounds__(1024) qr_mirror_kernel(float* __restrict__ G, 
 __global__ void __launch_bounds__(256) qr_colnorm_kernel(const float* __restrict__ G, long long ldg, int F, float* __restrict__ cn,
                                                         int* __restrict__ perm, float* __restrict__ scal)
 {
+    // scal (cleared by the launcher): [0] max |R_kk| so far, [1] tau of the current step, [2] nonzero_pivots + 1 (0 = elimination still
+    // running), [3] bits of the largest initial squared column norm (non-negative floats order like their bit patterns)
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j == 0) { scal[0] = 0.0f; scal[1] = 0.0f; }
     if (j >= F) return;
     float s = 0.0f;
     for (int i = 0; i < F; ++i) { const float a = G[(long long)i * ldg + j]; s += a * a; }
     cn[j] = s;
     perm[j] = j;
+    atomicMax((unsigned*)(scal + 3), __builtin_bit_cast(unsigned, s));
 }
 
 __device__ inline float block_sum_1024(float v, float* red)
@@ -74,6 +76,12 @@ __global__ void __launch_bounds__(1024) qr_pivot_kernel(float* __restrict__ G, l
     __shared__ int besti[16];
     __shared__ int p_sh;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // Eigen stops the elimination at the first step whose largest remaining squared column norm is negligible (below): from then on
+    // no swap, no reflection (tau = 0), and solve() uses the leading nonzero_pivots block only
+    if (scal[2] != 0.0f) {
+        if (t == 0) { tau[k] = 0.0f; scal[1] = 0.0f; }
+        return;
+    }
     // ---- pivot column: largest remaining norm, lowest index among equals ----
     float bv = -1.0f; int bi = k;
     for (int j = k + t; j < F; j += 1024) { const float c = cn[j]; if (c > bv) { bv = c; bi = j; } }
@@ -86,14 +94,19 @@ __global__ void __launch_bounds__(1024) qr_pivot_kernel(float* __restrict__ G, l
     if (t == 0) {
         float b = bestv[0]; int p = besti[0];
         for (int w = 1; w < 16; ++w) if (bestv[w] > b || (bestv[w] == b && besti[w] < p)) { b = bestv[w]; p = besti[w]; }
+        // ColPivHouseholderQR::compute: biggest_col_sq_norm < max_j ||a_j||^2 eps^2 / rows * (rows - k) (Eigen 3.2, "terminate to avoid
+        // generating nan/inf values"), or exactly zero (Eigen 3.3's count of nonzero pivots): nonzero_pivots = k
+        const float thr_helper = __builtin_bit_cast(float, ((const unsigned*)scal)[3]) * 1.1920929e-07f * 1.1920929e-07f / (float)F;
+        if (b < thr_helper * (float)(F - k) || b == 0.0f) { p = -1; scal[2] = (float)(k + 1); tau[k] = 0.0f; scal[1] = 0.0f; }
         p_sh = p;
-        if (p != k) {
+        if (p >= 0 && p != k) {
             const float c = cn[k]; cn[k] = cn[p]; cn[p] = c;
             const int q = perm[k]; perm[k] = perm[p]; perm[p] = q;
         }
     }
     __syncthreads();
     const int p = p_sh;
+    if (p < 0) return;                                   // (the elimination has ended at this step)
     if (p != k)
         for (int i = t; i < F; i += 1024) {
             float* r = G + (long long)i * ldg;
@@ -167,8 +180,9 @@ __global__ void __launch_bounds__(1024) qr_rank_kernel(const float* __restrict__
 {
     __shared__ float red[16];
     const float thr = 1.1920929e-07f * (float)F * scal[0];
+    const int nzp = scal[2] != 0.0f ? (int)scal[2] - 1 : F;      // Eigen's rank() counts among the nonzero pivots
     float n = 0.0f;
-    for (int i = threadIdx.x; i < F; i += 1024) n += fabsf(G[(long long)i * ldg + i]) > thr ? 1.0f : 0.0f;
+    for (int i = threadIdx.x; i < nzp; i += 1024) n += fabsf(G[(long long)i * ldg + i]) > thr ? 1.0f : 0.0f;
     const float s = block_sum_1024(n, red);
     if (threadIdx.x == 0) *rank_out = (int)s;
 }
@@ -176,8 +190,12 @@ __global__ void __launch_bounds__(1024) qr_rank_kernel(const float* __restrict__
 // R x' = Q^T b for CB right-hand-side columns per workgroup (the columns live in LDS), then x[perm[i]] = x'[i]
 template <int CB>
 __global__ void __launch_bounds__(1024) qr_backsolve_kernel(const float* __restrict__ G, long long ldg, int F, int rhs0, int nrhs,
-                                                            const int* __restrict__ perm, float* __restrict__ R_out, long long ldr)
+                                                            const int* __restrict__ perm, float* __restrict__ R_out, long long ldr,
+                                                            const float* __restrict__ scal)
 {
+    // ColPivHouseholderQR::solve (what inverse() at regressors.hpp:293 runs): the leading nonzero_pivots x nonzero_pivots block of R is
+    // solved, the remaining (permuted) unknowns are zero -- a singular system gives a finite regressor, "we continued learning"
+    const int nzp = scal[2] != 0.0f ? (int)scal[2] - 1 : F;
     extern __shared__ float xs[];                      // [CB][F]
     __shared__ float red[CB][16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -186,12 +204,16 @@ __global__ void __launch_bounds__(1024) qr_backsolve_kernel(const float* __restr
 #pragma unroll
         for (int c = 0; c < CB; ++c) xs[c * F + i] = c0 + c < nrhs ? G[(long long)i * ldg + rhs0 + c0 + c] : 0.0f;
     __syncthreads();
-    for (int i = F - 1; i >= 0; --i) {
+    for (int i = nzp + t; i < F; i += 1024)
+#pragma unroll
+        for (int c = 0; c < CB; ++c) xs[c * F + i] = 0.0f;
+    __syncthreads();
+    for (int i = nzp - 1; i >= 0; --i) {
         const float* row = G + (long long)i * ldg;
         float s[CB];
 #pragma unroll
         for (int c = 0; c < CB; ++c) s[c] = 0.0f;
-        for (int j = i + 1 + t; j < F; j += 1024) {
+        for (int j = i + 1 + t; j < nzp; j += 1024) {
             const float r = row[j];
 #pragma unroll
             for (int c = 0; c < CB; ++c) s[c] += r * xs[c * F + j];
@@ -233,6 +255,7 @@ void sdm_launch_colpiv_qr_solve(float* G, long long ldg, int F, int rhs0, int nr
     int* rank_dev = (int*)(scal + 8);
     if (rank_dev_out) *rank_dev_out = rank_dev;
     const unsigned nt = (unsigned)((F + 31) / 32);
+    (void)hipMemsetAsync(scal, 0, 8 * sizeof(float), stream);
     hipLaunchKernelGGL(qr_mirror_kernel, dim3(nt, nt), dim3(1024), 0, stream, G, ldg, F);
     hipLaunchKernelGGL(qr_colnorm_kernel, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, stream, G, ldg, F, cn, perm, scal);
     for (int k = 0; k < F; ++k) {
@@ -255,7 +278,7 @@ void sdm_launch_colpiv_qr_solve(float* G, long long ldg, int F, int rhs0, int nr
         SDM_SET_ATTR((const void*)qr_backsolve_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
     }
     const unsigned nb = (unsigned)((nrhs + cb - 1) / cb);
-    if (cb == 4) hipLaunchKernelGGL(qr_backsolve_kernel<4>, dim3(nb), dim3(1024), col_bytes * 4, stream, G, ldg, F, rhs0, nrhs, perm, R_out, ldr);
-    else if (cb == 2) hipLaunchKernelGGL(qr_backsolve_kernel<2>, dim3(nb), dim3(1024), col_bytes * 2, stream, G, ldg, F, rhs0, nrhs, perm, R_out, ldr);
-    else hipLaunchKernelGGL(qr_backsolve_kernel<1>, dim3(nb), dim3(1024), col_bytes, stream, G, ldg, F, rhs0, nrhs, perm, R_out, ldr);
+    if (cb == 4) hipLaunchKernelGGL(qr_backsolve_kernel<4>, dim3(nb), dim3(1024), col_bytes * 4, stream, G, ldg, F, rhs0, nrhs, perm, R_out, ldr, scal);
+    else if (cb == 2) hipLaunchKernelGGL(qr_backsolve_kernel<2>, dim3(nb), dim3(1024), col_bytes * 2, stream, G, ldg, F, rhs0, nrhs, perm, R_out, ldr, scal);
+    else hipLaunchKernelGGL(qr_backsolve_kernel<1>, dim3(nb), dim3(1024), col_bytes, stream, G, ldg, F, rhs0, nrhs, perm, R_out, ldr, scal);
 }

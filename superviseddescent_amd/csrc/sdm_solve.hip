@@ -362,6 +362,15 @@ __global__ void add_diag_kernel(float* __restrict__ G, long long ldg, int F, int
 #define IB 16                      // inner block
 #define NIB (TILE / IB)
 
+// scripts/ubench/chain_stamps.hip builds this file with SDM_SOLVE_STAMPS: workgroup 0's first thread leaves the shader clock at marked
+// points of the chain kernels (behind barriers: the moment the whole workgroup has arrived).  Nothing in the product build.
+#ifdef SDM_SOLVE_STAMPS
+__device__ unsigned long long g_solve_stamps[64];
+#define SOLVE_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_solve_stamps[(i)] = (unsigned long long)clock64(); } while (0)
+#else
+#define SOLVE_STAMP(i) do { } while (0)
+#endif
+
 typedef float f32x4s __attribute__((ext_vector_type(4)));
 
 __device__ inline void ld16(const float* p, float (&v)[IB])
@@ -415,6 +424,7 @@ potrf_tile_kernel(float* __restrict__ G, long long ldg, int k0, int* __restrict_
     float* Gk = G + (long long)k0 * ldg + k0;
     float* S = scratch + wave * IB * (IB + 1);
     if (t == 0) *badf = 0.0f;
+    SOLVE_STAMP(0);
     // this wave's tiles in C/D layout: acc[rb][e] = T[16 rb + 4 lq + e][16 wave + li], rb <= wave
     f32x4 acc[NIB];
 #pragma unroll
@@ -423,6 +433,7 @@ potrf_tile_kernel(float* __restrict__ G, long long ldg, int k0, int* __restrict_
         for (int e = 0; e < 4; ++e)
             acc[rb][e] = rb <= wave ? Gk[(long long)(IB * rb + 4 * lq + e) * ldg + IB * wave + li] : 0.0f;
     __syncthreads();
+    SOLVE_STAMP(1);
 #pragma unroll
     for (int jb = 0; jb < NIB; ++jb) {
         // (a) the diagonal tile: accumulator layout -> lane i holds column i -> factor -> Dt (for the others) and back
@@ -466,6 +477,7 @@ potrf_tile_kernel(float* __restrict__ G, long long ldg, int k0, int* __restrict_
             for (int e = 0; e < 4; ++e) acc[jb][e] = S[(4 * lq + e) * (IB + 1) + li];
         }
         __syncthreads();
+        SOLVE_STAMP(2 + 2 * jb);
         if (*badf != 0.0f) {
             // (the NaN travels with the tile: the other ranks of a sharded factorisation see the failure in trsm_tile_kernel)
             if (t == 0) { atomicOr(status, 2); Gk[0] = __builtin_nanf(""); }
@@ -502,6 +514,7 @@ potrf_tile_kernel(float* __restrict__ G, long long ldg, int k0, int* __restrict_
             for (int e = 0; e < 4; ++e) acc[jb][e] = S[(4 * lq + e) * (IB + 1) + li];
         }
         __syncthreads();
+        SOLVE_STAMP(3 + 2 * jb);
         // (c) trailing update of this wave's tiles (rb, wave), jb < rb <= wave: T -= P_rb^T P_wave
         if (wave > jb) {
             float bop[4];
@@ -526,6 +539,7 @@ potrf_tile_kernel(float* __restrict__ G, long long ldg, int k0, int* __restrict_
             if (rb <= wave) Gk[(long long)r * ldg + c] = (c >= r) ? acc[rb][e] : 0.0f;
             else Gk[(long long)r * ldg + c] = 0.0f;
         }
+    SOLVE_STAMP(20);
 }
 
 // ---- panel solve: G[k0:k0+128, tj*128 : +128] <- U_kk^-T * (same), on the matrix cores --------------------------------
@@ -562,6 +576,7 @@ trsm_tile_kernel(float* __restrict__ G, long long ldg, int k0, int tile_j0, int 
     if (inverse && t == 0 && !(Gk[0] == Gk[0])) atomicOr(status, 2);      // the owner's potrf reported "not positive definite"
     float* B = inverse ? winv_t : G + (long long)k0 * ldg + j0g;
     const long long ldb = inverse ? TILE : ldg;
+    SOLVE_STAMP(32);
     // this wave's strip in C/D layout: acc[rb][e] = B[16 rb + 4 lq + e][16 wave + li]
     f32x4 acc[NIB];
 #pragma unroll
@@ -578,6 +593,7 @@ trsm_tile_kernel(float* __restrict__ G, long long ldg, int k0, int tile_j0, int 
         if (rb_ >= jb_) *(f32x4s*)(Up + trsm_blk(jb_, rb_) * IB * IB + (r & 15) * IB + (lc & 15)) = *(const f32x4s*)(Gk + (long long)r * ldg + lc);
     }
     __syncthreads();
+    SOLVE_STAMP(33);
     if (t < NIB * IB) {
         // column i of the inverse of the upper triangular block D = U[j0 .. j0+15][j0 .. j0+15]: back substitution for e_i
         const int jb = t >> 4, i = t & 15;
@@ -596,6 +612,7 @@ trsm_tile_kernel(float* __restrict__ G, long long ldg, int k0, int tile_j0, int 
         for (int r = 0; r < IB; ++r) Dinv[(jb * IB + r) * IB + i] = x[r];
     }
     __syncthreads();
+    SOLVE_STAMP(34);
     float* S = scratch + wave * IB * (IB + 1);
 #pragma unroll
     for (int jb = 0; jb < NIB; ++jb) {
@@ -629,10 +646,12 @@ trsm_tile_kernel(float* __restrict__ G, long long ldg, int k0, int tile_j0, int 
                     acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Up[trsm_blk(jb, rb) * IB * IB + (4 * s_ + lq) * IB + li], bop[s_], acc[rb], 0, 0, 0);
         }
     }
+    SOLVE_STAMP(35);
 #pragma unroll
     for (int rb = 0; rb < NIB; ++rb)
 #pragma unroll
         for (int e = 0; e < 4; ++e) B[(long long)(IB * rb + 4 * lq + e) * ldb + IB * wave + li] = acc[rb][e];
+    SOLVE_STAMP(36);
 }
 
 
@@ -984,10 +1003,16 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
     // solve of the others need them); at a group end the ranks all-gather the group's panel rows, which the trailing update
     // reads across ALL columns.  After the last group every rank holds all of U and of the forward-substituted right-hand
     // sides; the back substitution is replicated.
-    const int LAZY = 4;
+    const int LAZY = (aux && aux->lazy > 0) ? aux->lazy : 4;
     const bool overlap = aux && aux->stream && Tf > 2 * LAZY;
+    // Round 5: the head of a group-end update -- the part the chain waits for -- is only the next TWO tile rows (one 256-row super-row
+    // of the float16 kernel); the group's other tile rows ("mid") are updated on a third queue while the chain factors the first
+    // two steps of the next group, and are waited for in front of the first launch that touches them (the row update of the group's
+    // third step).  Every tile is computed by the same kernel with the same operands as before: only the queue changes.
+    const int HEAD = (overlap && aux->mid_stream && aux->mid_done && LAZY > 2 && aux->head_split) ? 2 : LAZY;
+    bool mid_pending = false;
     const bool upd_f32_only = aux && aux->upd_f32_only;      // (A/B: every trailing update on the f32 kernel)
-    const int upd_min_tiles = 40;      // trailing tiles from which the float16-piece update pays (its split pre-pass is per panel group)
+    const int upd_min_tiles = (aux && aux->upd_min_tiles > 0) ? aux->upd_min_tiles : 40;      // trailing tiles from which the float16-piece update pays (its split pre-pass is per panel group)
     bool upd_f16 = aux && aux->upd_planes && aux->upd_maxdiag && !upd_f32_only;
     if (upd_f16) {
         sdm_launch_diag_absmax(G, ldg, F, aux->upd_maxdiag, stream);
@@ -1017,13 +1042,14 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
         const bool mine = !shard || k % W == me;
         // bring tile row k up to date with the panels g0 .. k-1 of its group (owned columns; the owner of column k first:
         // its tile (k, k) is what the chain waits for)
+        if (mid_pending && nb >= HEAD) { (void)hipStreamWaitEvent(stream, aux->mid_done, 0); mid_pending = false; }      // (tile row k was a "mid" row of the last group-end update)
         if (nb && mine) sdm_launch_syrk_tn(G + (long long)g0 * TILE * ldg, ldg, nb * TILE, ncols, G, ldg, -1.0f, 1, k, stream, 1, me, W);
         if (mine || shard->emulate_chain) hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(TILE * PQ), lds_potrf, stream, G, ldg, k0, status);
         if (shard) {
             // tiles (g0 .. k, k): the group's panel rows in column k, then the factored diagonal tile
             if (mine) hipLaunchKernelGGL(tiles_gather_kernel, dim3(1, nb + 1, 1), dim3(256), 0, stream, G, ldg, shard->stage, g0, nb + 1, k, k + 1, 1, 0, 1, 0, -1);
             const int rc = shard->bcast(shard->self, shard->stage, (size_t)(nb + 1) * TILE * TILE, k % W, stream);
-            if (rc) { if (tail_pending) (void)hipStreamWaitEvent(stream, aux->tail_done, 0); return rc; }      // (the caller's stream owns G again)
+            if (rc) { if (tail_pending) (void)hipStreamWaitEvent(stream, aux->tail_done, 0); if (mid_pending) (void)hipStreamWaitEvent(stream, aux->mid_done, 0); return rc; }      // (the caller's stream owns G again)
             if (!mine) {
                 hipLaunchKernelGGL(tiles_gather_kernel, dim3(1, nb + 1, 1), dim3(256), 0, stream, G, ldg, shard->stage, g0, nb + 1, k, k + 1, 1, 0, 1, 1, -1);
                 if (nb) sdm_launch_syrk_tn(G + (long long)g0 * TILE * ldg, ldg, nb * TILE, ncols, G, ldg, -1.0f, 1, k, stream, 1, me, W);
@@ -1047,7 +1073,7 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
                 float* recv = shard->stage + per_rank;
                 hipLaunchKernelGGL(tiles_gather_kernel, dim3(ncmax, nr, 1), dim3(256), 0, stream, G, ldg, send, g0, nr, k + 1, T, W, me, ncmax, 0, -1);
                 const int rc = shard->allgather(shard->self, send, recv, per_rank, stream);
-                if (rc) { if (tail_pending) (void)hipStreamWaitEvent(stream, aux->tail_done, 0); return rc; }
+                if (rc) { if (tail_pending) (void)hipStreamWaitEvent(stream, aux->tail_done, 0); if (mid_pending) (void)hipStreamWaitEvent(stream, aux->mid_done, 0); return rc; }
                 hipLaunchKernelGGL(tiles_gather_kernel, dim3(ncmax, nr, W), dim3(256), 0, stream, G, ldg, recv, g0, nr, k + 1, T, W, 0, ncmax, 1, me);
             }
             // A wide trailing matrix is updated on the float16 matrix cores (sdm_gram_bf16.hip: two pieces per entry; one scale per
@@ -1063,12 +1089,19 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
                                       aux->upd_maxdiag, (k / LAZY) & 1, r0 / 2, tile_rows > 0 ? (r0 + tile_rows) / 2 : (1 << 30), first, W, st);
             };
             if (overlap && tail_pending) (void)hipStreamWaitEvent(stream, aux->tail_done, 0);   // head rows were tail rows of the last group (and its tail read the planes)
+            if (mid_pending) { (void)hipStreamWaitEvent(stream, aux->mid_done, 0); mid_pending = false; }      // (a short last group: the mid update read the planes too)
             if (f16u) sdm_launch_update_split_f16(panels + (long long)(k + 1) * TILE, ldg, prow, ntr * TILE, Tloc * TILE, aux->upd_planes, aux->upd_maxdiag, (k / LAZY) & 1, status, stream);
             if (!overlap) {
                 update(k + 1, 0, stream);
             } else {
                 (void)hipEventRecord(aux->chain_done, stream);
-                update(k + 1, LAZY, stream);
+                update(k + 1, HEAD, stream);
+                if (HEAD < LAZY && k + 1 + HEAD < T) {
+                    (void)hipStreamWaitEvent(aux->mid_stream, aux->chain_done, 0);
+                    update(k + 1 + HEAD, LAZY - HEAD, aux->mid_stream);
+                    (void)hipEventRecord(aux->mid_done, aux->mid_stream);
+                    mid_pending = true;
+                }
                 if (k + 1 + LAZY < T) {
                     (void)hipStreamWaitEvent(aux->stream, aux->chain_done, 0);
                     update(k + 1 + LAZY, 0, aux->stream);
@@ -1079,6 +1112,7 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
         }
     }
     if (tail_pending) (void)hipStreamWaitEvent(stream, aux->tail_done, 0);
+    if (mid_pending) (void)hipStreamWaitEvent(stream, aux->mid_done, 0);
     int nj = nrhs / 16;   // nrhs is a multiple of 16, <= 144 (sharded: narrowed to this rank's column tiles below)
     {
         // one persistent launch: Tf workgroups x chunks of <= 5 column tiles; flags (one int per tile row and chunk) behind the

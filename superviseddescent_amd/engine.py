@@ -285,6 +285,12 @@ class Context:
         check(self._lib.sdm_set_allreduce(self._h, cb, None, world_size))
         self._keep_allreduce = cb       # (replaces the previous thunk, which the library no longer references)
 
+    def set_allreduce_rccl(self, comm, world_size: int = 1, allreduce_fn=None):
+        """The exchange through RCCL called by the library itself on its own stream (include/sdm.h: sdm_set_allreduce_rccl);
+        ``comm`` = ncclComm_t of this rank (``parallel.RcclCommunicator``), ``None`` uninstalls."""
+        check(self._lib.sdm_set_allreduce_rccl(self._h, comm, allreduce_fn, world_size))
+        self._keep_allreduce = None
+
     def allreduce_gram_rhs(self):
         check(self._lib.sdm_allreduce_gram_rhs(self._h))
 
@@ -643,41 +649,51 @@ class SupervisedDescentOptimiser:
     def train(self, parameters, initialisations, templates, projection: HogTransform,
               on_training_epoch_callback: Optional[Callable[[np.ndarray], None]] = None,
               allreduce=None, world_size: int = 1, n_train_global: int = 0, rank: Optional[int] = None,
-              solve_collectives=None, reduce_scatter=None):
+              solve_collectives=None, reduce_scatter=None, rccl=None, rccl_shard_solve: bool = False):
         """``rank`` + ``solve_collectives = (bcast, allgather)`` (parallel.make_torch_solve_collectives) additionally shard the
         factorisation of the summed system over the ranks (Context.set_solve_sharding); without them every rank solves it.
         ``reduce_scatter`` (parallel.make_torch_reduce_scatter) then replaces the all-reduce of the whole Gram matrix by a
-        reduce-scatter of the owned tile columns + a small all-reduce (Context.set_reduce_scatter)."""
+        reduce-scatter of the owned tile columns + a small all-reduce (Context.set_reduce_scatter).
+        ``rccl`` (a ``parallel.RcclCommunicator``) takes the place of all three callbacks: the library then issues the collectives
+        itself through RCCL on its own streams (``rccl_shard_solve``: sharded factorisation + reduce-scatter exchange); the
+        callbacks remain for backends without RCCL (the gloo tests)."""
         x0 = np.asarray(initialisations, np.float32)
         self._bind(projection, x0.shape[0])
         c = self.ctx
         c.set_templates(templates)                                           # superviseddescent.hpp:195-197
         c.set_x(x0)
         c.set_targets(np.asarray(parameters, np.float32))
-        c.set_allreduce(allreduce, world_size)
-        if hasattr(c, "set_solve_sharding"):
-            if solve_collectives is not None and rank is not None:
-                c.set_solve_sharding(rank, world_size, *solve_collectives)
-            else:
-                c.set_solve_sharding(0, 0, None, None)
-        if hasattr(c, "set_reduce_scatter"):
-            c.set_reduce_scatter(reduce_scatter if (solve_collectives is not None and rank is not None) else None)
+        if rccl is not None:
+            if allreduce is not None or solve_collectives is not None or reduce_scatter is not None:
+                raise ValueError("train: pass either the RCCL communicator or the collective callbacks, not both")
+            rccl.install(c, shard_solve=rccl_shard_solve, reduce_scatter=rccl_shard_solve)
+        else:
+            c.set_allreduce(allreduce, world_size)
+            if hasattr(c, "set_solve_sharding"):
+                if solve_collectives is not None and rank is not None:
+                    c.set_solve_sharding(rank, world_size, *solve_collectives)
+                else:
+                    c.set_solve_sharding(0, 0, None, None)
+            if hasattr(c, "set_reduce_scatter"):
+                c.set_reduce_scatter(reduce_scatter if (solve_collectives is not None and rank is not None) else None)
         n_glob = n_train_global or c.N
         try:
             return self._train_levels(c, n_glob, on_training_epoch_callback)
         finally:
             if hasattr(c, "set_solver"):
                 c.set_solver(0)                                              # (the context may be shared: leave the default solver behind)
+            if rccl is not None:
+                rccl.uninstall(c)                                            # (the communicator belongs to the caller)
 
     def _train_levels(self, c, n_glob, on_training_epoch_callback):
         for level, reg in enumerate(self.regressors):
+            kind = getattr(reg.solver, "kind", 0)
+            if hasattr(c, "set_solver"):
+                c.set_solver(kind)                                           # LinearRegressor<Solver>, regressors.hpp:318 (before the Gram launch: it picks the exchange form by the solver)
             c.hog_features(level)                                            # superviseddescent.hpp:173-189
             c.gram_rhs(level)                                                # :199-205 + regressors.hpp:208,225
             c.allreduce_gram_rhs()
             r = reg.regulariser
-            kind = getattr(reg.solver, "kind", 0)
-            if hasattr(c, "set_solver"):
-                c.set_solver(kind)                                           # LinearRegressor<Solver>, regressors.hpp:318
             reg.x, reg.last_lambda = c.solve(level, r.regularisation_type, r.param, r.regularise_last_row,
                                              n_glob)                         # :207
             if kind == 1 and hasattr(c, "last_rank"):

@@ -13,6 +13,7 @@ The C-ABI exposes the exchange as a callback (``sdm_set_allreduce``); this modul
 """
 from __future__ import annotations
 
+import ctypes
 from typing import Callable, Tuple
 
 import numpy as np
@@ -100,6 +101,74 @@ def make_torch_reduce_scatter(device_index: int):
         return 0
 
     return reduce_scatter
+
+
+class RcclCommunicator:
+    """An ``ncclComm_t`` of this process's own -- one rank per process / GPU -- for the library-native exchange: the engine then
+    calls ``ncclAllReduce`` / ``ncclReduceScatter`` / ``ncclBroadcast`` / ``ncclAllGather`` itself, on its own HIP streams
+    (``sdm_set_allreduce_rccl``, ``sdm_set_reduce_scatter_rccl``, ``sdm_set_solve_sharding_rccl``; include/sdm.h), with no Python
+    between two kernels of a training level.  The communicator is created with ``ncclCommInitRank`` from a unique id that rank 0
+    draws and ``torch.distributed`` (any backend) carries to the other ranks; RCCL itself is the copy torch already maps into
+    the process (exactly one RCCL per process), else ROCm's.  The device of this rank must be current
+    (``torch.cuda.set_device``) when the object is built.  The reference has no collective (superviseddescent.hpp:170-218 is
+    single-process)."""
+
+    class _UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+
+    def __init__(self, rank: int, world_size: int):
+        import torch
+        import torch.distributed as dist
+        self.rank, self.world_size = int(rank), int(world_size)
+        self._rccl = self._load()
+        uid = self._UniqueId()
+        if self.rank == 0 and self._rccl.ncclGetUniqueId(ctypes.byref(uid)) != 0:
+            raise RuntimeError("ncclGetUniqueId failed")
+        if self.world_size > 1:
+            box = [bytes(uid.internal) if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            ctypes.memmove(ctypes.byref(uid), box[0], 128)
+        torch.cuda.current_stream().synchronize()
+        self._rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, self._UniqueId, ctypes.c_int]
+        comm = ctypes.c_void_p()
+        rc = self._rccl.ncclCommInitRank(ctypes.byref(comm), self.world_size, uid, self.rank)
+        if rc != 0 or not comm.value:
+            raise RuntimeError("ncclCommInitRank failed with status %d" % rc)
+        self.comm = comm
+        self._fn = {n: ctypes.cast(getattr(self._rccl, n), ctypes.c_void_p)
+                    for n in ("ncclAllReduce", "ncclReduceScatter", "ncclBroadcast", "ncclAllGather")}
+
+    @staticmethod
+    def _load():
+        import importlib.util
+        import os
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.origin:
+            cand = os.path.join(os.path.dirname(spec.origin), "lib", "librccl.so")
+            if os.path.exists(cand):
+                return ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        return ctypes.CDLL("/opt/rocm/lib/librccl.so", mode=ctypes.RTLD_GLOBAL)
+
+    def install(self, ctx, shard_solve: bool = False, reduce_scatter: bool = False):
+        """Registers the communicator with a ``Context``: the Gram / RHS exchange always; the sharded factorisation and the
+        reduce-scatter form of the exchange on request (the latter only pays together with the former)."""
+        ctx.set_allreduce_rccl(self.comm, self.world_size, self._fn["ncclAllReduce"])
+        if shard_solve:
+            ctx.set_solve_sharding_rccl(self.comm, self.rank, self.world_size, self._fn["ncclBroadcast"], self._fn["ncclAllGather"])
+        else:
+            ctx.set_solve_sharding_rccl(None)
+        ctx.set_reduce_scatter_rccl(bool(shard_solve and reduce_scatter), self._fn["ncclReduceScatter"])
+
+    @staticmethod
+    def uninstall(ctx):
+        ctx.set_reduce_scatter_rccl(False)
+        ctx.set_solve_sharding_rccl(None)
+        ctx.set_allreduce_rccl(None, 1)
+
+    def destroy(self):
+        if getattr(self, "comm", None) is not None and self.comm.value:
+            self._rccl.ncclCommDestroy(self.comm)
+            self.comm = ctypes.c_void_p()
 
 
 def make_host_allreduce() -> Callable[[np.ndarray], None]:

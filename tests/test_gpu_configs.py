@@ -60,8 +60,9 @@ def test_training_at_baseline_configuration(built, name):
     images, boxes, gt = synth.make_faces(n_img, seed=seed)
     x_star, x0, idx = synth.make_samples(boxes, gt, ids, n_perturb=per - 1, seed=seed + 1)
     digest = hashlib.sha1(images.tobytes() + x0.tobytes() + x_star.tobytes()).digest()
-    if digest != FIX[name + "_sha1"].tobytes():
-        pytest.skip("the synthetic data of this machine differs from the fixture's (numpy/BLAS build): rerun scripts/parity_configs.py")
+    # (a FAILURE, not a skip: a numpy upgrade that changes the generator's stream must not silently drop the free-running parity of
+    #  BASELINE configs 3 / 5 -- VERDICT r04 item 7; the remedy is scripts/parity_configs.py + scripts/make_config_fixtures.py)
+    assert digest == FIX[name + "_sha1"].tobytes(), "the synthetic data of this machine differs from the fixture's (numpy build): rerun scripts/parity_configs.py"
     sdo = SupervisedDescentOptimiser([LinearRegressor(Regulariser(*reg)) for _ in params])
     hog = HogTransform(images, [HoGParam(*p) for p in params], ids, ibug.RIGHT_EYE_IDS, ibug.LEFT_EYE_IDS, idx)
     levels = []
@@ -163,7 +164,8 @@ def test_rcr68_detect_shard_matches_oracle(built):
     got = sdo.test(x0, None, HogTransform(images, [HoGParam(*p) for p in params], ids, ibug.RIGHT_EYE_IDS, ibug.LEFT_EYE_IDS, None))
     oregs = []
     for r in sdo.regressors:
-        o = orc.LinearRegressor()
+        o = orc.LinearRegressor()           # (predict accumulates in double as cv::gemm does: the oracle's default since round 5)
+        assert o.accumulate_double
         o.x = r.x
         oregs.append(o)
     osdo = orc.SupervisedDescentOptimiser(oregs, orc.InterEyeDistanceNormalisation(re, le))
@@ -172,4 +174,6 @@ def test_rcr68_detect_shard_matches_oracle(built):
     per_face = np.linalg.norm((got - want).astype(np.float64), axis=1) / np.linalg.norm(want.astype(np.float64), axis=1)
     print("RCR-68 shard of 8 192: rel-L2 %.2e, worst face %.2e, faces above 1e-4: %d" % (rel_l2(got, want), per_face.max(), int((per_face > 1e-4).sum())))
     assert rel_l2(got, want) < 1e-4
-    assert np.median(per_face) < 2e-7 and (per_face > 1e-4).sum() <= 16      # (a cvRound on a knife edge sends a face down the other, equally valid path)
+    # (a cvRound on a knife edge sends a face down the other, equally valid path; against the float32-accumulating oracle of round 4
+    #  this shard had 3 such faces per 512 -- most of them the CHECKER's own rounding: the bound is now 4 per 8 192)
+    assert np.median(per_face) < 2e-7 and (per_face > 1e-4).sum() <= 4

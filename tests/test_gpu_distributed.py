@@ -103,3 +103,42 @@ def test_bench_with_two_real_processes(built):
     nl = out["rcr68_train"]["nlsr_per_level_rank0"]
     assert len(nl) == 4 and all(b < a for a, b in zip(nl, nl[1:]))              # the cascade trained by two ranks converges
     assert out["rcr68_detect_shard"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_relaunches_itself_for_several_gpus(built):
+    """`python bench.py --gpus 2` with NO launcher (no RANK / WORLD_SIZE in the environment): the script replaces itself by
+    `python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2 ...` and the line says n_gpus = 2 -- it used to run one
+    rank silently and print n_gpus = 1.  gloo, the two ranks sharing the GPU of the test box."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", SDM_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "256",
+                        "--train-rows", "800", "--rcr68-shard", "0", "--no-cpu"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["train"]["sec_per_cascade"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_collectives_are_issued_by_the_library(built):
+    """Under torch.distributed.run on the nccl backend bench.py's collectives go through the library's own RCCL calls
+    (parallel.RcclCommunicator -> sdm_set_allreduce_rccl / sdm_set_reduce_scatter_rccl / sdm_set_solve_sharding_rccl), not through
+    Python callbacks; SDM_BENCH_COLLECTIVES=torch keeps the callback path for an A/B.  One rank per visible GPU (the test box has
+    one: every collective is issued, the sums are identities) -- both paths must train the same cascade."""
+    import json
+    import torch
+    n = min(torch.cuda.device_count(), 2)
+    common = ("--gpus", str(n), "--steps", "2", "--warmup", "1", "--batch", "256", "--train-rows", "800", "--rcr68-shard", "256", "--no-cpu")
+    outs = {}
+    for how in ("rccl", "torch"):
+        r = _torchrun(n, os.path.join(ROOT, "bench.py"), *common, SDM_BENCH_COLLECTIVES=how, SDM_BENCH_SHARD_SOLVE="1")
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        outs[how] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert "called by the library" in outs["rccl"]["train"]["collective"] and "callbacks" in outs["torch"]["train"]["collective"]
+    assert outs["rccl"]["train"]["solve"].startswith("sharded")
+    for leg in ("train", "rcr68_train"):
+        a, b = outs["rccl"][leg]["nlsr_per_level_rank0"], outs["torch"][leg]["nlsr_per_level_rank0"]
+        assert len(a) == 4 and a == pytest.approx(b, rel=1e-5)

@@ -61,8 +61,13 @@ def test_qr_solver_reports_a_singular_system(qctx):
     b = rng.standard_normal((200, 3)).astype(np.float32)
     R, _ = qctx.solve_normal_equations(A, b, 0, 0.0, True)                  # "we continued learning" (regressors.hpp:292): no error
     osolver = orc.ColPivHouseholderQRSolver()
-    osolver.solve(A, b, orc.Regulariser(0, 0.0, True))
+    x_orc = osolver.solve(A, b, orc.Regulariser(0, 0.0, True))
     assert qctx.last_rank() == (osolver.rank, 40) and osolver.rank == 38
+    # Eigen's solve() / inverse() (regressors.hpp:293) stop at the last nonzero pivot and return zero rows for the rest: the empty
+    # column's coefficient is exactly zero and the regressor is finite, on the device as in the restatement
+    assert osolver.nonzero_pivots == 39
+    assert np.isfinite(R).all() and np.isfinite(x_orc).all()
+    assert (R[30] == 0).all() and (x_orc[30] == 0).all()
     # with the reference's remedy ("Increase lambda") the system is invertible again
     R, _ = qctx.solve_normal_equations(A, b, 0, 1.0, True)
     assert qctx.last_rank() == (40, 40) and np.isfinite(R).all()
@@ -75,7 +80,7 @@ def test_qr_pivot_order_is_the_oracles(qctx):
     F = 48
     A = rng.standard_normal((300, F)).astype(np.float32) * (1.0 + np.arange(F, dtype=np.float32))[None, :]
     G = (A.T @ A).astype(np.float32)
-    qr, tau, perm, rank = orc.col_piv_householder_qr_f32(G + np.float32(0.5) * np.eye(F, dtype=np.float32))
+    qr, tau, perm, rank, _nzp = orc.col_piv_householder_qr_f32(G + np.float32(0.5) * np.eye(F, dtype=np.float32))
     assert rank == F and not np.array_equal(perm, np.arange(F))
     b = rng.standard_normal((300, 4)).astype(np.float32)
     R, _ = qctx.solve_normal_equations(A, b, 0, 0.5, True)

@@ -239,7 +239,8 @@ def test_col_piv_qr_factorisation_properties():
     n = 40
     B = rng.standard_normal((120, n)).astype(f32) * (1.0 + np.arange(n, dtype=f32))
     A = (B.T @ B).astype(f32)
-    qr, tau, perm, rank = o.col_piv_householder_qr_f32(A)
+    qr, tau, perm, rank, nzp = o.col_piv_householder_qr_f32(A)
+    assert nzp == n
     assert rank == n
     d = np.abs(np.diagonal(qr))
     assert (d[:-1] >= d[1:] * (1 - 1e-5)).all()
@@ -250,6 +251,16 @@ def test_col_piv_qr_factorisation_properties():
     assert np.abs(Q @ np.triu(qr).astype(np.float64) - A[:, perm]).max() / np.abs(A).max() < 5e-6
     A2 = A.copy(); A2[:, 9] = A2[:, 3]; A2[9, :] = A2[3, :]
     assert o.col_piv_householder_qr_f32(A2)[3] == n - 1
+    # an exactly empty column ends the elimination (Eigen's nonzero_pivots); solve() then returns a finite solution whose
+    # coefficient for that column is zero -- "we continued learning", regressors.hpp:291
+    A3 = A.copy(); A3[:, 5] = 0.0; A3[5, :] = 0.0
+    qr3, tau3, perm3, rank3, nzp3 = o.col_piv_householder_qr_f32(A3)
+    assert nzp3 == n - 1 and rank3 == n - 1 and perm3[n - 1] == 5
+    x3 = o._qr_solve_f32(qr3, tau3, perm3, np.eye(n, dtype=f32), nzp3)
+    assert np.isfinite(x3).all() and (x3[5] == 0).all()
+    keep = np.delete(np.arange(n), 5)
+    inv_sub = np.linalg.inv(A3[np.ix_(keep, keep)].astype(np.float64))
+    assert np.abs(x3[np.ix_(keep, keep)] - inv_sub).max() / np.abs(inv_sub).max() < 5e-3
     data = rng.standard_normal((200, 12)).astype(f32); y = rng.standard_normal((200, 3)).astype(f32)
     x = o.ColPivHouseholderQRSolver().solve(data, y, o.Regulariser(o.Regulariser.MANUAL, 0.5, True))
     G = data.astype(np.float64).T @ data.astype(np.float64) + 0.5 * np.eye(12)
