@@ -71,7 +71,7 @@ struct sdm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    SolveAux solve_aux = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0};   // second queue of the Cholesky look-ahead (+ the scratch of its float16 updates, set per solve)
+    SolveAux solve_aux = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0};   // second queue of the Cholesky look-ahead (+ the scratch of its float16 updates, set per solve)
     DevBuf<unsigned char> upd_planes;    // one panel group as float16 planes (sdm_update_f16_plane_bytes)
     DevBuf<unsigned> upd_maxdiag;
 
@@ -97,13 +97,6 @@ struct sdm_ctx {
     bool fuse_apply = true;         // SDM_DETECT_UNFUSED=1: sdm_detect_batch through the feature matrix + apply GEMM (A/B)
     bool fuse_wide = false;         // sdm_debug_set_detect_path(fused = 2): fuse also when 2L > 64 (tests of the wide launch)
     bool packing = true;            // sdm_debug_set_hog_packing / SDM_HOG_NO_PACK=1: run the one-patch-per-wave kernel instead
-    // Round 5 experiment (SDM_DETECT_HALVES=1|2): sdm_detect_batch runs the batch as two halves on two queues of
-    // its own, each half its own chain of cascade levels, the second half started one pixel kernel behind the first -- so that the
-    // short descriptor / product / update launches of one half and the ramp-up and tail of its pixel kernel run beside the other
-    // half's pixel kernel.  2: the descriptor / update launches on two further queues of the highest priority.
-    int env_halves = 0;
-    hipStream_t half_stream[4] = {nullptr, nullptr, nullptr, nullptr};      // pixel queue of half 0 / 1, descriptor queue of half 0 / 1
-    hipEvent_t half_ev[8] = {};                                             // per half: pixel done, level done; + fork, join (2 x 2 + 2 + spare)
     // A/B switches of the environment, all read ONCE in sdm_create (no getenv inside a launch path)
     bool env_fuse_wide = false;     // SDM_DETECT_FUSE_WIDE=1: fuse descriptor + apply also when 2L > 64
     bool env_apply_f32 = false;     // SDM_APPLY_F32=1: sdm_apply always on the f32 matrix-core kernel
@@ -447,7 +440,10 @@ bool fused_ok(const sdm_ctx* c, int level)
 // A cascade level of detect, fused: cells -> (descriptors x regressor slices) -> landmark update; the feature matrix is not
 // written.  (Measured and dropped: the batch as two blocks of rows on two queues, so that the short descriptor / update launches of
 // one block overlap the pixel kernel of the other -- 1.352 against 1.354 ms: the pixel kernel's workgroups hold every register
-// and LDS slot of a CU, the 51 KB descriptor workgroups of the other queue are admitted only when it drains.)
+// and LDS slot of a CU, the 51 KB descriptor workgroups of the other queue are admitted only when it drains.  Round 5 repeated it
+// as VERDICT r04 item 4b asks -- two half batches, each its own chain of levels on its own queue, the second started one pixel
+// kernel behind the first, optionally with the descriptor / update launches on highest-priority queues: 1.72 / 1.86 ms against
+// 1.12 ms per 4 096 faces (profiles/r05_experiments.txt): two pixel kernels sharing the chip are slower than one after the other.)
 int detect_level_fused(sdm_ctx* c, int l)
 {
     { const int rci = hog_checks(c, l); if (rci) return rci; }
@@ -472,62 +468,6 @@ int detect_level_fused(sdm_ctx* c, int l)
     c->cur ^= 1;
     c->feat_level = -1;          // (the feature rows were not produced)
     c->have_patch_idx = true;    // (this level's patch half-widths and centres)
-    return SDM_OK;
-}
-
-// The whole cascade with the batch as two halves on two queues (SDM_DETECT_HALVES; see sdm_ctx::env_halves).  Same kernels, same
-// per-sample arithmetic as detect_level_fused level by level: every buffer is indexed by sample, a half is a pointer offset.
-int detect_cascade_halves(sdm_ctx* c)
-{
-    const int NL = (int)c->levels.size(), Mp = Mp_of(c->M), N = c->N;
-    int rc;
-    size_t cells_max = 0;
-    for (int q = 0; q < NL; ++q) { const size_t n = sdm_cells_floats(c->levels[q], N, c->L); if (n > cells_max) cells_max = n; }
-    if ((rc = c->cells.ensure(cells_max)) || (rc = c->partial.ensure((size_t)c->L * N * Mp))) return rc;
-    const int n0[2] = {0, N / 2}, nh[2] = {N / 2, N - N / 2};
-    hipEvent_t fork = c->half_ev[4], join0 = c->half_ev[5], join1 = c->half_ev[6], stagger = c->half_ev[7];
-    HIP_TRY(hipEventRecord(fork, c->stream));
-    const bool prio = c->env_halves >= 2;
-    int cur = c->cur;
-    for (int hf = 0; hf < 2; ++hf) {
-        HIP_TRY(hipStreamWaitEvent(c->half_stream[hf], fork, 0));
-        if (prio) HIP_TRY(hipStreamWaitEvent(c->half_stream[2 + hf], fork, 0));
-    }
-    for (int l = 0; l < NL; ++l) {
-        const HogLevelDev& lv = c->levels[l];
-        const size_t cells_per_sample = (sdm_cells_floats(lv, N, c->L) - 4) / (size_t)N;
-        for (int hf = 0; hf < 2; ++hf) {
-            if (nh[hf] <= 0) continue;
-            hipStream_t sp = c->half_stream[hf], sd = prio ? c->half_stream[2 + hf] : sp;
-            hipEvent_t pixel_done = c->half_ev[2 * hf], level_done = c->half_ev[2 * hf + 1];
-            ImageSetDev is = image_set(c);
-            const int* idx = c->idx_identity ? nullptr : c->img_idx.p + n0[hf];
-            if (c->idx_identity) { is.offset += n0[hf]; is.w += n0[hf]; is.h += n0[hf]; is.stride += n0[hf]; is.n_images -= n0[hf]; }
-            const float* xin = c->x[cur].p + (size_t)n0[hf] * c->M;
-            float* xout = c->x[cur ^ 1].p + (size_t)n0[hf] * c->M;
-            float* cells = c->cells.p + (size_t)n0[hf] * cells_per_sample;
-            float* partial = c->partial.p + (size_t)c->L * n0[hf] * Mp;
-            if (l == 0 && hf == 1) HIP_TRY(hipStreamWaitEvent(sp, stagger, 0));      // the second half starts one pixel kernel behind the first
-            if (prio && l > 0) HIP_TRY(hipStreamWaitEvent(sp, level_done, 0));
-            sdm_launch_hog_cells(is, idx, xin, nh[hf], c->L, c->eyes, lv, c->plans[l].dev, cells, c->patch_idx.p + (size_t)n0[hf] * (1 + 2 * c->L),
-                                 c->status.p, sp);
-            if (l == 0 && hf == 0) HIP_TRY(hipEventRecord(stagger, sp));
-            if (prio) { HIP_TRY(hipEventRecord(pixel_done, sp)); HIP_TRY(hipStreamWaitEvent(sd, pixel_done, 0)); }
-            sdm_launch_desc_apply(lv, cells, c->plans[l].cut.p, nh[hf], c->L, c->M, c->Rd[l].p, c->Rmax.p + (size_t)l * Mp, c->Rt[l].p, c->ldf,
-                                  partial, sd);
-            sdm_launch_apply_reduce(partial, c->L, nh[hf], c->M, xin, xout, c->L, c->eyes, sd);
-            if (prio) HIP_TRY(hipEventRecord(level_done, sd));
-        }
-        cur ^= 1;
-    }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(join0, prio ? c->half_stream[2] : c->half_stream[0]));
-    HIP_TRY(hipEventRecord(join1, prio ? c->half_stream[3] : c->half_stream[1]));
-    HIP_TRY(hipStreamWaitEvent(c->stream, join0, 0));
-    HIP_TRY(hipStreamWaitEvent(c->stream, join1, 0));
-    c->cur = cur;
-    c->feat_level = -1;
-    c->have_patch_idx = true;
     return SDM_OK;
 }
 
@@ -580,25 +520,13 @@ sdm_ctx* sdm_create(int device)
     // at F = 8801; moving the chain to a highest-priority queue of its own on top of that: 7.3, not kept)
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    int mid_prio = 0;
-    { const char* v = getenv("SDM_SOLVE_MID_PRIO"); if (v && v[0] == 'l') mid_prio = prio_least; else if (v && v[0] == 'h') mid_prio = prio_greatest; }
     if (hipStreamCreateWithPriority(&c->solve_aux.stream, hipStreamNonBlocking, prio_least) != hipSuccess ||
         hipEventCreateWithFlags(&c->solve_aux.chain_done, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->solve_aux.tail_done, hipEventDisableTiming) != hipSuccess ||
-        hipStreamCreateWithPriority(&c->solve_aux.mid_stream, hipStreamNonBlocking, mid_prio) != hipSuccess ||
-        hipEventCreateWithFlags(&c->solve_aux.mid_done, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->solve_aux.tail_done, hipEventDisableTiming) != hipSuccess) {
         fail(SDM_ERR_HIP, "hipStreamCreate failed"); delete c; return nullptr;
     }
     if (c->status.ensure(1, true, c->stream) || c->lambda_dev.ensure(1, true, c->stream)) { delete c; return nullptr; }
     { const char* np = getenv("SDM_HOG_NO_PACK"); c->packing = !(np && np[0] == '1'); }
-    { const char* v = getenv("SDM_DETECT_HALVES"); c->env_halves = v ? atoi(v) : 0; }
-    if (c->env_halves > 0) {
-        bool ok = true;
-        for (int q = 0; q < 4 && ok; ++q)
-            ok = hipStreamCreateWithPriority(&c->half_stream[q], hipStreamNonBlocking, q < 2 ? 0 : prio_greatest) == hipSuccess;
-        for (int q = 0; q < 8 && ok; ++q) ok = hipEventCreateWithFlags(&c->half_ev[q], hipEventDisableTiming) == hipSuccess;
-        if (!ok) { fail(SDM_ERR_HIP, "hipStreamCreate failed"); delete c; return nullptr; }
-    }
     { const char* np = getenv("SDM_HOG_SPLIT_STORE"); c->split_store = np && np[0] == '1'; }
     { const char* np = getenv("SDM_DETECT_UNFUSED"); c->fuse_apply = !(np && np[0] == '1'); }
     auto env_on = [](const char* name) { const char* v = getenv(name); return v && v[0] == '1'; };
@@ -611,9 +539,8 @@ sdm_ctx* sdm_create(int device)
     c->env_gram_f32 = env_on("SDM_GRAM_F32");
     c->env_gram_bf16 = env_on("SDM_GRAM_BF16X3");
     c->solve_aux.upd_f32_only = env_on("SDM_UPDATE_F32") ? 1 : 0;
-    { const char* v = getenv("SDM_SOLVE_HEAD_SPLIT"); c->solve_aux.head_split = (v && v[0] == '1'); }
+    c->solve_aux.chain_v1 = env_on("SDM_SOLVE_CHAIN_V1") ? 1 : 0;
     { const char* v = getenv("SDM_SOLVE_UPD_MIN_TILES"); c->solve_aux.upd_min_tiles = v ? atoi(v) : 0; }
-    { const char* v = getenv("SDM_SOLVE_LAZY"); const int lz = v ? atoi(v) : 0; c->solve_aux.lazy = (lz == 2 || lz == 4 || lz == 6 || lz == 8) ? lz : 0; }
     { const char* v = getenv("SDM_SOLVE_SHARD_EMULATE"); c->env_shard_emulate = v ? atoi(v) : 0; }
     return c;
 }
@@ -629,12 +556,8 @@ void sdm_destroy(sdm_ctx* c)
         for (int b = 0; b < sdm_ctx::XBLOCKS_MAX; ++b) if (c->gram_ev[b]) e = hipEventDestroy(c->gram_ev[b]);
         if (c->gram_xdone) e = hipEventDestroy(c->gram_xdone);
         e = hipStreamDestroy(c->solve_aux.stream);
-        if (c->solve_aux.mid_stream) { e = hipStreamSynchronize(c->solve_aux.mid_stream); e = hipStreamDestroy(c->solve_aux.mid_stream); }
-        if (c->solve_aux.mid_done) e = hipEventDestroy(c->solve_aux.mid_done);
     }
     drain_timing(c);
-    for (int q = 0; q < 4; ++q) if (c->half_stream[q]) { e = hipStreamSynchronize(c->half_stream[q]); e = hipStreamDestroy(c->half_stream[q]); }
-    for (int q = 0; q < 8; ++q) if (c->half_ev[q]) e = hipEventDestroy(c->half_ev[q]);
     for (auto ev : c->pool) { e = hipEventDestroy(ev); }
     c->img_owned.release(); c->img_off.release(); c->img_w.release(); c->img_h.release();
     c->img_stride.release(); c->img_idx.release(); c->x[0].release(); c->x[1].release();
@@ -1129,10 +1052,6 @@ int sdm_detect_batch(sdm_ctx* c, float* x_host)
     HIP_TRY(hipSetDevice(c->device));
     c->chain_timers = true; c->ev_fresh = false;
     int rc = SDM_OK;
-    bool halves = c->env_halves > 0 && c->N >= 512 && !c->timing;
-    for (int l = 0; l < (int)c->levels.size() && halves; ++l) halves = fused_ok(c, l);
-    if (halves) { rc = hog_checks(c, 0); if (!rc) rc = detect_cascade_halves(c); }
-    else
     for (int l = 0; l < (int)c->levels.size() && !rc; ++l) rc = detect_level(c, l);
     c->chain_timers = false; c->ev_fresh = false;
     if (rc) return rc;
@@ -1351,7 +1270,7 @@ int sdm_set_solve_sharding_rccl(sdm_ctx* c, void* nccl_comm, int rank, int world
 int solve_update_scratch(sdm_ctx* c, int ncols)
 {
     int rc;
-    if ((rc = c->upd_planes.ensure(sdm_update_f16_plane_bytes(128 * (c->solve_aux.lazy > 0 ? c->solve_aux.lazy : 4), ncols))) || (rc = c->upd_maxdiag.ensure(4))) return rc;
+    if ((rc = c->upd_planes.ensure(sdm_update_f16_plane_bytes(512, ncols))) || (rc = c->upd_maxdiag.ensure(4))) return rc;
     c->solve_aux.upd_planes = c->upd_planes.p;
     c->solve_aux.upd_maxdiag = c->upd_maxdiag.p;
     c->solve_aux.range_fallbacks = &c->update_range_fallbacks;
@@ -1527,7 +1446,7 @@ int sdm_solve(sdm_ctx* c, int level, int reg_type, float reg_param, int regulari
             // capacity, which a reused context may hold larger than its peers (one rank would then take the all-gather of
             // the sharded back substitution and the others not).  Sized so that the sharded back substitution always fits.
             const size_t nj_rhs = (size_t)(Mp / 16), bs_per = (nj_rhs + c->shard_world - 1) / c->shard_world;
-            size_t stage_need = sdm_solve_shard_stage_tiles(ncols, c->shard_world, c->solve_aux.lazy) * 128 * 128;
+            size_t stage_need = sdm_solve_shard_stage_tiles(ncols, c->shard_world) * 128 * 128;
             const size_t bs_need = (size_t)(c->shard_world + 1) * (size_t)Fp * 16 * bs_per;
             if (bs_need > stage_need) stage_need = bs_need;
             if ((rc = c->shard_stage.ensure(stage_need))) return rc;

@@ -1279,6 +1279,10 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
     // fold stores its cells to HBM -- ONE pass (HP_SPLIT_PASSES): uniform, short waves whose number is a finer multiple of the
     // 6 144 wave slots of the chip (RCR-22 level 1 at 4 096 faces: 20 480 waves of four or two passes = 3.3 rounds of slots
     // became 73 728 waves of one pass = 12.0 rounds)
+    // (Round 5, VERDICT r04 item 4a: a wave taking k consecutive passes of its sample -- inter-eye distance, half-width, taps, row
+    //  table and the cleared column rows set up once per k passes -- measured 1.141 / 1.158 / 1.165 / 1.169 ms per 4 096 faces for
+    //  k = 1 / 2 / 3 / 4, scripts/r5_detect_env_ab.py, profiles/r05_experiments.txt: the finer balance of one pass per wave is worth more
+    //  than the set-up it repeats.  One pass per wave stays.)
     constexpr bool SPLIT = CELLS && HP_SPLIT_PASSES;
     const int gpf = SPLIT ? plan.n_main * plan.P + plan.Pt : plan.n_main + (plan.Gt > 0 ? 1 : 0);      // units per sample
     const long long wid = (long long)blk * HP_WAVES + wave;

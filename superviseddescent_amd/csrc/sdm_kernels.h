@@ -259,10 +259,8 @@ struct SolveAux {
     void* upd_planes; unsigned* upd_maxdiag;      // (upd_maxdiag: 4 words -- largest diagonal entry, two right-hand-side scale slots, smallest diagonal entry)
     int* range_fallbacks;                          // host counter: factorisations whose diagonal spanned > 2^20 and therefore ran their updates in f32 (may be null)
     int upd_f32_only;                              // A/B (SDM_UPDATE_F32=1, read at sdm_create): every trailing update on the f32 matrix-core kernel
-    // round 5: third queue + event for the "mid" rows of a group-end update (the tile rows of the next group the chain does not need
-    // at once); head_split = 0 keeps the whole next group on the chain's queue (A/B: SDM_SOLVE_HEAD_SPLIT=0); lazy = panels per group (0 = 4)
-    hipStream_t mid_stream; hipEvent_t mid_done; int head_split; int lazy;
-    int upd_min_tiles;                             // A/B (SDM_SOLVE_UPD_MIN_TILES): trailing tiles from which the float16 update runs (0 = 40)
+    int chain_v1;                                  // A/B (SDM_SOLVE_CHAIN_V1=1): the round-2/3 potrf / panel-solve kernels
+    int upd_min_tiles;                             // A/B (SDM_SOLVE_UPD_MIN_TILES): trailing tiles from which the float16-piece update runs (0: the default)
 };
 size_t sdm_update_f16_plane_bytes(int rows_max, int ncols);
 void sdm_launch_diag_absmax(const float* G, long long ldg, int F, unsigned* scales, hipStream_t stream);
@@ -285,7 +283,7 @@ struct SolveShard {
     // that one context on one GPU spends the time a rank of a real run spends waiting for the owner's potrf
     int emulate_chain;
 };
-inline size_t sdm_solve_shard_stage_tiles(int ncols, int world, int lazy = 4) { return (size_t)(world + 1) * (size_t)(lazy > 4 ? lazy : 4) * (size_t)(ncols / 128 / world + 1); }
+inline size_t sdm_solve_shard_stage_tiles(int ncols, int world) { return (size_t)(world + 1) * 4 * (size_t)(ncols / 128 / world + 1); }
 // returns 0, or the non-zero result of a failed collective
 inline size_t sdm_backsolve_flag_floats(int Fp) { return (size_t)9 * (size_t)(Fp / 128) + 64; }      // (<= 144 right-hand sides = 9 column tiles: <= 9 chunks)
 int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs, float* R_out,

@@ -655,6 +655,259 @@ trsm_tile_kernel(float* __restrict__ G, long long ldg, int k0, int tile_j0, int 
 }
 
 
+// =====================================================================================================
+// Round 5: the two chain kernels again.  Three changes against the first generation above, all on the serial path every 128-column step
+// of the factorisation waits for (scripts/ubench/chain_stamps.hip prices them; profiles/r05_experiments.txt):
+//
+//  1. The tile never leaves the matrix-core accumulator layout.  D[row 4 lq + e][column li] is what a lane holds; a product
+//     sum_k A[i][k] B[k][n] may enumerate k in any order as long as both operands use the same one, so k = 4 lq + s (instead of the
+//     customary 4 s + lq) makes register e = s of an accumulator tile DIRECTLY the B operand of k-step s -- and, for a symmetric update
+//     T -= P^T P, also the A operand.  The trips through LDS that turned an accumulator tile into an operand (two per 16-column step
+//     and wave in both kernels, each behind a wavefront-scope fence) are gone.
+//  2. The 16 x 16 factor of step (a) is blocked by four: the four pivots of a block touch only the block's own four rows (six
+//     v_readlane + multiply-add pairs instead of up to fifteen per pivot -- v_readlane, a VALU -> SGPR move, is what the first
+//     generation's 230 clocks per pivot were made of), the rows below receive the block's rank-4 update as ONE v_mfma_f32_16x16x4_f32.
+//     The same row operations applied to the identity give M = U_jj^-T (M A = U, A = U^T U): a second accumulator tile carries the
+//     identity through them, at one more multiply-add per row operation and one more matrix instruction per block.
+//  3. With M at hand the panel solve of step (b) is four matrix instructions per tile (Y = M T), and the panel solve of the tile ROW
+//     (trsm_tile2_kernel) no longer inverts the eight diagonal blocks itself: potrf_tile2_kernel leaves M_j in the strictly lower
+//     triangle of diagonal block j of the factored tile -- free storage, nothing reads below the diagonal of a factored tile; the
+//     diagonal of M_j is the reciprocal of U's, recomputed by the reader -- so the inverses travel with the tile when a sharded
+//     factorisation broadcasts it.
+// v_rsq_f32 (<= 1 ulp) replaces the v_sqrt_f32 + v_rcp_f32 pair on the pivot chain.  The factor differs from the first generation's in
+// the last bits (it is the engine's own factor, pinned to nothing bit-wise; against float64 it is the closer one); the same tile is
+// computed by the same instructions for any number of ranks.
+// The loop over the eight 16-column steps is NOT unrolled (the wave's diagonal tile is a variable of its own, the tile a step's panel
+// solve needs is picked by uniform selects): unrolled, step (a) exists eight times, each copy executed once by one wave.
+// =====================================================================================================
+#define POTRF2_LDS_FLOATS (IB * POTRF_PLD + NIB * IB * IB + 4)
+__global__ void __launch_bounds__(TILE * PQ)
+potrf_tile2_kernel(float* __restrict__ G, long long ldg, int k0, int* __restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* P = sm;                               // [16][POTRF_PLD]  current panel: P[m][c] = U[j0 + m][c]
+    float* Mt = P + IB * POTRF_PLD;              // [8 blocks][16][16]  Mt[j][k][i] = M_j[i][k], M_j = U_jj^-T (lower triangular)
+    float* badf = Mt + NIB * IB * IB;            // "not positive definite" flag
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    float* Gk = G + (long long)k0 * ldg + k0;
+    if (t == 0) *badf = 0.0f;
+    SOLVE_STAMP(0);
+    // this wave's tiles in accumulator layout: acc[rb][e] = T[16 rb + 4 lq + e][16 wave + li] for rb < wave, diag = the tile on the diagonal
+    f32x4 acc[NIB - 1], diag;
+#pragma unroll
+    for (int rb = 0; rb < NIB - 1; ++rb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            acc[rb][e] = rb < wave ? Gk[(long long)(IB * rb + 4 * lq + e) * ldg + IB * wave + li] : 0.0f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) diag[e] = Gk[(long long)(IB * wave + 4 * lq + e) * ldg + IB * wave + li];
+    __syncthreads();
+    SOLVE_STAMP(1);
+    int nsteps = NIB;
+    asm volatile("" : "+s"(nsteps));      // (opaque trip count: the compiler must not peel or unroll the step loop)
+#pragma unroll 1
+    for (int jb = 0; jb < nsteps; ++jb) {
+        // (a) the diagonal tile on wave jb, blocked by four rows; mi carries the identity through the same row operations
+        if (wave == jb) {
+            f32x4 mi;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mi[e] = (4 * lq + e == li) ? 1.0f : 0.0f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (lq == b) {      // rows 4 b .. 4 b + 3 live in these sixteen lanes (v_readlane reads across the execution mask)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        // (scalar copies before every bit cast: __builtin_bit_cast applied to a vector ELEMENT reads element 0 with this compiler)
+                        const float row_e = diag[e];
+                        const float piv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, row_e), 16 * b + 4 * b + e));
+                        // (v_rsq_f32 flushes denormals: a pivot below FLT_MIN -- or a negative one, or NaN -- is "not positive definite" here)
+                        if (!(piv >= 1.17549435e-38f)) *badf = 1.0f;      // (a uniform branch: the pivot is a scalar)
+                        const float rs = __builtin_amdgcn_rsqf(piv);
+                        const float us = row_e * rs, ms = mi[e] * rs;
+                        diag[e] = us;                      // row s of U (lane s: the pivot times its reciprocal root)
+                        mi[e] = ms;                        // row s of M
+#pragma unroll
+                        for (int e2 = e + 1; e2 < 4; ++e2) {
+                            const float f = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, us), 16 * b + 4 * b + e2));   // U[s][r]
+                            diag[e2] = __builtin_fmaf(-f, us, diag[e2]);
+                            mi[e2] = __builtin_fmaf(-f, ms, mi[e2]);
+                        }
+                    }
+                }
+                if (b < 3) {
+                    // the block's four finished rows as a matrix-core operand: lane (lq, li) <- row 4 b + lq, column li (held by lane 16 b + li in register lq)
+                    const int src = (16 * b + li) * 4;
+                    float p = 0.0f, pm = 0.0f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float de = diag[e], me = mi[e];
+                        const float v = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, de)));
+                        const float vm = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, me)));
+                        p = lq == e ? v : p;
+                        pm = lq == e ? vm : pm;
+                    }
+                    // rows below the block lose the block's rank-4 update: T[i][n] -= sum_k U[k][i] U[k][n], M likewise (finished rows: A = 0)
+                    const float a = li >= 4 * (b + 1) ? -p : 0.0f;
+                    diag = __builtin_amdgcn_mfma_f32_16x16x4f32(a, p, diag, 0, 0, 0);
+                    mi = __builtin_amdgcn_mfma_f32_16x16x4f32(a, pm, mi, 0, 0, 0);
+                }
+            }
+            // Mt[jb][k = li][i = 4 lq + e] = M[4 lq + e][li]: sixteen consecutive bytes per lane
+            *(f32x4s*)(Mt + (jb * IB + li) * IB + 4 * lq) = (f32x4s){mi[0], mi[1], mi[2], mi[3]};
+        }
+        __syncthreads();
+        SOLVE_STAMP(2 + 2 * jb);
+        if (*badf != 0.0f) {
+            // (the NaN travels with the tile: the other ranks of a sharded factorisation see the failure in trsm_tile2_kernel)
+            if (t == 0) { atomicOr(status, 2); Gk[0] = __builtin_nanf(""); }
+            return;
+        }
+        // (b) panel: tile (jb, wave) for wave > jb: Y = M_jb T, k enumerated as 4 lq + s: A = M[li][4 lq + s] = Mt[4 lq + s][li], B = register s
+        //     of the tile; then the wave's own diagonal tile at once (T_ww -= Y^T Y: both operands are Y's registers), so that the wave
+        //     of the next step goes straight on to its factor
+        f32x4 y = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (wave > jb) {
+            f32x4 tile = acc[0];
+#pragma unroll
+            for (int q = 1; q < NIB - 1; ++q) tile = (jb == q) ? acc[q] : tile;          // (uniform selects)
+            float mop[4];
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) mop[s_] = Mt[(jb * IB + 4 * lq + s_) * IB + li];
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) y = __builtin_amdgcn_mfma_f32_16x16x4f32(mop[s_], tile[s_], y, 0, 0, 0);
+            // (Measured and dropped: one step of iterative refinement -- r = T - U_jj^T Y, Y += M r, eight more matrix instructions per
+            //  tile -- against the loss of multiplying by an explicit inverse: the distance of a training level from its float64 solution
+            //  did not move (3.44e-3 against 3.54e-3 at the one level of eleven where this generation is further from float64 than the
+            //  first; it is closer at five), the factor took 2 us longer.)
+#pragma unroll
+            for (int q = 0; q < NIB - 1; ++q) acc[q] = (jb == q) ? y : acc[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) P[(4 * lq + e) * POTRF_PLD + IB * wave + li] = y[e];
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) diag = __builtin_amdgcn_mfma_f32_16x16x4f32(-y[s_], y[s_], diag, 0, 0, 0);
+        }
+        __syncthreads();
+        SOLVE_STAMP(3 + 2 * jb);
+        // (c) trailing update of this wave's other tiles (rb, wave), jb < rb < wave: T -= P_rb^T Y
+        if (wave > jb + 1) {
+#pragma unroll
+            for (int rb = 1; rb < NIB - 1; ++rb)
+                if (rb > jb && rb < wave) {
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_)
+                        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(P[(4 * lq + s_) * POTRF_PLD + IB * rb + li], -y[s_], acc[rb], 0, 0, 0);
+                }
+        }
+        // (the next step's (a) touches only its own wave's registers; P is rewritten after the next barrier)
+    }
+    // store: the upper triangle from the accumulators; below the diagonal zeros, except the strictly lower triangles of the eight
+    // diagonal blocks, which receive M_j (row r, column c < r of block j: M_j[r][c] = Mt[j][c][r])
+#pragma unroll
+    for (int rb = 0; rb < NIB; ++rb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = IB * rb + 4 * lq + e, c = IB * wave + li;
+            float v = 0.0f;
+            if (rb < NIB - 1 && rb < wave) v = acc[rb < NIB - 1 ? rb : 0][e];
+            if (rb == wave) v = (c >= r) ? diag[e] : Mt[(wave * IB + li) * IB + 4 * lq + e];
+            Gk[(long long)r * ldg + c] = v;
+        }
+    SOLVE_STAMP(20);
+}
+
+// Panel solve of the tile row against a tile factored by potrf_tile2_kernel: G[k0 : k0 + 128, strip] <- U_kk^-T (same).  Forward
+// substitution blocked by 16 with the strip in the accumulators of NW waves (16 columns each): Y_j = M_j B_j, then B_r -= U_jr^T Y_j for
+// the blocks r > j -- every product with k enumerated as 4 lq + s, so that the strip's registers are the operands (no LDS between the
+// steps, no fence, no barrier after the staging of U_kk).  M_j is read from the tile (below the diagonal of block j; its diagonal = 1 / U's).
+// The extra last tile (identity) gives U_kk^-T for the back substitution.  NW = 4: two workgroups per tile, each on a compute unit of
+// its own -- the steps are bound by the f32 matrix pipe (144 matrix instructions per wave), two waves per SIMD would share it.
+template <int NW>
+__global__ void __launch_bounds__(64 * NW)
+trsm_tile2_kernel(float* __restrict__ G, long long ldg, int k0, int tile_j0, int n_tiles, float* __restrict__ winv_t, int own_stride,
+                  int* __restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Up = sm;                              // [36 blocks][16][16]   the upper blocks of U_kk
+    float* Dm = sm + 36 * IB * IB;               // [8][16][16]      the diagonal blocks TRANSPOSED: Dm[j][k][i] = block_j[i][k] -- M_j[i][k] for i > k, U's diagonal at i == k
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    constexpr int SUB = NIB / NW;                // workgroups per tile
+    const int tile = (int)blockIdx.x / SUB, c0 = ((int)blockIdx.x % SUB) * IB * NW;      // this workgroup's strip: columns c0 .. c0 + 16 NW - 1 of its tile
+    const bool inverse = tile == n_tiles;
+    const long long j0g = (long long)(tile_j0 + tile * own_stride) * TILE;
+    const float* Gk = G + (long long)k0 * ldg + k0;
+    if (inverse && t == 0 && !(Gk[0] == Gk[0])) atomicOr(status, 2);      // the owner's potrf reported "not positive definite"
+    float* B = inverse ? winv_t : G + (long long)k0 * ldg + j0g;
+    const long long ldb = inverse ? TILE : ldg;
+    SOLVE_STAMP(32);
+    // U_kk first (the staging and its barrier are what the first product waits for), then the strip.  ALL loads are issued before the
+    // first LDS write: with the write inside the (per-lane) "upper block?" branch every pass was a memory round trip of its own -- 16 of
+    // them made 22 000 of this kernel's clocks (scripts/ubench/chain_stamps.hip).  The blocks below the diagonal are loaded and dropped.
+    const int lr = t >> 5, lc = (t & 31) * 4;
+    constexpr int PASSES = TILE / (2 * NW);
+    f32x4s stage[PASSES];
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) stage[pass] = *(const f32x4s*)(Gk + (long long)(lr + pass * 2 * NW) * ldg + lc);
+    // this wave's strip in accumulator layout: acc[rb][e] = B[16 rb + 4 lq + e][c0 + 16 wave + li]
+    // (one branch around all 32 loads: with the "identity or load" choice per element every load sat in a branch of its own, followed by
+    //  its own wait -- 32 memory round trips, 18 000 clocks)
+    f32x4 acc[NIB];
+    if (inverse) {
+#pragma unroll
+        for (int rb = 0; rb < NIB; ++rb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[rb][e] = (IB * rb + 4 * lq + e == c0 + IB * wave + li) ? 1.0f : 0.0f;
+    } else {
+        const float* Bs = B + c0 + IB * wave + li;
+#pragma unroll
+        for (int rb = 0; rb < NIB; ++rb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[rb][e] = Bs[(long long)(IB * rb + 4 * lq + e) * ldb];
+    }
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
+        const int r = lr + pass * 2 * NW;
+        const int jb_ = (pass * 2 * NW) >> 4, rb_ = lc >> 4;  // (= r >> 4: lr < 2 NW, and 2 NW divides 16)
+        if (rb_ >= jb_) {
+            const f32x4s v = stage[pass];
+            *(f32x4s*)(Up + trsm_blk(jb_, rb_) * IB * IB + (r & 15) * IB + (lc & 15)) = v;
+            if (rb_ == jb_) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Dm[(jb_ * IB + (lc & 15) + q) * IB + (r & 15)] = v[q];
+            }
+        }
+    }
+    __syncthreads();
+    SOLVE_STAMP(34);
+#pragma unroll
+    for (int jb = 0; jb < NIB; ++jb) {
+        // Y_j = M_j B_j: A[row li][k] = M[li][k], k = 4 lq + s: below the diagonal as stored, on it the reciprocal of U's, above it zero
+        f32x4 y = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+            const int k = 4 * lq + s_;
+            const float m = Dm[(jb * IB + k) * IB + li];
+            const float a = li > k ? m : (li == k ? __builtin_amdgcn_rcpf(m) : 0.0f);
+            y = __builtin_amdgcn_mfma_f32_16x16x4f32(a, acc[jb][s_], y, 0, 0, 0);
+        }
+        acc[jb] = y;
+        // B_r -= U_jr^T Y_j:  A[row li][k] = U[j0 + k][16 rb + li], k = 4 lq + s
+        // (k-step outermost: consecutive matrix instructions update different row blocks and do not wait for each other)
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+            for (int rb = jb + 1; rb < NIB; ++rb)
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Up[trsm_blk(jb, rb) * IB * IB + (4 * lq + s_) * IB + li], -y[s_], acc[rb], 0, 0, 0);
+    }
+    SOLVE_STAMP(35);
+#pragma unroll
+    for (int rb = 0; rb < NIB; ++rb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) B[(long long)(IB * rb + 4 * lq + e) * ldb + c0 + IB * wave + li] = acc[rb][e];
+    SOLVE_STAMP(36);
+}
+
 
 // ---- back substitution in ONE launch (round 3) -------------------------------------------------------
 // One persistent workgroup per tile row i (and per chunk of <= 5 right-hand-side column tiles).  Y_i lives in the matrix-core
@@ -716,10 +969,22 @@ backsolve_persistent_kernel(const float* __restrict__ G, long long ldg, int Tf, 
         // -U_ik -> A, R_k -> Bk
 #pragma unroll
         for (int q = 0; q < TILE / 16; ++q) *(f32x4s*)(A + (lr + 16 * q) * (TILE + 4) + lc) = -pre[q];
+        // (all loads of R_k first, unconditional -- columns beyond the last right-hand side read the last one and are zeroed after --
+        //  then the LDS writes: as a loop of "in range ? load : 0" every element was a memory round trip of its own, twelve in a row on
+        //  the chain of the substitution at 48 right-hand sides)
         const float* Rk = R + (long long)k * TILE * ldr + col0;
-        for (int idx = t; idx < TILE * ncb; idx += BSP_WAVES * 64) {
-            const int r = idx / ncb, cc = idx - r * ncb;
-            Bk[idx] = (col0 + cc < nrhs) ? Rk[(long long)r * ldr + cc] : 0.0f;
+        constexpr int NLD = TILE * ncb / (BSP_WAVES * 64);      // 4 NJ elements per thread
+        const int cc_last = nrhs - 1 - col0;
+        float rk[NLD];
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int idx = t + q * BSP_WAVES * 64, r = idx / ncb, cc = idx - r * ncb;
+            rk[q] = Rk[(long long)r * ldr + (cc < cc_last ? cc : cc_last)];
+        }
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int idx = t + q * BSP_WAVES * 64, r = idx / ncb, cc = idx - r * ncb;
+            Bk[idx] = cc <= cc_last ? rk[q] : 0.0f;
         }
         __syncthreads();
         // the next operand's memory round trip runs under this product
@@ -983,10 +1248,14 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
     const int T = ncols / TILE;
     const size_t lds_potrf = ((size_t)IB * POTRF_PLD + IB * IB + 4 + 8 * IB * (IB + 1)) * sizeof(float);
     const size_t lds_trsm = (size_t)TRSM_LDS_FLOATS * sizeof(float);
+    const size_t lds_potrf2 = (size_t)POTRF2_LDS_FLOATS * sizeof(float);
+    const bool v2 = !(aux && aux->chain_v1);      // round 5: the chain kernels with the diagonal blocks' inverses as a by-product (A/B: SDM_SOLVE_CHAIN_V1=1)
     static unsigned long long attr_seen = 0;
     if (sdm_first_use_on_device(attr_seen)) {
         SDM_SET_ATTR((const void*)potrf_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         SDM_SET_ATTR((const void*)trsm_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        SDM_SET_ATTR((const void*)potrf_tile2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        SDM_SET_ATTR((const void*)trsm_tile2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     // Panels are processed in groups of LAZY: inside a group only the NEXT tile row receives the pending rank-128
     // updates (a thin launch); the whole trailing matrix is updated once per group with K = 128*LAZY.  That is 1/LAZY of
@@ -1003,16 +1272,16 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
     // solve of the others need them); at a group end the ranks all-gather the group's panel rows, which the trailing update
     // reads across ALL columns.  After the last group every rank holds all of U and of the forward-substituted right-hand
     // sides; the back substitution is replicated.
-    const int LAZY = (aux && aux->lazy > 0) ? aux->lazy : 4;
+    // (Round 5 measured the schedule again -- profiles/r05_experiments.txt: 2 / 4 / 8 panels per group 6.01 / 5.93 / 6.46 ms at
+    //  F = 8 801 and - / 44.9 / 44.1 ms at F = 27 201; the next group's tile rows 3 and 4 updated on a third queue while the chain
+    //  factors rows 1 and 2 ("head split"): 6.44 / 6.06 ms with that queue at normal / highest priority against 5.93-6.00 -- the
+    //  extra events cost what the shorter head saves.  Four panels and the whole next group on the chain's queue stay.)
+    const int LAZY = 4;
     const bool overlap = aux && aux->stream && Tf > 2 * LAZY;
-    // Round 5: the head of a group-end update -- the part the chain waits for -- is only the next TWO tile rows (one 256-row super-row
-    // of the float16 kernel); the group's other tile rows ("mid") are updated on a third queue while the chain factors the first
-    // two steps of the next group, and are waited for in front of the first launch that touches them (the row update of the group's
-    // third step).  Every tile is computed by the same kernel with the same operands as before: only the queue changes.
-    const int HEAD = (overlap && aux->mid_stream && aux->mid_done && LAZY > 2 && aux->head_split) ? 2 : LAZY;
-    bool mid_pending = false;
     const bool upd_f32_only = aux && aux->upd_f32_only;      // (A/B: every trailing update on the f32 kernel)
-    const int upd_min_tiles = (aux && aux->upd_min_tiles > 0) ? aux->upd_min_tiles : 40;      // trailing tiles from which the float16-piece update pays (its split pre-pass is per panel group)
+    // trailing tiles from which the float16-piece update runs (its split pre-pass is per panel group): 40 until round 4; measured again in
+    // round 5 -- 8 / 16 / 24 / 40 tiles: 5.75 / 5.73 / 5.73 / 5.97 ms at F = 8 801, no difference at F = 27 201 (profiles/r05_experiments.txt)
+    const int upd_min_tiles = (aux && aux->upd_min_tiles > 0) ? aux->upd_min_tiles : 16;      // (A/B: SDM_SOLVE_UPD_MIN_TILES)
     bool upd_f16 = aux && aux->upd_planes && aux->upd_maxdiag && !upd_f32_only;
     if (upd_f16) {
         sdm_launch_diag_absmax(G, ldg, F, aux->upd_maxdiag, stream);
@@ -1042,14 +1311,16 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
         const bool mine = !shard || k % W == me;
         // bring tile row k up to date with the panels g0 .. k-1 of its group (owned columns; the owner of column k first:
         // its tile (k, k) is what the chain waits for)
-        if (mid_pending && nb >= HEAD) { (void)hipStreamWaitEvent(stream, aux->mid_done, 0); mid_pending = false; }      // (tile row k was a "mid" row of the last group-end update)
         if (nb && mine) sdm_launch_syrk_tn(G + (long long)g0 * TILE * ldg, ldg, nb * TILE, ncols, G, ldg, -1.0f, 1, k, stream, 1, me, W);
-        if (mine || shard->emulate_chain) hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(TILE * PQ), lds_potrf, stream, G, ldg, k0, status);
+        if (mine || shard->emulate_chain) {
+            if (v2) hipLaunchKernelGGL(potrf_tile2_kernel, dim3(1), dim3(TILE * PQ), lds_potrf2, stream, G, ldg, k0, status);
+            else hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(TILE * PQ), lds_potrf, stream, G, ldg, k0, status);
+        }
         if (shard) {
             // tiles (g0 .. k, k): the group's panel rows in column k, then the factored diagonal tile
             if (mine) hipLaunchKernelGGL(tiles_gather_kernel, dim3(1, nb + 1, 1), dim3(256), 0, stream, G, ldg, shard->stage, g0, nb + 1, k, k + 1, 1, 0, 1, 0, -1);
             const int rc = shard->bcast(shard->self, shard->stage, (size_t)(nb + 1) * TILE * TILE, k % W, stream);
-            if (rc) { if (tail_pending) (void)hipStreamWaitEvent(stream, aux->tail_done, 0); if (mid_pending) (void)hipStreamWaitEvent(stream, aux->mid_done, 0); return rc; }      // (the caller's stream owns G again)
+            if (rc) { if (tail_pending) (void)hipStreamWaitEvent(stream, aux->tail_done, 0); return rc; }      // (the caller's stream owns G again)
             if (!mine) {
                 hipLaunchKernelGGL(tiles_gather_kernel, dim3(1, nb + 1, 1), dim3(256), 0, stream, G, ldg, shard->stage, g0, nb + 1, k, k + 1, 1, 0, 1, 1, -1);
                 if (nb) sdm_launch_syrk_tn(G + (long long)g0 * TILE * ldg, ldg, nb * TILE, ncols, G, ldg, -1.0f, 1, k, stream, 1, me, W);
@@ -1059,8 +1330,10 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
         // the panel tiles of the owned columns + one workgroup that produces U_kk^-T for the back substitution
         const int first = k + 1 + ((((me - (k + 1)) % W) + W) % W);             // first owned column right of k
         const int nown = first < T ? (T - first + W - 1) / W : 0;
-        hipLaunchKernelGGL(trsm_tile_kernel, dim3(nown + 1), dim3(TILE * PQ), lds_trsm, stream, G, ldg, k0, first, nown,
-                           work + (size_t)k * TILE * TILE, W, status);
+        if (v2) hipLaunchKernelGGL(trsm_tile2_kernel<4>, dim3(2 * (nown + 1)), dim3(256), lds_trsm, stream, G, ldg, k0, first, nown,
+                                   work + (size_t)k * TILE * TILE, W, status);
+        else hipLaunchKernelGGL(trsm_tile_kernel, dim3(nown + 1), dim3(TILE * PQ), lds_trsm, stream, G, ldg, k0, first, nown,
+                                work + (size_t)k * TILE * TILE, W, status);
         const bool group_end = (k + 1) % LAZY == 0 || k == Tf - 1;
         if (group_end && ntr > 0) {   // trailing update of all tiles (ti >= k+1, tj >= ti) from the group's panel rows
             const float* panels = G + (long long)g0 * TILE * ldg;
@@ -1073,7 +1346,7 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
                 float* recv = shard->stage + per_rank;
                 hipLaunchKernelGGL(tiles_gather_kernel, dim3(ncmax, nr, 1), dim3(256), 0, stream, G, ldg, send, g0, nr, k + 1, T, W, me, ncmax, 0, -1);
                 const int rc = shard->allgather(shard->self, send, recv, per_rank, stream);
-                if (rc) { if (tail_pending) (void)hipStreamWaitEvent(stream, aux->tail_done, 0); if (mid_pending) (void)hipStreamWaitEvent(stream, aux->mid_done, 0); return rc; }
+                if (rc) { if (tail_pending) (void)hipStreamWaitEvent(stream, aux->tail_done, 0); return rc; }
                 hipLaunchKernelGGL(tiles_gather_kernel, dim3(ncmax, nr, W), dim3(256), 0, stream, G, ldg, recv, g0, nr, k + 1, T, W, 0, ncmax, 1, me);
             }
             // A wide trailing matrix is updated on the float16 matrix cores (sdm_gram_bf16.hip: two pieces per entry; one scale per
@@ -1089,19 +1362,12 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
                                       aux->upd_maxdiag, (k / LAZY) & 1, r0 / 2, tile_rows > 0 ? (r0 + tile_rows) / 2 : (1 << 30), first, W, st);
             };
             if (overlap && tail_pending) (void)hipStreamWaitEvent(stream, aux->tail_done, 0);   // head rows were tail rows of the last group (and its tail read the planes)
-            if (mid_pending) { (void)hipStreamWaitEvent(stream, aux->mid_done, 0); mid_pending = false; }      // (a short last group: the mid update read the planes too)
             if (f16u) sdm_launch_update_split_f16(panels + (long long)(k + 1) * TILE, ldg, prow, ntr * TILE, Tloc * TILE, aux->upd_planes, aux->upd_maxdiag, (k / LAZY) & 1, status, stream);
             if (!overlap) {
                 update(k + 1, 0, stream);
             } else {
                 (void)hipEventRecord(aux->chain_done, stream);
-                update(k + 1, HEAD, stream);
-                if (HEAD < LAZY && k + 1 + HEAD < T) {
-                    (void)hipStreamWaitEvent(aux->mid_stream, aux->chain_done, 0);
-                    update(k + 1 + HEAD, LAZY - HEAD, aux->mid_stream);
-                    (void)hipEventRecord(aux->mid_done, aux->mid_stream);
-                    mid_pending = true;
-                }
+                update(k + 1, LAZY, stream);
                 if (k + 1 + LAZY < T) {
                     (void)hipStreamWaitEvent(aux->stream, aux->chain_done, 0);
                     update(k + 1 + LAZY, 0, aux->stream);
@@ -1112,7 +1378,7 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
         }
     }
     if (tail_pending) (void)hipStreamWaitEvent(stream, aux->tail_done, 0);
-    if (mid_pending) (void)hipStreamWaitEvent(stream, aux->mid_done, 0);
+   
     int nj = nrhs / 16;   // nrhs is a multiple of 16, <= 144 (sharded: narrowed to this rank's column tiles below)
     {
         // one persistent launch: Tf workgroups x chunks of <= 5 column tiles; flags (one int per tile row and chunk) behind the
@@ -1134,7 +1400,10 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
         const int nj_full = nj;
         nj = bs_n;
         const int rhs_shift = 16 * bs_lo;
-        const int cap = 5;      // column tiles per workgroup (measured 42.3 / 43.7 / 47.4 / 56.2 ms at F = 27 201 for 5 / 3 / 2 / 1)
+        // column tiles per workgroup (measured 42.3 / 43.7 / 47.4 / 56.2 ms at F = 27 201 for 5 / 3 / 2 / 1; round 5, F = 8 801 with 3 column
+        // tiles: one workgroup per tile row 5.56 ms, three of one column tile each 5.74 -- the shorter product does not pay for the
+        // second and third copy of every U tile; F = 17 051: 14.8 against 15.8 ms)
+        const int cap = 5;
         const int nchunks = nj > 0 ? (nj + cap - 1) / cap : 0, NJ = nchunks ? (nj + nchunks - 1) / nchunks : 1;
         int* flags = (int*)(work + (size_t)Tf * TILE * TILE);
         if (nchunks) (void)hipMemsetAsync(flags, 0, ((size_t)nchunks * Tf + nchunks) * sizeof(int), stream);      // flags + one ticket counter per chunk

@@ -106,8 +106,9 @@ def test_linear_regressor_with_the_qr_solver_trains_the_cascade(gpu_ctx):
         assert a.last_lambda == pytest.approx(b.last_lambda, rel=1e-6)
     assert rel(x_qr, x_lu.astype(np.float64)) < 2e-5
     assert np.array_equal(sdo_qr.test(x0, None, hog), sdo_qr.test(x0, None, hog))
-    # the default solver is back for the next user of the shared context: a singular system raises there (Cholesky), where the
-    # QR would have reported a rank
+    # the default solver is back for the next user of the shared context: an indefinite system raises there (Cholesky), where the
+    # QR would have reported a rank.  (G - I with G = 50 x ones: eigenvalues 199, -1, -1, -1.  The exactly singular G itself is no
+    # test: whether its second pivot comes out as +-1e-6 is a matter of rounding -- the round-3 kernels happened to see a negative one.)
     A = np.ones((50, 4), np.float32); b = np.ones((50, 1), np.float32)
     with pytest.raises(Exception):
-        gpu_ctx.solve_normal_equations(A, b, 0, 0.0, True)
+        gpu_ctx.solve_normal_equations(A, b, 0, -1.0, True)

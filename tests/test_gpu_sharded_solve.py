@@ -378,7 +378,10 @@ def test_reduce_scatter_exchange_feeds_the_sharded_factorisation(built, world, g
     sent_ar = ref_calls[0]["allreduce_floats"]
     print("reduce-scatter exchange, %s, %d ranks: R vs all-reduce run %.2e, landmarks %.2e; buffer floats %d against %d (all-reduce)"
           % (geometry, world, rel_R, rel_x, sent_rs, sent_ar))
-    assert rel_R < 1e-5 and rel_x < 1e-6
+    # (R: the two runs' lambdas differ in the last bit -- a float sum of the ranks' shares of ||G||_F^2 against one reduction -- and the
+    #  regressor of a system with a few hundred rows for ~9 800 unknowns moves with it along directions the data does not see: measured
+    #  0.5 - 1.8e-5 over the solver generations, as between processes in tests/_rccl_worker.py (5e-5 there too); the landmarks bind: 2e-8)
+    assert rel_R < 5e-5 and rel_x < 1e-6
     # a ring all-reduce moves 2 (W-1)/W x its buffer per rank, a ring reduce-scatter (W-1)/W x its buffer: the padded owner-ordered
     # buffer is within a few tiles of the all-reduce's
     assert sent_rs < 1.1 * sent_ar
