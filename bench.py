@@ -203,7 +203,21 @@ def main():
     # 6).  The torch.distributed callbacks (ctypes -> Python -> torch) remain for backends without RCCL -- the gloo runs of the
     # tests -- and as SDM_BENCH_COLLECTIVES=torch for an A/B.
     native = use_dist and backend == "nccl" and os.environ.get("SDM_BENCH_COLLECTIVES", "rccl") != "torch"
-    rccl = parallel.RcclCommunicator(rank, world) if native else None
+    # The communicator is created at its FIRST USE -- with several GPUs that is behind the headline measurement, under the watchdog
+    # below: an ncclCommInitRank that hangs or fails on links this code has never seen must not take the headline with it.
+    class _LazyRccl:
+        def __init__(self):
+            self.comm = None
+
+        def get(self):
+            if self.comm is None:
+                self.comm = parallel.RcclCommunicator(rank, world)
+            return self.comm
+
+        def destroy(self):
+            if self.comm is not None:
+                self.comm.destroy()
+    lazy_rccl = _LazyRccl() if native else None
     allreduce = parallel.make_torch_allreduce(local_rank) if (use_dist and not native) else None
     # SDM_BENCH_SHARD_SOLVE=1: the summed system is factored by all ranks together (tile-column ownership).  Off by
     # default: at the bench's F = 8 801 the factorisation is bound by its chain of 69 single-workgroup panel steps, which
@@ -226,7 +240,7 @@ def main():
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             if collective and native:
-                sdo.train(txs, tx0, None, hog, world_size=world, n_train_global=n_train_global, rccl=rccl, rccl_shard_solve=shard_solve,
+                sdo.train(txs, tx0, None, hog, world_size=world, n_train_global=n_train_global, rccl=lazy_rccl.get(), rccl_shard_solve=shard_solve,
                           on_training_epoch_callback=(lambda cur: nlsr_.append(float(np.linalg.norm(cur - txs) / np.linalg.norm(txs))))
                           if rep == 0 else None)
             elif collective:
@@ -283,7 +297,7 @@ def main():
             t1 = time.perf_counter()
             cb68 = (lambda cur: nlsr68.append(float(np.linalg.norm(cur - txs68) / np.linalg.norm(txs68)))) if rep == 0 else None
             if native:
-                sdo68.train(txs68, tx068, None, hog68, world_size=world, n_train_global=n_train_global, rccl=rccl, rccl_shard_solve=shard68,
+                sdo68.train(txs68, tx068, None, hog68, world_size=world, n_train_global=n_train_global, rccl=lazy_rccl.get(), rccl_shard_solve=shard68,
                             on_training_epoch_callback=cb68)
             else:
                 sdo68.train(txs68, tx068, None, hog68, allreduce=allreduce, world_size=world, n_train_global=n_train_global,
@@ -563,8 +577,8 @@ def main():
         watchdog.cancel()
 
     if rank != 0:
-        if rccl is not None:
-            rccl.destroy()
+        if lazy_rccl is not None:
+            lazy_rccl.destroy()
         if use_dist:
             dist.destroy_process_group()
         return
@@ -899,8 +913,8 @@ def main():
             "note": "CPU stages as the reference's VerbosePartialPivLUSolver prints them (verbose_solver.hpp:66-97): Eigen's f32 GEMM / "
                     "PartialPivLU restated with numpy sgemm / LAPACK sgetrf on all cores; never extrapolated to the full row count"}
     print(json.dumps(out))
-    if rccl is not None:
-        rccl.destroy()
+    if lazy_rccl is not None:
+        lazy_rccl.destroy()
     if use_dist:
         dist.destroy_process_group()
 

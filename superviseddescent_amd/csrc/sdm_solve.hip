@@ -241,8 +241,13 @@ syrk_tn_gldsw_kernel(const float* __restrict__ A, long long lda, int rows, float
 // With one workgroup per 128x128 tile such a launch has fewer workgroups than the chip has CUs and every slab costs a full
 // memory round trip.  Here a tile is split into four 64x64 sub-tiles (4x the workgroups), and K arrives in batches of
 // 128 rows -- 2 x 32 KB straight into LDS, all loads of a batch in flight together, one barrier pair per batch.
-#define THIN_BK 128
+#define THIN_BK 64
 #define THIN_N 64
+// Round 5: on the chain of every 128-column step this launch had become the longest of the three (16 / 22 / 29 us for one / two / three
+// pending panels at 70 tiles against potrf 19 and the tile-row solve 11).  Two changes: K arrives in batches of 64 rows in TWO buffers --
+// batch b + 1 is in flight while batch b is multiplied, one barrier per batch -- and the sub-tile of C is requested before the first batch
+// instead of read-modify-written behind the last product (a memory round trip off the end of the launch).  Same products in the same
+// order per element: the sums are bit-identical to the single-buffer version's.
 __global__ void __launch_bounds__(256)
 syrk_tn_thin_kernel(const float* __restrict__ A, long long lda, int rows, float* __restrict__ C, long long ldc,
                     float alpha, int tile_i0, int own_first, int own_stride)
@@ -254,46 +259,47 @@ syrk_tn_thin_kernel(const float* __restrict__ A, long long lda, int rows, float*
     const int tjc = tile_i0 + own_first + (int)(blockIdx.x >> 1) * own_stride;
     const int sj = 2 * (tjc - ti) + (int)(blockIdx.x & 1);  // sub-tile column counted from the start of tile ti
     if (sj < si) return;                                   // left of / below the diagonal
-    extern __shared__ __attribute__((aligned(16))) float tl[];   // [A | B][THIN_BK][THIN_N]
-    float* As = tl;
-    float* Bs = tl + THIN_BK * THIN_N;
+    extern __shared__ __attribute__((aligned(16))) float tl[];   // [2 buffers][A | B][THIN_BK][THIN_N]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const bool diag = (sj == si);
     const float* Ai = A + (long long)ti * TILE + (long long)si * THIN_N;
     const float* Aj = A + (long long)ti * TILE + (long long)sj * THIN_N;
-    f32x16 acc;
+    // this wave's 32 x 32 part of C, requested first (C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5))
+    float* Cw = C + ((long long)ti * TILE + si * THIN_N + wr * 32 + 4 * (lane >> 5)) * ldc + (long long)ti * TILE + sj * THIN_N + wc * 32 + (lane & 31);
+    f32x16 cin, acc;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    for (int e = 0; e < 16; ++e) { cin[e] = Cw[(long long)((e & 3) + 8 * (e >> 2)) * ldc]; acc[e] = 0.0f; }
     // thread t fetches float4 number (t % 16) of batch rows t/16 + 16p; a wave's 64 lanes cover 4 consecutive rows (1 KB)
     const int lrow = t >> 4, lcol = (t & 15) * 4;
-    for (int n0 = 0; n0 < rows; n0 += THIN_BK) {
-        if (n0) __syncthreads();                           // the previous batch has been consumed
+    auto issue = [&](int n0, int buf) {
+        float* As = tl + (size_t)buf * 2 * THIN_BK * THIN_N;
+        float* Bs = As + THIN_BK * THIN_N;
 #pragma unroll
         for (int p = 0; p < THIN_BK / 16; ++p) {
             const long long n = (long long)n0 + lrow + 16 * p;
             glds16_solve(Ai + n * lda + lcol, As + (4 * wave + 16 * p) * THIN_N);
             if (!diag) glds16_solve(Aj + n * lda + lcol, Bs + (4 * wave + 16 * p) * THIN_N);
         }
-        __syncthreads();                                   // (drains the LDS-direct loads)
-        const float* Bp = diag ? As : Bs;
+    };
+    const int nbatch = rows / THIN_BK;
+    issue(0, 0);
+    for (int b = 0; b < nbatch; ++b) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);                 // vmcnt(0): this thread's loads of batch b (and of C) have landed
+        __syncthreads();                                   // ... everybody's; and everybody has left the other buffer (batch b - 1)
+        if (b + 1 < nbatch) issue((b + 1) * THIN_BK, (b + 1) & 1);
+        const float* As = tl + (size_t)(b & 1) * 2 * THIN_BK * THIN_N;
+        const float* Bp = diag ? As : As + THIN_BK * THIN_N;
 #pragma unroll 8
         for (int kk = 0; kk < THIN_BK; kk += 2) {
             const int k = kk + (lane >> 5);
             const float a = As[k * THIN_N + wr * 32 + (lane & 31)];
-            const float b = Bp[k * THIN_N + wc * 32 + (lane & 31)];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            const float bq = Bp[k * THIN_N + wc * 32 + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc, 0, 0, 0);
         }
     }
-    // C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int r = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        const long long gi = (long long)ti * TILE + si * THIN_N + wr * 32 + r;
-        const long long gj = (long long)ti * TILE + sj * THIN_N + wc * 32 + (lane & 31);
-        float* p = C + gi * ldc + gj;
-        *p += alpha * acc[e];
-    }
+    for (int e = 0; e < 16; ++e) Cw[(long long)((e & 3) + 8 * (e >> 2)) * ldc] = cin[e] + alpha * acc[e];
 }
 
 // ---- Frobenius norm of the symmetric matrix stored as its upper triangle ------------------------------
@@ -1053,7 +1059,7 @@ void sdm_launch_syrk_tn(const float* A, long long lda, int rows, int ncols, floa
     const bool chunked = rows > SYRK_CHUNK * SYRK_BK * 4;
     // thin updates (a panel group's row update / a head with fewer tiles than the chip has CUs)
     if (Ty <= 4 && T * Ty <= 320 && accumulate && rows % THIN_BK == 0 && rows <= 1024) {
-        const size_t lds = (size_t)2 * THIN_BK * THIN_N * sizeof(float);      // 64 KB
+        const size_t lds = (size_t)2 * 2 * THIN_BK * THIN_N * sizeof(float);      // 64 KB: two buffers of 64 rows x (A | B)
         static unsigned long long thin_seen = 0;
         if (sdm_first_use_on_device(thin_seen))
             sdm_check_launch_attr(hipFuncSetAttribute((const void*)syrk_tn_thin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "syrk_tn_thin_kernel");
