@@ -1,11 +1,12 @@
 // Where the microseconds of the factorisation's chain kernels go (round 5), and a stand-alone check of both generations of them:
-// potrf_tile_kernel / trsm_tile_kernel (rounds 2-3) and potrf_tile2_kernel / trsm_tile2_kernel (round 5: the diagonal blocks' inverses as a
+// potrf_tile_kernel / trsm_tile_kernel (rounds 2-3; scripts/ubench/chain_gen1.inc) and potrf_tile2_kernel / trsm_tile2_kernel (round 5: the diagonal blocks' inverses as a
 // by-product of the factor) of superviseddescent_amd/csrc/sdm_solve.hip, built with SDM_SOLVE_STAMPS -- thread 0 of workgroup 0 leaves
 // the shader clock behind the kernels' barriers -- on one tile row of a random SPD system of T tiles (default 70: the RCR-22 shape).
 // Checked against float64: the factor U_kk, the solved tile row U_kk^-T B and the transposed inverse the back substitution uses.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -w -o scripts/ubench/bin/chain_stamps scripts/ubench/chain_stamps.hip
 #define SDM_SOLVE_STAMPS 1
 #include "../../superviseddescent_amd/csrc/sdm_solve.hip"
+#include "chain_gen1.inc"
 #include <vector>
 #include <cmath>
 #include <cstdio>
@@ -52,7 +53,7 @@ int main(int argc, char** argv)
     (void)hipMalloc(&d, (size_t)TILE * n * 4); (void)hipMalloc(&winv, TILE * TILE * 4); (void)hipMalloc(&st, 4); (void)hipMemset(st, 0, 4);
     const size_t lds_potrf = ((size_t)IB * POTRF_PLD + IB * IB + 4 + 8 * IB * (IB + 1)) * sizeof(float);
     const size_t lds_potrf2 = (size_t)POTRF2_LDS_FLOATS * sizeof(float);
-    const size_t lds_trsm = (size_t)TRSM_LDS_FLOATS * sizeof(float);
+    const size_t lds_trsm = (size_t)TRSM_LDS_FLOATS * sizeof(float), lds_trsm1 = ((size_t)TRSM_LDS_FLOATS + 8 * IB * (IB + 1)) * sizeof(float);
     (void)hipFuncSetAttribute((const void*)potrf_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)trsm_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)potrf_tile2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -69,7 +70,7 @@ int main(int argc, char** argv)
             if (ver == 1) hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(512), lds_potrf, 0, d, (long long)n, 0, st);
             else hipLaunchKernelGGL(potrf_tile2_kernel, dim3(1), dim3(512), lds_potrf2, 0, d, (long long)n, 0, st);      // (ver 2 and 3)
             (void)hipEventRecord(e1, 0);
-            if (ver == 1) hipLaunchKernelGGL(trsm_tile_kernel, dim3(T - 1 + 1), dim3(512), lds_trsm, 0, d, (long long)n, 0, 1, T - 1, winv, 1, st);
+            if (ver == 1) hipLaunchKernelGGL(trsm_tile_kernel, dim3(T - 1 + 1), dim3(512), lds_trsm1, 0, d, (long long)n, 0, 1, T - 1, winv, 1, st);
             else if (ver == 2) hipLaunchKernelGGL(trsm_tile2_kernel<8>, dim3(T - 1 + 1), dim3(512), lds_trsm, 0, d, (long long)n, 0, 1, T - 1, winv, 1, st);
             else hipLaunchKernelGGL(trsm_tile2_kernel<4>, dim3(2 * (T - 1 + 1)), dim3(256), lds_trsm, 0, d, (long long)n, 0, 1, T - 1, winv, 1, st);
             (void)hipEventRecord(e2, 0);

@@ -3,6 +3,7 @@
 // wrong.  It located the missing wavefront-scope fences of round 2.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17
 // -ffp-contract=off -I include -o scripts/ubench/bin/potrf_tile_test scripts/ubench/potrf_tile_test.hip
 #include "../../superviseddescent_amd/csrc/sdm_solve.hip"
+#include "chain_gen1.inc"      // (generation 1, the kernel this check was written for; scripts/ubench/chain_stamps.hip checks both generations)
 #include <vector>
 #include <cmath>
 #include <cstdio>

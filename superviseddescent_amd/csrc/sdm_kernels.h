@@ -259,7 +259,6 @@ struct SolveAux {
     void* upd_planes; unsigned* upd_maxdiag;      // (upd_maxdiag: 4 words -- largest diagonal entry, two right-hand-side scale slots, smallest diagonal entry)
     int* range_fallbacks;                          // host counter: factorisations whose diagonal spanned > 2^20 and therefore ran their updates in f32 (may be null)
     int upd_f32_only;                              // A/B (SDM_UPDATE_F32=1, read at sdm_create): every trailing update on the f32 matrix-core kernel
-    int chain_v1;                                  // A/B (SDM_SOLVE_CHAIN_V1=1): the round-2/3 potrf / panel-solve kernels
     int upd_min_tiles;                             // A/B (SDM_SOLVE_UPD_MIN_TILES): trailing tiles from which the float16-piece update runs (0: the default)
 };
 size_t sdm_update_f16_plane_bytes(int rows_max, int ncols);

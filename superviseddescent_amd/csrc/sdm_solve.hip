@@ -359,11 +359,10 @@ __global__ void add_diag_kernel(float* __restrict__ G, long long ldg, int F, int
 // =====================================================================================================
 // Tile kernels of the blocked Cholesky / substitutions.
 //
-// A 128 x 128 tile step is latency bound, not flop bound (128^3/3 flops is nothing): the first two versions walked
-// the 128 elimination steps with one or three barriers each and took 80-400 us per tile (profiles/r01_*).  These
-// kernels are blocked by 16 inside the tile and give every thread ONE column: the 16 x 16 triangular solves and the
-// rank-16 updates of a column are thread-local register arithmetic fed by broadcast LDS reads (ds_read_b128 of 16
-// consecutive coefficients), so a tile needs 16 barriers (potrf) or none at all (the substitutions).
+// A 128 x 128 tile step is latency bound, not flop bound (128^3/3 flops is nothing): what it costs is the chain of dependent
+// operations every 128-column step of the factorisation waits for.  Round 1 walked the 128 elimination steps with one or three
+// barriers each (80-400 us per tile); rounds 2-3 blocked the tile by 16 with one column per lane (28.7 / 15.2 us for factor /
+// tile-row solve); the kernels below keep the tile in the matrix-core accumulator layout throughout (20.7 / 11.3 us).
 // =====================================================================================================
 #define IB 16                      // inner block
 #define NIB (TILE / IB)
@@ -379,290 +378,16 @@ __device__ unsigned long long g_solve_stamps[64];
 
 typedef float f32x4s __attribute__((ext_vector_type(4)));
 
-__device__ inline void ld16(const float* p, float (&v)[IB])
-{
-#pragma unroll
-    for (int q = 0; q < IB / 4; ++q) {
-        const f32x4s t = *(const f32x4s*)(p + 4 * q);
-        v[4 * q] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
-    }
-}
-__device__ inline void st16(float* p, const float (&v)[IB])
-{
-#pragma unroll
-    for (int q = 0; q < IB / 4; ++q) *(f32x4s*)(p + 4 * q) = (f32x4s){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-}
-
-// Lanes of ONE wave exchanging data through LDS: the hardware executes a wave's LDS instructions in order, but the compiler
-// reasons per thread (it may forward a thread's own earlier store to its later load of the same address, past another lane's
-// store in between): a wavefront-scope release / acquire pair makes the exchange visible to it.  No workgroup barrier.
-__device__ inline void wave_lds_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// ---- Cholesky of one diagonal tile (upper: G_kk = U^T U) ---------------------------------------------------------------
-// One workgroup of 8 waves; the upper triangle is 36 tiles of 16 x 16 and never leaves the registers: wave w owns the tiles
-// (rb, w), rb <= w, of block column w as matrix-core accumulators.  Per 16-wide step j:
-//   (a) wave j factors its diagonal tile -- one lane per column, pivots and the scaled pivot row travel through v_readlane;
-//   (b) every wave w > j solves its tile (j, w) against that factor (one lane per column, coefficients broadcast from LDS)
-//       and publishes it as a panel row block in LDS;
-//   (c) every wave w > j applies the rank-16 update to its tiles (rb, w), j < rb <= w, with v_mfma_f32_16x16x4_f32 (operands
-//       straight from the panel).
-// Two barriers per step, 64 KB less LDS than the version that kept the working tile there, and the trailing update -- the
-// only part with flops -- no longer walks LDS element by element: 50 -> 38.5 us per tile, on the chain of every 128-column step
-// (what remains is the serial 16 x 16 factor of (a): 16 pivots x (sqrt, divide, 15 v_readlane + FMA), eight times).
-// An accumulator tile is turned into "one column per lane" (and back) through 1 KB of wave-private LDS.
-#define PQ 4
+// (matrix-core tile kernels of the chain: generation 2 below; generation 1 -- rounds 2-3, one column per lane, 16 barriers per tile --
+//  lives on in scripts/ubench/chain_gen1.inc for the side-by-side ubench)
+#define PQ 4                      // waves of a tile kernel = TILE * PQ / 64 = 8
 #define POTRF_PLD (TILE + 16)     // row stride of the panel in LDS (fragment reads of two 16-column halves: disjoint banks)
-__global__ void __launch_bounds__(TILE * PQ)
-potrf_tile_kernel(float* __restrict__ G, long long ldg, int k0, int* __restrict__ status)
-{
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* P = sm;                               // [16][POTRF_PLD]  current panel: P[m][c] = U[j0 + m][c]
-    float* Dt = P + IB * POTRF_PLD;              // [16][16]         factor of the current diagonal block, transposed: Dt[i][q] = U[j0+q][j0+i], q < i; Dt[i][i] = 1 / U[j0+i][j0+i]
-    float* badf = Dt + IB * IB;                  // "not positive definite" flag
-    float* scratch = badf + 4;                   // [8 waves][16][17]
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int li = lane & 15, lq = lane >> 4;
-    float* Gk = G + (long long)k0 * ldg + k0;
-    float* S = scratch + wave * IB * (IB + 1);
-    if (t == 0) *badf = 0.0f;
-    SOLVE_STAMP(0);
-    // this wave's tiles in C/D layout: acc[rb][e] = T[16 rb + 4 lq + e][16 wave + li], rb <= wave
-    f32x4 acc[NIB];
-#pragma unroll
-    for (int rb = 0; rb < NIB; ++rb)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            acc[rb][e] = rb <= wave ? Gk[(long long)(IB * rb + 4 * lq + e) * ldg + IB * wave + li] : 0.0f;
-    __syncthreads();
-    SOLVE_STAMP(1);
-#pragma unroll
-    for (int jb = 0; jb < NIB; ++jb) {
-        // (a) the diagonal tile: accumulator layout -> lane i holds column i -> factor -> Dt (for the others) and back
-        if (wave == jb) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) S[(4 * lq + e) * (IB + 1) + li] = acc[jb][e];
-            wave_lds_sync();
-            float d[IB];
-#pragma unroll
-            for (int r = 0; r < IB; ++r) d[r] = S[r * (IB + 1) + li];
-            wave_lds_sync();
-            bool bad = false;
-#pragma unroll
-            for (int s_ = 0; s_ < IB; ++s_) {
-                const float piv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d[s_]), s_));
-                // (hardware sqrt / reciprocal, <= 1 ulp each: this is the engine's own factor, pinned to nothing bit-wise, and
-                //  the IEEE sequences are a third of the serial pivot step every 128-column step of the solve waits for)
-                const float sd = __builtin_amdgcn_sqrtf(piv);
-                // v_sqrt_f32 / v_rcp_f32 flush denormals: a pivot below FLT_MIN would give sd = 0, 1 / sd = inf and a factor full
-                // of inf / NaN with the status never set -- such a pivot is "not positive definite" here
-                bad = bad || !(piv >= 1.17549435e-38f);
-                const float u = (li == s_) ? sd : d[s_] * __builtin_amdgcn_rcpf(sd);          // U[s][i] for i >= s
-                d[s_] = u;
-#pragma unroll
-                for (int r = s_ + 1; r < IB; ++r) {
-                    const float ur = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u), r));   // U[s][r]
-                    d[r] -= ur * u;                                   // meaningful for i >= r
-                }
-            }
-            if (bad && lane == 0) *badf = 1.0f;
-            if (lane < IB) {
-#pragma unroll
-                for (int r = 0; r < IB; ++r) {
-                    const float v = (li >= r) ? d[r] : 0.0f;
-                    Dt[li * IB + r] = (li == r) ? __builtin_amdgcn_rcpf(v) : v;      // (the panel solve multiplies by the diagonal's reciprocal)
-                    S[r * (IB + 1) + li] = v;
-                }
-            }
-            wave_lds_sync();
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[jb][e] = S[(4 * lq + e) * (IB + 1) + li];
-        }
-        __syncthreads();
-        SOLVE_STAMP(2 + 2 * jb);
-        if (*badf != 0.0f) {
-            // (the NaN travels with the tile: the other ranks of a sharded factorisation see the failure in trsm_tile_kernel)
-            if (t == 0) { atomicOr(status, 2); Gk[0] = __builtin_nanf(""); }
-            return;
-        }
-        if (jb + 1 == NIB) break;
-        // (b) panel: tile (jb, wave) for wave > jb: U[j0+m][c] = (T[j0+m][c] - sum_{p<m} U[j0+p][j0+m] U[j0+p][c]) / U[j0+m][j0+m]
-        if (wave > jb) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) S[(4 * lq + e) * (IB + 1) + li] = acc[jb][e];
-            wave_lds_sync();
-            float y[IB];
-#pragma unroll
-            for (int m = 0; m < IB; ++m) y[m] = S[m * (IB + 1) + li];
-            wave_lds_sync();
-#pragma unroll
-            for (int m = 0; m < IB; ++m) {
-                float dcol[IB];
-                ld16(Dt + m * IB, dcol);                              // U[j0+p][j0+m], p < m; 1 / U[j0+m][j0+m] at p = m
-                float a_ = y[m];
-#pragma unroll
-                for (int p_ = 0; p_ < m; ++p_) a_ -= dcol[p_] * y[p_];
-                y[m] = a_ * dcol[m];
-            }
-            if (lane < IB) {
-#pragma unroll
-                for (int m = 0; m < IB; ++m) {
-                    S[m * (IB + 1) + li] = y[m];
-                    P[m * POTRF_PLD + IB * wave + li] = y[m];
-                }
-            }
-            wave_lds_sync();
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[jb][e] = S[(4 * lq + e) * (IB + 1) + li];
-        }
-        __syncthreads();
-        SOLVE_STAMP(3 + 2 * jb);
-        // (c) trailing update of this wave's tiles (rb, wave), jb < rb <= wave: T -= P_rb^T P_wave
-        if (wave > jb) {
-            float bop[4];
-#pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_) bop[s_] = -P[(4 * s_ + lq) * POTRF_PLD + IB * wave + li];
-#pragma unroll
-            for (int rb = jb + 1; rb < NIB; ++rb)
-                if (rb <= wave) {
-#pragma unroll
-                    for (int s_ = 0; s_ < 4; ++s_)
-                        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(P[(4 * s_ + lq) * POTRF_PLD + IB * rb + li], bop[s_], acc[rb], 0, 0, 0);
-                }
-        }
-        // (the next step's (a) touches only its own wave's registers and scratch; P is rewritten after the next barrier)
-    }
-    // store: the upper triangle from the accumulators, zeros below the diagonal (mirror tiles included)
-#pragma unroll
-    for (int rb = 0; rb < NIB; ++rb)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int r = IB * rb + 4 * lq + e, c = IB * wave + li;
-            if (rb <= wave) Gk[(long long)r * ldg + c] = (c >= r) ? acc[rb][e] : 0.0f;
-            else Gk[(long long)r * ldg + c] = 0.0f;
-        }
-    SOLVE_STAMP(20);
-}
-
-// ---- panel solve: G[k0:k0+128, tj*128 : +128] <- U_kk^-T * (same), on the matrix cores --------------------------------
-// Forward substitution with L = U_kk^T, blocked by 16: Y_j = D_j^-T B_j, then B_r -= L_rj Y_j for the row blocks r > j.  The
-// columns of the right-hand side are independent, so wave w takes the 16 columns 16w .. 16w+15 of the tile through all
-// eight steps without a single workgroup barrier; its 128 x 16 strip lives in registers as eight 16 x 16 accumulator tiles.
-// Both products of a step are v_mfma_f32_16x16x4_f32: the 16 x 16 triangular solve becomes a product with the inverse of
-// the diagonal block D_j (the workgroup's first 128 threads invert the eight blocks once, 136 dependent FMAs each, as the
-// blocked solvers of the GPU linear-algebra libraries do), the update a (112 - 16 j) x 16 x 16 product with L from LDS.
-// Turning an accumulator tile into a B operand is a trip through 1 KB of wave-private LDS.  13.7 us per tile (the scalar
-// substitution it replaces: 37.6 us), and the panel solve is on the chain every 128-column step waits for.
-// The extra last workgroup solves for the identity instead and stores U_kk^-T into winv_t: the back substitution then
-// needs only products, no serial solves.
-// Round 3: U_kk sits in LDS as its 36 upper 16 x 16 blocks only (block (jb, rb), rb >= jb, row-major 16 x 16; the fragment reads
-// of a block -- rows 4s + lq, column li -- fall into 32 different banks per half wave), 54 KB with the inverses and the waves'
-// scratch instead of 91 KB: a panel-solve workgroup now fits on a CU beside ONE trailing-update workgroup (64 KB), i.e. it is
-// placed as soon as one of the two finishes instead of waiting for both while the dispatcher refills the freed half.
+// U_kk in LDS as its 36 upper 16 x 16 blocks only (block (jb, rb), rb >= jb, row-major 16 x 16): 54 KB with the transposed diagonal blocks
 __host__ __device__ constexpr int trsm_blk(int jb, int rb) { return jb * (17 - jb) / 2 + rb - jb; }
-#define TRSM_LDS_FLOATS (36 * IB * IB + NIB * IB * IB + 8 * IB * (IB + 1))
-__global__ void __launch_bounds__(TILE * PQ)
-trsm_tile_kernel(float* __restrict__ G, long long ldg, int k0, int tile_j0, int n_tiles, float* __restrict__ winv_t, int own_stride,
-                 int* __restrict__ status)
-{
-    // workgroup b < n_tiles: tile column tile_j0 + b * own_stride (the caller's columns: all of them, or the owned ones)
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* Up = sm;                              // [36 blocks][16][16]   the upper blocks of U_kk
-    float* Dinv = sm + 36 * IB * IB;             // [8][16][16]      inverses of the diagonal blocks: Dinv[j][r][c] = (D_j^-1)[r][c]
-    float* scratch = Dinv + NIB * IB * IB;       // [8 waves][16][16 + 1]
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int li = lane & 15, lq = lane >> 4;
-    const bool inverse = (int)blockIdx.x == n_tiles;
-    const long long j0g = (long long)(tile_j0 + (int)blockIdx.x * own_stride) * TILE;
-    const float* Gk = G + (long long)k0 * ldg + k0;
-    if (inverse && t == 0 && !(Gk[0] == Gk[0])) atomicOr(status, 2);      // the owner's potrf reported "not positive definite"
-    float* B = inverse ? winv_t : G + (long long)k0 * ldg + j0g;
-    const long long ldb = inverse ? TILE : ldg;
-    SOLVE_STAMP(32);
-    // this wave's strip in C/D layout: acc[rb][e] = B[16 rb + 4 lq + e][16 wave + li]
-    f32x4 acc[NIB];
-#pragma unroll
-    for (int rb = 0; rb < NIB; ++rb)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int r = IB * rb + 4 * lq + e, c = IB * wave + li;
-            acc[rb][e] = inverse ? (r == c ? 1.0f : 0.0f) : B[(long long)r * ldb + c];
-        }
-    const int lr = t >> 5, lc = (t & 31) * 4;
-#pragma unroll 8
-    for (int r = lr; r < TILE; r += 16) {
-        const int jb_ = r >> 4, rb_ = lc >> 4;           // (r >> 4 is the unrolled trip number: a constant)
-        if (rb_ >= jb_) *(f32x4s*)(Up + trsm_blk(jb_, rb_) * IB * IB + (r & 15) * IB + (lc & 15)) = *(const f32x4s*)(Gk + (long long)r * ldg + lc);
-    }
-    __syncthreads();
-    SOLVE_STAMP(33);
-    if (t < NIB * IB) {
-        // column i of the inverse of the upper triangular block D = U[j0 .. j0+15][j0 .. j0+15]: back substitution for e_i
-        const int jb = t >> 4, i = t & 15;
-        float x[IB], rd[IB];
-        const float* Dj = Up + trsm_blk(jb, jb) * IB * IB;                                                  // the diagonal block D_jb
-#pragma unroll
-        for (int r = 0; r < IB; ++r) rd[r] = __builtin_amdgcn_rcpf(Dj[r * IB + r]);      // off the serial chain below
-#pragma unroll
-        for (int r = IB - 1; r >= 0; --r) {
-            float sacc = (r == i) ? 1.0f : 0.0f;
-#pragma unroll
-            for (int m = r + 1; m < IB; ++m) sacc -= Dj[r * IB + m] * x[m];     // (x[m] = 0 for m > i)
-            x[r] = (r <= i) ? sacc * rd[r] : 0.0f;
-        }
-#pragma unroll
-        for (int r = 0; r < IB; ++r) Dinv[(jb * IB + r) * IB + i] = x[r];
-    }
-    __syncthreads();
-    SOLVE_STAMP(34);
-    float* S = scratch + wave * IB * (IB + 1);
-#pragma unroll
-    for (int jb = 0; jb < NIB; ++jb) {
-        // B_j (accumulator layout) -> B operand: k-step s needs rows 4 s + lq
-#pragma unroll
-        for (int e = 0; e < 4; ++e) S[(4 * lq + e) * (IB + 1) + li] = acc[jb][e];
-        wave_lds_sync();
-        float bop[4], aop[4];
-#pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_) {
-            bop[s_] = S[(4 * s_ + lq) * (IB + 1) + li];
-            aop[s_] = Dinv[(jb * IB + 4 * s_ + lq) * IB + li];            // A[row li][k] = (D^-T)[li][k] = Dinv[k][li]
-        }
-        f32x4 y = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_) y = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[s_], bop[s_], y, 0, 0, 0);
-        acc[jb] = y;
-        if (jb + 1 < NIB) {
-            wave_lds_sync();          // (the reads of B_j above are done before the slot is rewritten)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) S[(4 * lq + e) * (IB + 1) + li] = y[e];
-            wave_lds_sync();
-#pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_) bop[s_] = -S[(4 * s_ + lq) * (IB + 1) + li];
-            wave_lds_sync();
-            // B_r -= L_rj Y_j:  A[row li][k] = L[16 rb + li][j0 + k] = U[j0 + k][16 rb + li]
-#pragma unroll
-            for (int rb = jb + 1; rb < NIB; ++rb)
-#pragma unroll
-                for (int s_ = 0; s_ < 4; ++s_)
-                    acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Up[trsm_blk(jb, rb) * IB * IB + (4 * s_ + lq) * IB + li], bop[s_], acc[rb], 0, 0, 0);
-        }
-    }
-    SOLVE_STAMP(35);
-#pragma unroll
-    for (int rb = 0; rb < NIB; ++rb)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) B[(long long)(IB * rb + 4 * lq + e) * ldb + IB * wave + li] = acc[rb][e];
-    SOLVE_STAMP(36);
-}
-
+#define TRSM_LDS_FLOATS (36 * IB * IB + NIB * IB * IB)
 
 // =====================================================================================================
-// Round 5: the two chain kernels again.  Three changes against the first generation above, all on the serial path every 128-column step
+// Round 5: the two chain kernels again.  Changes against the first generation (scripts/ubench/chain_gen1.inc), all on the serial path every 128-column step
 // of the factorisation waits for (scripts/ubench/chain_stamps.hip prices them; profiles/r05_experiments.txt):
 //
 //  1. The tile never leaves the matrix-core accumulator layout.  D[row 4 lq + e][column li] is what a lane holds; a product
@@ -1252,14 +977,10 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
     const int Tf = (F + TILE - 1) / TILE;          // factor tiles
     const int ncols = rhs0 + TILE * ((nrhs + TILE - 1) / TILE);   // factor tiles + one or two RHS tile columns
     const int T = ncols / TILE;
-    const size_t lds_potrf = ((size_t)IB * POTRF_PLD + IB * IB + 4 + 8 * IB * (IB + 1)) * sizeof(float);
     const size_t lds_trsm = (size_t)TRSM_LDS_FLOATS * sizeof(float);
     const size_t lds_potrf2 = (size_t)POTRF2_LDS_FLOATS * sizeof(float);
-    const bool v2 = !(aux && aux->chain_v1);      // round 5: the chain kernels with the diagonal blocks' inverses as a by-product (A/B: SDM_SOLVE_CHAIN_V1=1)
     static unsigned long long attr_seen = 0;
     if (sdm_first_use_on_device(attr_seen)) {
-        SDM_SET_ATTR((const void*)potrf_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        SDM_SET_ATTR((const void*)trsm_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         SDM_SET_ATTR((const void*)potrf_tile2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         SDM_SET_ATTR((const void*)trsm_tile2_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
@@ -1318,10 +1039,7 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
         // bring tile row k up to date with the panels g0 .. k-1 of its group (owned columns; the owner of column k first:
         // its tile (k, k) is what the chain waits for)
         if (nb && mine) sdm_launch_syrk_tn(G + (long long)g0 * TILE * ldg, ldg, nb * TILE, ncols, G, ldg, -1.0f, 1, k, stream, 1, me, W);
-        if (mine || shard->emulate_chain) {
-            if (v2) hipLaunchKernelGGL(potrf_tile2_kernel, dim3(1), dim3(TILE * PQ), lds_potrf2, stream, G, ldg, k0, status);
-            else hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(TILE * PQ), lds_potrf, stream, G, ldg, k0, status);
-        }
+        if (mine || shard->emulate_chain) hipLaunchKernelGGL(potrf_tile2_kernel, dim3(1), dim3(TILE * PQ), lds_potrf2, stream, G, ldg, k0, status);
         if (shard) {
             // tiles (g0 .. k, k): the group's panel rows in column k, then the factored diagonal tile
             if (mine) hipLaunchKernelGGL(tiles_gather_kernel, dim3(1, nb + 1, 1), dim3(256), 0, stream, G, ldg, shard->stage, g0, nb + 1, k, k + 1, 1, 0, 1, 0, -1);
@@ -1336,10 +1054,8 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
         // the panel tiles of the owned columns + one workgroup that produces U_kk^-T for the back substitution
         const int first = k + 1 + ((((me - (k + 1)) % W) + W) % W);             // first owned column right of k
         const int nown = first < T ? (T - first + W - 1) / W : 0;
-        if (v2) hipLaunchKernelGGL(trsm_tile2_kernel<4>, dim3(2 * (nown + 1)), dim3(256), lds_trsm, stream, G, ldg, k0, first, nown,
-                                   work + (size_t)k * TILE * TILE, W, status);
-        else hipLaunchKernelGGL(trsm_tile_kernel, dim3(nown + 1), dim3(TILE * PQ), lds_trsm, stream, G, ldg, k0, first, nown,
-                                work + (size_t)k * TILE * TILE, W, status);
+        hipLaunchKernelGGL(trsm_tile2_kernel<4>, dim3(2 * (nown + 1)), dim3(256), lds_trsm, stream, G, ldg, k0, first, nown,
+                           work + (size_t)k * TILE * TILE, W, status);
         const bool group_end = (k + 1) % LAZY == 0 || k == Tf - 1;
         if (group_end && ntr > 0) {   // trailing update of all tiles (ti >= k+1, tj >= ti) from the group's panel rows
             const float* panels = G + (long long)g0 * TILE * ldg;

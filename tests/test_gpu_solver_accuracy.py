@@ -1,5 +1,5 @@
-"""The blocked Cholesky behind sdm_solve / sdm_solve_normal_equations (csrc/sdm_solve.hip: potrf_tile_kernel with the tile in
-matrix-core accumulators, trsm_tile_kernel with inverted 16 x 16 diagonal blocks, MFMA substitutions) against an f64 solve of
+"""The blocked Cholesky behind sdm_solve / sdm_solve_normal_equations (csrc/sdm_solve.hip: potrf_tile2_kernel with the tile in
+matrix-core accumulators, trsm_tile2_kernel with the diagonal blocks' inverses from the factor, MFMA substitutions) against an f64 solve of
 the same normal equations (regressors.hpp:199-234), over sizes that exercise partial tiles, one tile, several tiles and the
 two-queue look-ahead (> 8 tiles).  Well-conditioned systems (condition 2 ... 35).  The yardstick is what f32 storage of the
 Gram matrix costs by itself: the f64 solve of the f32-accumulated system is 0.5 ... 1.7e-6 away from the f64 solution
