@@ -666,11 +666,16 @@ backsolve_persistent_kernel(const float* __restrict__ G, long long ldg, int Tf, 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 15, lq = lane >> 4;
     __shared__ int ticket_sh;
-    if (t == 0) ticket_sh = atomicAdd(flags + (size_t)gridDim.y * Tf + blockIdx.y, 1);      // (the counters sit behind the flags, cleared with them)
+    // Grid (chunk, tile row): the dispatcher walks x fastest, so the chunks' workgroups start INTERLEAVED.  (As (tile row, chunk) -- rounds
+    // 3-4 -- all rows of chunk 0 were placed first; with one 108 KB workgroup per compute unit 256 of RCR-68's 2 x 213 workgroups are
+    // resident, chunk 1 got its rows only as chunk 0's finished, each late row had a hundred published R_k to catch up with, and the two
+    // chunks ran almost one after the other: 44 us per tile row where a row's work is ~20.)
+    const int chunk = blockIdx.x, nchunks = gridDim.x;
+    if (t == 0) ticket_sh = atomicAdd(flags + (size_t)nchunks * Tf + chunk, 1);      // (the counters sit behind the flags, cleared with them)
     __syncthreads();
     const int i = Tf - 1 - ticket_sh;                  // tile row of this workgroup
-    const int col0 = (int)blockIdx.y * ncb;            // first right-hand-side column of this chunk
-    int* flag = flags + (size_t)blockIdx.y * Tf;
+    const int col0 = chunk * ncb;                      // first right-hand-side column of this chunk
+    int* flag = flags + (size_t)chunk * Tf;
     const long long i0 = (long long)i * TILE;
     const int lr = t >> 5, lc = (t & 31) * 4;          // staging: thread -> rows lr + 16 q, columns lc .. lc + 3
     // Y_i into the accumulators: wave w owns rows 16 w .. 16 w + 15; C/D layout row = 4 lq + e, col = li
@@ -1135,7 +1140,7 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
             BSPATTR(1); BSPATTR(2); BSPATTR(3); BSPATTR(4); BSPATTR(5);
 #undef BSPATTR
         }
-#define BSP(NJv) hipLaunchKernelGGL(backsolve_persistent_kernel<NJv>, dim3(Tf, nchunks), dim3(BSP_WAVES * 64),                         \
+#define BSP(NJv) hipLaunchKernelGGL(backsolve_persistent_kernel<NJv>, dim3(nchunks, Tf), dim3(BSP_WAVES * 64),                         \
                                     ((size_t)TILE * (TILE + 4) + (size_t)TILE * NJv * 16) * sizeof(float), stream, G, ldg, Tf, rhs0 + rhs_shift, \
                                     16 * nj < nrhs - rhs_shift ? 16 * nj : nrhs - rhs_shift, work, R_out + rhs_shift, ldr, flags, status)
         if (nchunks)
