@@ -71,7 +71,7 @@ struct sdm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    SolveAux solve_aux = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};   // second queue of the Cholesky look-ahead (+ the scratch of its float16 updates, set per solve)
+    SolveAux solve_aux = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};   // second queue of the Cholesky look-ahead (+ the scratch of its float16 updates, set per solve)
     DevBuf<unsigned char> upd_planes;    // one panel group as float16 planes (sdm_update_f16_plane_bytes)
     DevBuf<unsigned> upd_maxdiag;
 
@@ -540,6 +540,8 @@ sdm_ctx* sdm_create(int device)
     c->env_gram_bf16 = env_on("SDM_GRAM_BF16X3");
     c->solve_aux.upd_f32_only = env_on("SDM_UPDATE_F32") ? 1 : 0;
     { const char* v = getenv("SDM_SOLVE_UPD_MIN_TILES"); c->solve_aux.upd_min_tiles = v ? atoi(v) : 0; }
+    { const char* v = getenv("SDM_SOLVE_FINE_HEAD"); c->solve_aux.fine_head_max = v ? atoi(v) : 0; }
+    { const char* v = getenv("SDM_SOLVE_BS_CAP"); c->solve_aux.bs_cap = v ? atoi(v) : 0; }
     { const char* v = getenv("SDM_SOLVE_SHARD_EMULATE"); c->env_shard_emulate = v ? atoi(v) : 0; }
     return c;
 }

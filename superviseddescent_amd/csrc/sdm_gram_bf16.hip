@@ -434,9 +434,12 @@ __global__ void __launch_bounds__(256) block_absmax_kernel(const float* __restri
 
 __global__ void __launch_bounds__(256)
 split_planes_f16_scaled_kernel(const float* __restrict__ A, long long lda, int N, int ncols_src, int ncols, int NG, f16x8* __restrict__ planes,
-                               const unsigned* __restrict__ scales, int slot, int rhs_col0, int* __restrict__ status)
+                               unsigned* __restrict__ scales, int slot, int rhs_col0, int* __restrict__ status, int clear_other_slot)
 {
     const int col = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+    // (the other slot's last reader -- the previous group's tail update -- has finished before this launch; its next writers, the
+    //  next group's panel solves, start behind it)
+    if (clear_other_slot && col == 0 && g == 0) scales[1 + (slot ^ 1)] = 0;
     if (col >= ncols) return;
     const float scale = __builtin_ldexpf(1.0f, 14 - (col >= rhs_col0 ? f16_rhs_exponent(scales, slot) : f16_factor_exponent(scales)));
     f16x8 p1, p2;
@@ -509,6 +512,85 @@ syrk_update_f16_kernel(const bf16x8* __restrict__ planes, int NG, int ncols2, in
     if (!writes) return;
     const int ef = f16_factor_exponent(scales);
     const float unscale = __builtin_ldexpf(1.0f, (ef - 14) + ((j >= TlocF ? f16_rhs_exponent(scales, slot) : ef) - 14));
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                Cw[(long long)(m * 32 + (e & 3) + 8 * (e >> 2)) * ldc + n * 32] = cin[m][n][e] - acc[m][n][e] * unscale;
+}
+
+// The same update for the HEAD of the look-ahead (the next group's four tile rows, on the factorisation's serial chain) while the
+// trailing matrix is narrow (round 5).  There the 256 x 128 kernel above is a latency chain of its own: 2 Tloc workgroups on 256
+// compute units, each a full K = 512 pipeline of one tile -- 31 us at F = 8 801 whatever Tloc is.  Here one WAVE owns a 64 x 64
+// sub-tile and is a workgroup by itself: 16 Tloc of them, on every SIMD of the chip; the operands come straight from the planes
+// (the eight k-rows of a column a lane feeds to the matrix core are 16 contiguous bytes: one global_load_dwordx4 per fragment, no
+// LDS, no barrier), four k-steps in flight.  Twice the operand bytes per product of the tiled kernel, which is why the wide
+// updates stay there.  Sub-tiles are dealt to the XCDs by column range (an XCD's L2 holds its eighth of the column planes + the
+// four row panels).  One accumulator level (K <= 512), per k-step low x high, high x low, high x high.
+__global__ void __launch_bounds__(64)
+syrk_update_f16_fine_kernel(const f16x8* __restrict__ planes, int NG, int ncols2, int TlocF, float* __restrict__ C, long long ldc,
+                            const unsigned* __restrict__ scales, int slot, int row_lo, int SR, int own_first, int own_stride, int SC, int per)
+{
+    // XCD x = blockIdx.x % 8 serves the owned sub-columns x, x + 8, ... (the triangle's short and long columns alike), each with the SR sub-rows
+    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int sc = (q / SR) * 8 + x, sr = q - (q / SR) * SR;
+    if (q / SR >= per || sc >= SC) return;
+    const int j = own_first + (sc >> 1) * own_stride;                         // local tile column
+    const int ri = (row_lo + (sr >> 1)) * 128 + (sr & 1) * 64;                // first row / column of the sub-tile in the trailing matrix
+    const int cj = j * 128 + (sc & 1) * 64;
+    if (cj + 64 <= ri) return;                                                // below the diagonal
+    const int lane = threadIdx.x, lc = lane & 31, lh = lane >> 5;
+    const int nks = NG >> 1;                                                  // k-steps of 16 rows (a multiple of 8: whole 128-row panels)
+    const f16x8* pa = planes + (size_t)lh * ncols2 + ri + lc;                 // + (piece NG + 2 ks) ncols2 + 32 m
+    const f16x8* pb = planes + (size_t)lh * ncols2 + cj + lc;
+    const size_t kstride = (size_t)2 * ncols2, pstride = (size_t)NG * ncols2;
+    f16x8 fa[4][2][2], fb[4][2][2];                                           // [stage][piece][fragment]
+    auto fetch = [&](int st, int ks) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                fa[st][p][m] = pa[p * pstride + ks * kstride + 32 * m];
+                fb[st][p][m] = pb[p * pstride + ks * kstride + 32 * m];
+            }
+    };
+#pragma unroll
+    for (int st = 0; st < 4; ++st) fetch(st, st);
+    // this wave's part of C is requested behind the first four k-steps' operands and arrives under the products
+    const int ef = f16_factor_exponent(scales);
+    const float unscale = __builtin_ldexpf(1.0f, (ef - 14) + ((j >= TlocF ? f16_rhs_exponent(scales, slot) : ef) - 14));
+    float* Cw = C + (long long)(ri + 4 * lh) * ldc + cj + lc;
+    f32x16 acc[2][2], cin[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                acc[m][n][e] = 0.0f;
+                cin[m][n][e] = Cw[(long long)(m * 32 + (e & 3) + 8 * (e >> 2)) * ldc + n * 32];
+            }
+    auto products = [&](int st) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[st][1][m], fb[st][0][n], acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[st][0][m], fb[st][1][n], acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[st][0][m], fb[st][0][n], acc[m][n], 0, 0, 0);
+            }
+    };
+    for (int ks0 = 0; ks0 < nks - 4; ks0 += 4) {
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            products(st);
+            fetch(st, ks0 + 4 + st);      // (unconditional: nks is a multiple of 4)
+        }
+    }
+#pragma unroll
+    for (int st = 0; st < 4; ++st) products(st);
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -626,18 +708,20 @@ void sdm_launch_diag_absmax(const float* G, long long ldg, int F, unsigned* scal
 }
 
 void sdm_launch_update_split_f16(const float* P, long long ldp, int rows, int wcols, int wcols_factor, void* planes, unsigned* scales,
-                                 int slot, int* status, hipStream_t stream)
+                                 int slot, int* status, hipStream_t stream, bool rhs_scale_known)
 {
     // P: rows x wcols (the group's panel rows, from the first trailing column on); columns >= wcols_factor are right-hand sides
+    // rhs_scale_known: scales[1 + slot] already holds the largest right-hand-side entry of these rows (the panel solves collected it);
+    // the split kernel then clears the other slot for the next group, as block_absmax_kernel does otherwise
     const int NG = ((rows + 31) / 32) * 4, ncols2 = ((wcols + 255) / 256) * 256;
-    if (wcols > wcols_factor)
+    if (wcols > wcols_factor && !rhs_scale_known)
         hipLaunchKernelGGL(block_absmax_kernel, dim3((rows + 7) / 8), dim3(256), 0, stream, P + wcols_factor, ldp, rows, wcols - wcols_factor, scales, slot);
     hipLaunchKernelGGL(split_planes_f16_scaled_kernel, dim3(ncols2 / 256, NG), dim3(256), 0, stream, P, ldp, rows, wcols, ncols2, NG,
-                       (f16x8*)planes, scales, slot, wcols_factor, status);
+                       (f16x8*)planes, scales, slot, wcols_factor, status, rhs_scale_known ? 1 : 0);
 }
 
 void sdm_launch_update_f16(const void* planes, int rows, int wcols, int wcols_factor, float* C, long long ldc, const unsigned* scales,
-                           int slot, int I_lo, int I_hi, int own_first, int own_stride, hipStream_t stream)
+                           int slot, int I_lo, int I_hi, int own_first, int own_stride, hipStream_t stream, int fine_max_tiles)
 {
     // super-rows I_lo <= I < I_hi of the trailing matrix (local tile rows 2 I, 2 I + 1), local tile columns own_first + n own_stride
     const int NG = ((rows + 31) / 32) * 4, ncols2 = ((wcols + 255) / 256) * 256, Tloc = wcols / GB_TILE, TlocF = wcols_factor / GB_TILE;
@@ -648,6 +732,15 @@ void sdm_launch_update_f16(const void* planes, int rows, int wcols, int wcols_fa
     if (sdm_first_use_on_device(attr))
         SDM_SET_ATTR((const void*)syrk_update_f16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     const int nI = I_hi - I_lo;
+    if ((nI <= 2 || fine_max_tiles >= 1000) && Tloc <= fine_max_tiles % 1000) {      // (>= 1000: experiment -- the tail as well)
+        // the head of the look-ahead over a narrow trailing matrix: one wave per 64 x 64 sub-tile (syrk_update_f16_fine_kernel)
+        const int row_lo = 2 * I_lo, row_hi = 2 * I_hi < TlocF ? 2 * I_hi : TlocF;
+        const int SR = 2 * (row_hi - row_lo), SC = 2 * ((Tloc - own_first + own_stride - 1) / own_stride), per = (SC + 7) / 8;
+        if (SR <= 0 || SC <= 0) return;
+        hipLaunchKernelGGL(syrk_update_f16_fine_kernel, dim3((unsigned)(8 * per * SR)), dim3(64), 0, stream, (const f16x8*)planes, NG, ncols2,
+                           TlocF, C, ldc, scales, slot, row_lo, SR, own_first, own_stride, SC, per);
+        return;
+    }
     unsigned grid;
     int chunk = 0;
     if (nI <= 4) grid = (unsigned)(nI * Tloc);

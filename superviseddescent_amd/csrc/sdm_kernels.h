@@ -231,7 +231,7 @@ void sdm_launch_add_diag(float* G, long long ldg, int F, const double* fro2, int
 // Blocked Cholesky G = U^T U on the upper triangle of the leading F x F block, with the
 // forward substitution fused into the panel updates for the extra columns [rhs0, rhs0+nrhs),
 // then back substitution; R_out [F][ldr].  work: ceil(F/128) * 128 * 128 floats (inverted diagonal tiles) + sdm_backsolve_flag_floats(Fp)
-// (one int per tile row and right-hand-side chunk: the persistent back substitution's flags).
+// (one int per tile row and right-hand-side chunk: the persistent back substitution's flags; two more tiles per tile row: its pre-multiplied operands).
 // hipFuncSetAttribute (dynamic LDS above 64 KB) is per device: true the first time a call site runs on the current one
 inline bool sdm_first_use_on_device(unsigned long long& seen)
 {
@@ -260,13 +260,15 @@ struct SolveAux {
     int* range_fallbacks;                          // host counter: factorisations whose diagonal spanned > 2^20 and therefore ran their updates in f32 (may be null)
     int upd_f32_only;                              // A/B (SDM_UPDATE_F32=1, read at sdm_create): every trailing update on the f32 matrix-core kernel
     int upd_min_tiles;                             // A/B (SDM_SOLVE_UPD_MIN_TILES): trailing tiles from which the float16-piece update runs (0: the default)
+    int bs_cap;                                    // A/B (SDM_SOLVE_BS_CAP): right-hand-side column tiles per back-substitution workgroup (0: the default, 5)
+    int fine_head_max;                             // A/B (SDM_SOLVE_FINE_HEAD): widest trailing matrix (tiles) whose look-ahead head runs one wave per 64 x 64 sub-tile (0: the default, < 0: never)
 };
 size_t sdm_update_f16_plane_bytes(int rows_max, int ncols);
 void sdm_launch_diag_absmax(const float* G, long long ldg, int F, unsigned* scales, hipStream_t stream);
 void sdm_launch_update_split_f16(const float* P, long long ldp, int rows, int wcols, int wcols_factor, void* planes, unsigned* scales,
-                                 int slot, int* status, hipStream_t stream);
+                                 int slot, int* status, hipStream_t stream, bool rhs_scale_known = false);
 void sdm_launch_update_f16(const void* planes, int rows, int wcols, int wcols_factor, float* C, long long ldc, const unsigned* scales,
-                           int slot, int I_lo, int I_hi, int own_first, int own_stride, hipStream_t stream);
+                           int slot, int I_lo, int I_hi, int own_first, int own_stride, hipStream_t stream, int fine_max_tiles = 0);
 // Sharded factorisation: every rank holds the same regularised system; rank r performs the tile operations of
 // the tile columns j with j % world == r.  Per 128-column step the owner of the step's column broadcasts its factored
 // diagonal tile and the column's tiles of the open panel group (<= 4 tiles); per group of 4 steps the ranks all-gather the
@@ -284,7 +286,10 @@ struct SolveShard {
 };
 inline size_t sdm_solve_shard_stage_tiles(int ncols, int world) { return (size_t)(world + 1) * 4 * (size_t)(ncols / 128 / world + 1); }
 // returns 0, or the non-zero result of a failed collective
-inline size_t sdm_backsolve_flag_floats(int Fp) { return (size_t)9 * (size_t)(Fp / 128) + 64; }      // (<= 144 right-hand sides = 9 column tiles: <= 9 chunks)
+// (the flags: <= 144 right-hand sides = 9 column tiles: <= 9 chunks; behind them two 128 x 128 tiles per tile row: the back substitution's
+//  pre-multiplied operands U_ii^-1 U_{i,i+1}, U_ii^-1 U_{i,i+2})
+inline size_t sdm_backsolve_flag_ints(int Fp) { return (((size_t)9 * (size_t)(Fp / 128) + 64) + 3) & ~(size_t)3; }
+inline size_t sdm_backsolve_flag_floats(int Fp) { return sdm_backsolve_flag_ints(Fp) + (size_t)2 * (size_t)(Fp / 128) * 128 * 128; }
 int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs, float* R_out,
                               long long ldr, float* work, int* status, hipStream_t stream, const SolveAux* aux = nullptr,
                               const SolveShard* shard = nullptr);

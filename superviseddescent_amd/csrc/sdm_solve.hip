@@ -18,6 +18,8 @@
 //
 // Only 128 x 128 tiles with tile-row <= tile-column are computed and stored (upper triangle).
 #include "sdm_kernels.h"
+#include <vector>
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace {
@@ -556,7 +558,7 @@ potrf_tile2_kernel(float* __restrict__ G, long long ldg, int k0, int* __restrict
 template <int NW>
 __global__ void __launch_bounds__(64 * NW)
 trsm_tile2_kernel(float* __restrict__ G, long long ldg, int k0, int tile_j0, int n_tiles, float* __restrict__ winv_t, int own_stride,
-                  int* __restrict__ status)
+                  int* __restrict__ status, unsigned* __restrict__ rhs_absmax, int rhs_tile0)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* Up = sm;                              // [36 blocks][16][16]   the upper blocks of U_kk
@@ -636,33 +638,97 @@ trsm_tile2_kernel(float* __restrict__ G, long long ldg, int k0, int tile_j0, int
     for (int rb = 0; rb < NIB; ++rb)
 #pragma unroll
         for (int e = 0; e < 4; ++e) B[(long long)(IB * rb + 4 * lq + e) * ldb + c0 + IB * wave + li] = acc[rb][e];
+    // the largest |entry| of the group's forward-substituted right-hand sides (the scale of their float16 pieces in the trailing
+    // update, sdm_gram_bf16.hip) is collected here, where they are in registers, instead of by a launch of its own at the group end
+    if (rhs_absmax && !inverse && tile_j0 + tile * own_stride >= rhs_tile0) {
+        float v = 0.0f;
+#pragma unroll
+        for (int rb = 0; rb < NIB; ++rb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v = __builtin_fmaxf(v, __builtin_fabsf(acc[rb][e]));
+        for (int o = 32; o; o >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, o));
+        if (lane == 0) atomicMax(rhs_absmax, __builtin_bit_cast(unsigned, v));      // (non-negative floats order like their bit patterns)
+    }
     SOLVE_STAMP(36);
 }
 
 
-// ---- back substitution in ONE launch (round 3) -------------------------------------------------------
+// ---- back substitution in ONE launch (round 3; the chain step shortened in round 5) -----------------------
 // One persistent workgroup per tile row i (and per chunk of <= 5 right-hand-side column tiles).  Y_i lives in the matrix-core
-// accumulators of its 8 waves for the whole solve: for k = T-1 ... i+1 the workgroup waits for R_k (a flag in global memory,
-// published by workgroup k), multiplies it by U_ik (fetched into registers while the previous product ran) and subtracts; then
-// R_i = U_ii^-1 Y_i from the stored transposed inverse, stored, fenced, flagged.  A workgroup takes its tile row from a ticket
-// drawn when it STARTS (one counter per column chunk): ticket 0 -> row T-1, ticket 1 -> row T-2, ...  A workgroup therefore only
-// ever waits for workgroups that were already running when it drew its ticket, whatever order the hardware dispatches blocks in
-// (HIP specifies none), so the kernel cannot deadlock even when the grid does not fit the chip; the spin is bounded
-// all the same (status bit 4 instead of a hung GPU).
-// Measured (rocprofv3 kernel trace, F = 8 801, 44 right-hand sides): 1.19 ms for the 69 steps = 17 us per step -- the release /
-// acquire round trip through memory, the R_k fetch and the two products -- against 69 launches x 19.9 us = 1.38 ms; F = 27 201,
-// 136 right-hand sides (two column chunks side by side): factor + solve 86.6 -> 83.1 ms.
+// accumulators of its 8 waves for the whole solve: for k = T-1 ... the workgroup waits for R_k (a flag in global memory, published
+// by workgroup k), multiplies it by its operand tile (fetched into registers while the previous product ran, staged in LDS before
+// the wait) and subtracts.  A workgroup takes its tile row from a ticket drawn when it STARTS (one counter per column chunk):
+// ticket 0 -> row T-1, ticket 1 -> row T-2, ...  A workgroup therefore only ever waits for workgroups that were already running
+// when it drew its ticket, whatever order the hardware dispatches blocks in (HIP specifies none), so the kernel cannot
+// deadlock even when the grid does not fit the chip; the spin is bounded all the same (status bit 4 instead of a hung GPU).
+//
+// The serial chain is "R_{i+1} published -> R_i published".  Until round 5 it held TWO products, R_i = W_i (Y_i' - U_{i,i+1} R_{i+1})
+// with W_i = U_ii^-1, the LDS staging of both operands and four barriers: 13.6 us per tile row at 48 right-hand sides, 35 us at 144
+// with all compute units busy (scripts: SDM_BS_STAMPS).  Now the last two tile products of a row run in R space with operands that
+// were multiplied by W_i beforehand (backsolve_prep_kernel: V1_i = W_i U_{i,i+1}, V2_i = W_i U_{i,i+2}, all rows at once):
+//     Y space:  acc  = Y_i - sum_{k >= i+3} U_ik R_k          (as before)
+//     switch:   acc <- W_i acc                                 (while the chain is two rows away)
+//     R space:  acc -= V2_i R_{i+2};  acc -= V1_i R_{i+1};  R_i = acc
+// so that ONE product, with its operand already in LDS, stands between the arrival of R_{i+1} and the store of R_i.
+// Measured (rocprofv3 kernel trace, F = 8 801, 44 right-hand sides, round 3): 1.19 ms for the 69 steps against 69 launches x 19.9 us.
 #define BSP_WAVES 8
 #define BSP_SPIN_LIMIT (1 << 22)
+#define BSP_LDA (TILE + 4)
+#define BSP_LDB2 (TILE + 16)
+// V_d(i) = U_ii^-1 U_{i,i+d}, d = 1, 2: vt[d - 1][i] row-major 128 x 128
+__global__ void __launch_bounds__(BSP_WAVES * 64)
+backsolve_prep_kernel(const float* __restrict__ G, long long ldg, int Tf, const float* __restrict__ winv_t, float* __restrict__ vt)
+{
+    const int i = blockIdx.x, d = blockIdx.y + 1;
+    if (i + d >= Tf) return;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* A = sm;                                     // [128][128 + 4]: W_i^T, k-major as stored
+    float* B = sm + TILE * BSP_LDA;                    // [128][128 + 16]: U_{i,i+d}
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lq = lane >> 4;
+    const int lr = t >> 5, lc = (t & 31) * 4;
+    const float* Wt = winv_t + (size_t)i * TILE * TILE;
+    const float* U = G + (long long)i * TILE * ldg + (long long)(i + d) * TILE;
+    f32x4s w4[TILE / 16], u4[TILE / 16];
+#pragma unroll
+    for (int q = 0; q < TILE / 16; ++q) {
+        w4[q] = *(const f32x4s*)(Wt + (lr + 16 * q) * TILE + lc);
+        u4[q] = *(const f32x4s*)(U + (long long)(lr + 16 * q) * ldg + lc);
+    }
+#pragma unroll
+    for (int q = 0; q < TILE / 16; ++q) {
+        *(f32x4s*)(A + (lr + 16 * q) * BSP_LDA + lc) = w4[q];
+        *(f32x4s*)(B + (lr + 16 * q) * BSP_LDB2 + lc) = u4[q];
+    }
+    __syncthreads();
+    f32x4 acc[TILE / 16];
+#pragma unroll
+    for (int b = 0; b < TILE / 16; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int kk = 0; kk < TILE / 4; ++kk) {
+        const int m = 4 * kk + lq;
+        const float av = A[m * BSP_LDA + 16 * wave + li];      // A[row r = 16 wave + li][k = m] = W[r][m] = W^T[m][r]
+        float bv[TILE / 16];
+#pragma unroll
+        for (int b = 0; b < TILE / 16; ++b) bv[b] = B[m * BSP_LDB2 + 16 * b + li];
+#pragma unroll
+        for (int b = 0; b < TILE / 16; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[b], acc[b], 0, 0, 0);
+    }
+    float* V = vt + ((size_t)(d - 1) * Tf + i) * TILE * TILE;
+#pragma unroll
+    for (int b = 0; b < TILE / 16; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) V[(16 * wave + 4 * lq + e) * TILE + 16 * b + li] = acc[b][e];
+}
+
 template <int NJ>
 __global__ void __launch_bounds__(BSP_WAVES * 64)
 backsolve_persistent_kernel(const float* __restrict__ G, long long ldg, int Tf, int rhs0, int nrhs, const float* __restrict__ winv_t,
-                            float* __restrict__ R, long long ldr, int* __restrict__ flags, int* __restrict__ status)
+                            const float* __restrict__ vt, float* __restrict__ R, long long ldr, int* __restrict__ flags, int* __restrict__ status)
 {
     constexpr int ncb = NJ * 16;                       // columns of this chunk
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* A = sm;                                     // [128][128 + 4]: -U_ik (row-major), at the end W_i^T (k-major)
-    float* Bk = sm + TILE * (TILE + 4);                // [128][ncb]: R_k, at the end Y_i
+    float* A = sm;                                     // [128][128 + 4]: the operand tile: -U_ik / -V (row-major) or W_i^T (k-major)
+    float* Bk = sm + TILE * BSP_LDA;                   // [128][ncb]: R_k, at the switch Y_i
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 15, lq = lane >> 4;
     __shared__ int ticket_sh;
@@ -674,6 +740,9 @@ backsolve_persistent_kernel(const float* __restrict__ G, long long ldg, int Tf, 
     if (t == 0) ticket_sh = atomicAdd(flags + (size_t)nchunks * Tf + chunk, 1);      // (the counters sit behind the flags, cleared with them)
     __syncthreads();
     const int i = Tf - 1 - ticket_sh;                  // tile row of this workgroup
+#ifdef SDM_BS_STAMPS
+    long long* dbg = (long long*)(((unsigned long long)(flags + (size_t)nchunks * Tf + nchunks) + 15) & ~15ull);
+#endif
     const int col0 = chunk * ncb;                      // first right-hand-side column of this chunk
     int* flag = flags + (size_t)chunk * Tf;
     const long long i0 = (long long)i * TILE;
@@ -685,27 +754,83 @@ backsolve_persistent_kernel(const float* __restrict__ G, long long ldg, int Tf, 
     for (int b = 0; b < NJ; ++b)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[b][e] = Yg[(long long)(16 * wave + 4 * lq + e) * ldg + 16 * b + li];
+    // the operands in the order they are used: n < ny: U_{i, T-1-n} (k >= i + 3);  n == ny: W_i^T;  n > ny: V_{k-i}(i), k = kz, kz - 1 (> i)
+    const int ny = Tf - i - 3 > 0 ? Tf - i - 3 : 0;
+    const int kz = i + 2 < Tf ? i + 2 : Tf - 1;        // first k of the R-space products
+    const int nops = ny + 1 + (kz - i);
     f32x4s pre[TILE / 16];
-    auto fetch_tile = [&](const float* src, long long ld) {
+    auto fetch_op = [&](int n) {
+        // (address first, then eight unconditional loads: a choice per load would give every load a branch and a wait of its own)
+        const float* src; long long ld;
+        if (n < ny) { src = G + i0 * ldg + (long long)(Tf - 1 - n) * TILE; ld = ldg; }
+        else if (n == ny) { src = winv_t + (size_t)i * TILE * TILE; ld = TILE; }
+        else { src = vt + ((size_t)(kz - (n - ny - 1) - i - 1) * Tf + i) * TILE * TILE; ld = TILE; }
 #pragma unroll
         for (int q = 0; q < TILE / 16; ++q) pre[q] = *(const f32x4s*)(src + (long long)(lr + 16 * q) * ld + lc);
     };
-    if (i < Tf - 1) fetch_tile(G + i0 * ldg + (long long)(Tf - 1) * TILE, ldg);
-    else fetch_tile(winv_t + (size_t)i * TILE * TILE, TILE);
-    for (int k = Tf - 1; k > i; --k) {
+    fetch_op(0);
+    for (int n = 0; n < nops; ++n) {
+        // the operand into LDS BEFORE the wait for R_k (the previous product has left A / Bk: barrier), the next one requested
+        __syncthreads();
+        if (n == ny) {
+#pragma unroll
+            for (int q = 0; q < TILE / 16; ++q) *(f32x4s*)(A + (lr + 16 * q) * BSP_LDA + lc) = pre[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < TILE / 16; ++q) *(f32x4s*)(A + (lr + 16 * q) * BSP_LDA + lc) = -pre[q];
+        }
+        if (n + 1 < nops) fetch_op(n + 1);
+        if (n == ny) {
+            // the switch to R space: acc <- W_i acc,  R[r][c] = sum_m W^T[m][r] Y[m][c]  (W_i^T k-major in A, Y_i' in Bk)
+#pragma unroll
+            for (int b = 0; b < NJ; ++b)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Bk[(16 * wave + 4 * lq + e) * ncb + 16 * b + li] = acc[b][e];
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < NJ; ++b) acc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int kk = 0; kk < TILE / 4; ++kk) {
+                const int m = 4 * kk + lq;
+                const float av = A[m * BSP_LDA + 16 * wave + li];
+                float bv[NJ];
+#pragma unroll
+                for (int b = 0; b < NJ; ++b) bv[b] = Bk[m * ncb + 16 * b + li];
+#pragma unroll
+                for (int b = 0; b < NJ; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[b], acc[b], 0, 0, 0);
+            }
+            continue;
+        }
+        const int k = n < ny ? Tf - 1 - n : kz - (n - ny - 1);
         if (t == 0) {
+            // The two rows whose turn is next (k <= i + 2: the second one's product must be done when the first one publishes) poll with
+            // acquiring loads -- each a load + an invalidation of this compute unit's L1 and its XCD's L2, so that the poll cannot be
+            // served from a stale line.  Every other row has as many steps of slack as it is rows away from the chain: it polls with an atomic read-modify-write (performed at the
+            // memory side, no invalidation), the further away the less often, and acquires ONCE behind the loop.  (With acquiring polls
+            // by all 256 workgroups and a fence per wave the invalidations queued in the L2s: the row whose turn it was waited 13 us for
+            // R_k at 144 right-hand sides -- 0.8 us now.)  The invalidation serves the whole compute unit: the other waves load R_k
+            // behind the barrier.
             int spins = 0;
-            while (__hip_atomic_load(&flag[k], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > BSP_SPIN_LIMIT) { atomicOr(status, 4); break; }
+            const int d = k - i;
+            if (d <= 2) {
+                while (__hip_atomic_load(&flag[k], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > BSP_SPIN_LIMIT) { atomicOr(status, 4); break; }
+                }
+            } else {
+                const int naps = d < 10 ? d - 2 : 8;                  // (x ~0.5 us)
+                while (__hip_atomic_fetch_or(&flag[k], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                    for (int z = 0; z < naps; ++z) __builtin_amdgcn_s_sleep(16);
+                    if (++spins > BSP_SPIN_LIMIT) { atomicOr(status, 4); break; }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
         }
-        __syncthreads();                                               // R_k is published (and the previous product has left A / Bk)
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        // -U_ik -> A, R_k -> Bk
-#pragma unroll
-        for (int q = 0; q < TILE / 16; ++q) *(f32x4s*)(A + (lr + 16 * q) * (TILE + 4) + lc) = -pre[q];
-        // (all loads of R_k first, unconditional -- columns beyond the last right-hand side read the last one and are zeroed after --
+        __syncthreads();                                               // R_k is published
+#ifdef SDM_BS_STAMPS
+        if (t == 0 && chunk == 0 && nchunks <= 2 && k == i + 1) dbg[3 * i + 1] = wall_clock64();
+#endif
+        // R_k -> Bk  (all loads first, unconditional -- columns beyond the last right-hand side read the last one and are zeroed after --
         //  then the LDS writes: as a loop of "in range ? load : 0" every element was a memory round trip of its own, twelve in a row on
         //  the chain of the substitution at 48 right-hand sides)
         const float* Rk = R + (long long)k * TILE * ldr + col0;
@@ -715,7 +840,7 @@ backsolve_persistent_kernel(const float* __restrict__ G, long long ldg, int Tf, 
 #pragma unroll
         for (int q = 0; q < NLD; ++q) {
             const int idx = t + q * BSP_WAVES * 64, r = idx / ncb, cc = idx - r * ncb;
-            rk[q] = Rk[(long long)r * ldr + (cc < cc_last ? cc : cc_last)];
+            rk[q] = __hip_atomic_load(Rk + (long long)r * ldr + (cc < cc_last ? cc : cc_last), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #pragma unroll
         for (int q = 0; q < NLD; ++q) {
@@ -723,13 +848,13 @@ backsolve_persistent_kernel(const float* __restrict__ G, long long ldg, int Tf, 
             Bk[idx] = cc <= cc_last ? rk[q] : 0.0f;
         }
         __syncthreads();
-        // the next operand's memory round trip runs under this product
-        if (k - 1 > i) fetch_tile(G + i0 * ldg + (long long)(k - 1) * TILE, ldg);
-        else fetch_tile(winv_t + (size_t)i * TILE * TILE, TILE);
+#ifdef SDM_BS_STAMPS
+        if (t == 0 && chunk == 0 && nchunks <= 2 && k == i + 1) dbg[3 * i] = (wall_clock64() - dbg[3 * i + 1]) & 0xffffffffll;
+#endif
 #pragma unroll 4
         for (int kk = 0; kk < TILE / 4; ++kk) {
             const int m = 4 * kk + lq;
-            const float av = A[(16 * wave + li) * (TILE + 4) + m];
+            const float av = A[(16 * wave + li) * BSP_LDA + m];
             float bv[NJ];
 #pragma unroll
             for (int b = 0; b < NJ; ++b) bv[b] = Bk[m * ncb + 16 * b + li];
@@ -737,37 +862,27 @@ backsolve_persistent_kernel(const float* __restrict__ G, long long ldg, int Tf, 
             for (int b = 0; b < NJ; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[b], acc[b], 0, 0, 0);
         }
     }
-    __syncthreads();
-    // R_i[r][c] = sum_m W^T[m][r] Y_i[m][c]: W_i^T -> A (k-major as stored), Y_i -> Bk
-#pragma unroll
-    for (int q = 0; q < TILE / 16; ++q) *(f32x4s*)(A + (lr + 16 * q) * (TILE + 4) + lc) = pre[q];
-#pragma unroll
-    for (int b = 0; b < NJ; ++b)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) Bk[(16 * wave + 4 * lq + e) * ncb + 16 * b + li] = acc[b][e];
-    __syncthreads();
-    f32x4 r4[NJ];
-#pragma unroll
-    for (int b = 0; b < NJ; ++b) r4[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int kk = 0; kk < TILE / 4; ++kk) {
-        const int m = 4 * kk + lq;
-        const float av = A[m * (TILE + 4) + 16 * wave + li];
-        float bv[NJ];
-#pragma unroll
-        for (int b = 0; b < NJ; ++b) bv[b] = Bk[m * ncb + 16 * b + li];
-#pragma unroll
-        for (int b = 0; b < NJ; ++b) r4[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[b], r4[b], 0, 0, 0);
-    }
+    // R_i is in the accumulators
+#ifdef SDM_BS_STAMPS
+    if (t == 0 && chunk == 0 && nchunks <= 2 && i < Tf - 1) dbg[3 * i] |= ((wall_clock64() - dbg[3 * i + 1]) & 0xffffffffll) << 32;
+#endif
     float* Ri = R + i0 * ldr + col0;
 #pragma unroll
     for (int b = 0; b < NJ; ++b)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (col0 + 16 * b + li < nrhs) Ri[(long long)(16 * wave + 4 * lq + e) * ldr + 16 * b + li] = r4[b][e];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                     // every thread's stores, before the flag
+            if (col0 + 16 * b + li < nrhs) __hip_atomic_store(Ri + (long long)(16 * wave + 4 * lq + e) * ldr + 16 * b + li, acc[b][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // every wave's stores have reached the L2 (vmcnt 0), then ONE write-back of the L2 + the flag (a release fence per wave = eight
+    // write-backs queued behind one another)
+    __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();
-    if (t == 0) __hip_atomic_store(&flag[i], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_store(&flag[i], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#ifdef SDM_BS_STAMPS
+    if (t == 0 && chunk == 0 && nchunks <= 2) dbg[3 * i + 2] = wall_clock64();
+#endif
 }
 
 }  // namespace
@@ -1014,6 +1129,9 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
     // trailing tiles from which the float16-piece update runs (its split pre-pass is per panel group): 40 until round 4; measured again in
     // round 5 -- 8 / 16 / 24 / 40 tiles: 5.75 / 5.73 / 5.73 / 5.97 ms at F = 8 801, no difference at F = 27 201 (profiles/r05_experiments.txt)
     const int upd_min_tiles = (aux && aux->upd_min_tiles > 0) ? aux->upd_min_tiles : 16;      // (A/B: SDM_SOLVE_UPD_MIN_TILES)
+    // the head of the look-ahead (the next group's tile rows, on the chain) runs one wave per 64 x 64 sub-tile while the trailing matrix
+    // is at most this many tiles wide (16 waves per tile column: 64 tiles fill the chip's 1 024 SIMDs once); chosen from the global shape
+    const int fine_head_max = (aux && aux->fine_head_max) ? (aux->fine_head_max > 0 ? aux->fine_head_max : 0) : 64;      // (A/B: SDM_SOLVE_FINE_HEAD)
     bool upd_f16 = aux && aux->upd_planes && aux->upd_maxdiag && !upd_f32_only;
     if (upd_f16) {
         sdm_launch_diag_absmax(G, ldg, F, aux->upd_maxdiag, stream);
@@ -1059,8 +1177,11 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
         // the panel tiles of the owned columns + one workgroup that produces U_kk^-T for the back substitution
         const int first = k + 1 + ((((me - (k + 1)) % W) + W) % W);             // first owned column right of k
         const int nown = first < T ? (T - first + W - 1) / W : 0;
+        // (replicated solve: the panel solve also collects the group's right-hand-side scale; a rank of a sharded one sees its own columns
+        //  only and takes the scale from the gathered panel rows at the group end, block_absmax_kernel -- the same maximum, bit for bit)
+        const bool fused_absmax = upd_f16 && !shard;
         hipLaunchKernelGGL(trsm_tile2_kernel<4>, dim3(2 * (nown + 1)), dim3(256), lds_trsm, stream, G, ldg, k0, first, nown,
-                           work + (size_t)k * TILE * TILE, W, status);
+                           work + (size_t)k * TILE * TILE, W, status, fused_absmax ? aux->upd_maxdiag + 1 + ((k / LAZY) & 1) : (unsigned*)nullptr, Tf);
         const bool group_end = (k + 1) % LAZY == 0 || k == Tf - 1;
         if (group_end && ntr > 0) {   // trailing update of all tiles (ti >= k+1, tj >= ti) from the group's panel rows
             const float* panels = G + (long long)g0 * TILE * ldg;
@@ -1086,10 +1207,11 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
                 const int r0 = ti0 - (k + 1);                       // first local tile row: 0 (head / everything) or LAZY (tail)
                 const int first = (((me - (k + 1)) % W) + W) % W;   // first owned local column
                 sdm_launch_update_f16(aux->upd_planes, prow, ntr * TILE, Tloc * TILE, G + (long long)(k + 1) * TILE * ldg + (long long)(k + 1) * TILE, ldg,
-                                      aux->upd_maxdiag, (k / LAZY) & 1, r0 / 2, tile_rows > 0 ? (r0 + tile_rows) / 2 : (1 << 30), first, W, st);
+                                      aux->upd_maxdiag, (k / LAZY) & 1, r0 / 2, tile_rows > 0 ? (r0 + tile_rows) / 2 : (1 << 30), first, W, st,
+                                      (overlap && ((r0 == 0 && tile_rows == LAZY) || fine_head_max >= 1000)) ? fine_head_max : 0);
             };
             if (overlap && tail_pending) (void)hipStreamWaitEvent(stream, aux->tail_done, 0);   // head rows were tail rows of the last group (and its tail read the planes)
-            if (f16u) sdm_launch_update_split_f16(panels + (long long)(k + 1) * TILE, ldg, prow, ntr * TILE, Tloc * TILE, aux->upd_planes, aux->upd_maxdiag, (k / LAZY) & 1, status, stream);
+            if (f16u) sdm_launch_update_split_f16(panels + (long long)(k + 1) * TILE, ldg, prow, ntr * TILE, Tloc * TILE, aux->upd_planes, aux->upd_maxdiag, (k / LAZY) & 1, status, stream, fused_absmax);
             if (!overlap) {
                 update(k + 1, 0, stream);
             } else {
@@ -1127,25 +1249,44 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
         const int nj_full = nj;
         nj = bs_n;
         const int rhs_shift = 16 * bs_lo;
-        // column tiles per workgroup (measured 42.3 / 43.7 / 47.4 / 56.2 ms at F = 27 201 for 5 / 3 / 2 / 1; round 5, F = 8 801 with 3 column
-        // tiles: one workgroup per tile row 5.56 ms, three of one column tile each 5.74 -- the shorter product does not pay for the
-        // second and third copy of every U tile; F = 17 051: 14.8 against 15.8 ms)
-        const int cap = 5;
+        // column tiles per workgroup.  Rounds 3-4 (every poll an invalidation of the L2: the more workgroups, the longer the queue):
+        // 42.3 / 43.7 / 47.4 / 56.2 ms at F = 27 201 for 5 / 3 / 2 / 1.  With round 5's polling the chain step is flag latency + ONE
+        // product of 128 x 128 x 16 cap, so the narrowest chunk wins where the chain is the limit: 3.85 / 3.81 / 3.69 ms at F = 8 801 for
+        // 5 (3) / 2 / 1, 11.50 / 11.45 / 11.31 at F = 17 051, 34.4 / 33.9 / 34.2 / 34.0 at F = 27 201 for 5 / 3 / 2 / 1.
+        const int cap = (aux && aux->bs_cap > 0 && aux->bs_cap <= 5) ? aux->bs_cap : 1;      // (A/B: SDM_SOLVE_BS_CAP)
         const int nchunks = nj > 0 ? (nj + cap - 1) / cap : 0, NJ = nchunks ? (nj + nchunks - 1) / nchunks : 1;
         int* flags = (int*)(work + (size_t)Tf * TILE * TILE);
+        float* vt = work + (size_t)Tf * TILE * TILE + sdm_backsolve_flag_ints(Tf * TILE);      // V1, V2 of every tile row (backsolve_prep_kernel)
         if (nchunks) (void)hipMemsetAsync(flags, 0, ((size_t)nchunks * Tf + nchunks) * sizeof(int), stream);      // flags + one ticket counter per chunk
         static unsigned long long attr_bsp = 0;
         if (sdm_first_use_on_device(attr_bsp)) {
 #define BSPATTR(NJv) SDM_SET_ATTR((const void*)backsolve_persistent_kernel<NJv>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024)      /* (+ the static ticket word) */
             BSPATTR(1); BSPATTR(2); BSPATTR(3); BSPATTR(4); BSPATTR(5);
 #undef BSPATTR
+            SDM_SET_ATTR((const void*)backsolve_prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
         }
+        if (nchunks && Tf > 1)
+            hipLaunchKernelGGL(backsolve_prep_kernel, dim3(Tf, 2), dim3(BSP_WAVES * 64), ((size_t)TILE * BSP_LDA + (size_t)TILE * BSP_LDB2) * sizeof(float),
+                               stream, G, ldg, Tf, work, vt);
 #define BSP(NJv) hipLaunchKernelGGL(backsolve_persistent_kernel<NJv>, dim3(nchunks, Tf), dim3(BSP_WAVES * 64),                         \
-                                    ((size_t)TILE * (TILE + 4) + (size_t)TILE * NJv * 16) * sizeof(float), stream, G, ldg, Tf, rhs0 + rhs_shift, \
-                                    16 * nj < nrhs - rhs_shift ? 16 * nj : nrhs - rhs_shift, work, R_out + rhs_shift, ldr, flags, status)
+                                    ((size_t)TILE * BSP_LDA + (size_t)TILE * NJv * 16) * sizeof(float), stream, G, ldg, Tf, rhs0 + rhs_shift, \
+                                    16 * nj < nrhs - rhs_shift ? 16 * nj : nrhs - rhs_shift, work, vt, R_out + rhs_shift, ldr, flags, status)
         if (nchunks)
             switch (NJ) { case 1: BSP(1); break; case 2: BSP(2); break; case 3: BSP(3); break; case 4: BSP(4); break; default: BSP(5); break; }
 #undef BSP
+#ifdef SDM_BS_STAMPS
+        if (nchunks && nchunks <= 2) {      // (the stamps live in the unused flag words: room for two chunks' flags + three words per row)
+            (void)hipStreamSynchronize(stream);
+            std::vector<long long> h(3 * (size_t)Tf);
+            const long long* dbg = (const long long*)(((unsigned long long)(flags + (size_t)nchunks * Tf + nchunks) + 15) & ~15ull);
+            (void)hipMemcpy(h.data(), dbg, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+            const long long t0 = h[3 * (size_t)(Tf - 1) + 2];
+            fprintf(stderr, "BS_STAMPS Tf=%d NJ=%d nchunks=%d (10 ns ticks): row start seen-prev_publish publish-seen publish\n", Tf, NJ, nchunks);
+            for (int i = Tf - 1; i >= 0; --i)
+                fprintf(stderr, "BS %d %lld %lld %lld %lld %lld %lld\n", i, 0ll, i < Tf - 1 ? h[3 * i + 1] - h[3 * (i + 1) + 2] : 0, i < Tf - 1 ? h[3 * i + 2] - h[3 * i + 1] : 0, h[3 * i + 2] - t0,
+                        h[3 * i] & 0xffffffffll, (h[3 * i] >> 32) & 0xffffffffll);
+        }
+#endif
         if (bs_sharded) {
             const int nc = 16 * bs_per;
             const size_t per_rank = Fp_rows * nc;
