@@ -1,14 +1,23 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-export TMPDIR=/tmp
-( timeout 600 python scripts/r5_bs_determinism.py 17051 88 ) > gpurun_out/r5_bs_det_17051.log 2>&1
-( timeout 600 python scripts/r5_bs_determinism.py 8801 44 ) > gpurun_out/r5_bs_det_8801.log 2>&1
-( timeout 600 python scripts/r5_bs_determinism.py 27201 136 ) > gpurun_out/r5_bs_det_27201.log 2>&1
-for F in "8801 44" "17051 88" "27201 136"; do
-  set -- $F
-  ( timeout 900 python scripts/r5_solve_ab.py $1 $2 4096 - SDM_SOLVE_BS_CAP=5 ) > gpurun_out/r5_bs7_ab_$1.log 2>&1
-done
-( timeout 1500 python -m pytest tests/test_gpu_sharded_solve.py tests/test_gpu_solver_accuracy.py tests/test_gpu_configs.py tests/test_gpu_qr_solver.py tests/test_gpu_distributed.py -m gpu -q 2>&1 | tail -8 ) > gpurun_out/r5_bs7_tests.log 2>&1
-grep -c identical gpurun_out/r5_bs_det_*.log; grep DIFFERS gpurun_out/r5_bs_det_*.log | head -20
-tail -n 3 gpurun_out/r5_bs7_ab_*.log; tail -8 gpurun_out/r5_bs7_tests.log
+R=$PWD
+cd /tmp && export TMPDIR=/tmp
+rm -rf $R/gpurun_out/fine_trace
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/fine_trace -o t -- python $R/scripts/r5_solve_ab.py --child 27201 136 4096 /tmp/x.npy > $R/gpurun_out/fine_trace.log 2>&1
+python - <<PY
+import csv,glob,re,collections
+f=glob.glob('$R/gpurun_out/fine_trace/*kernel_trace.csv')[0]
+rows=list(csv.DictReader(open(f)))
+rows.sort(key=lambda r:int(r['Start_Timestamp']))
+def short(n):
+    m=re.search(r'(\w+_kernel)', n); return m.group(1) if m else n[:30]
+idx=[i for i,r in enumerate(rows) if 'diag_absmax_kernel' in r['Kernel_Name']]
+seg=rows[idx[-1]:]
+t0=int(seg[0]['Start_Timestamp'])
+with open('$R/gpurun_out/trace68_timeline.txt','w') as fh:
+    for r in seg:
+        fh.write("%9.1f %8.1f %-34s grid=%s q=%s\n" % ((int(r['Start_Timestamp'])-t0)/1e3, (int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3, short(r['Kernel_Name']), r['Grid_Size_X'], r.get('Queue_Id')))
+PY
+rm -rf $R/gpurun_out/fine_trace
+tail -4 $R/gpurun_out/trace68_timeline.txt
