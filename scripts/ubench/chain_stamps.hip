@@ -13,8 +13,8 @@
 #include <cstdlib>
 // (the launcher of the translation unit refers to the float16 update kernels of sdm_gram_bf16.hip: not used here)
 void sdm_launch_diag_absmax(const float*, long long, int, unsigned*, hipStream_t) {}
-void sdm_launch_update_split_f16(const float*, long long, int, int, int, void*, unsigned*, int, int*, hipStream_t) {}
-void sdm_launch_update_f16(const void*, int, int, int, float*, long long, const unsigned*, int, int, int, int, int, hipStream_t) {}
+void sdm_launch_update_split_f16(const float*, long long, int, int, int, void*, unsigned*, int, int*, hipStream_t, bool) {}
+void sdm_launch_update_f16(const void*, int, int, int, float*, long long, const unsigned*, int, int, int, int, int, hipStream_t, int) {}
 static void stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_solve_stamps), 64 * sizeof(unsigned long long)); }
 int main(int argc, char** argv)
 {
@@ -71,8 +71,8 @@ int main(int argc, char** argv)
             else hipLaunchKernelGGL(potrf_tile2_kernel, dim3(1), dim3(512), lds_potrf2, 0, d, (long long)n, 0, st);      // (ver 2 and 3)
             (void)hipEventRecord(e1, 0);
             if (ver == 1) hipLaunchKernelGGL(trsm_tile_kernel, dim3(T - 1 + 1), dim3(512), lds_trsm1, 0, d, (long long)n, 0, 1, T - 1, winv, 1, st);
-            else if (ver == 2) hipLaunchKernelGGL(trsm_tile2_kernel<8>, dim3(T - 1 + 1), dim3(512), lds_trsm, 0, d, (long long)n, 0, 1, T - 1, winv, 1, st);
-            else hipLaunchKernelGGL(trsm_tile2_kernel<4>, dim3(2 * (T - 1 + 1)), dim3(256), lds_trsm, 0, d, (long long)n, 0, 1, T - 1, winv, 1, st);
+            else if (ver == 2) hipLaunchKernelGGL(trsm_tile2_kernel<8>, dim3(T - 1 + 1), dim3(512), lds_trsm, 0, d, (long long)n, 0, 1, T - 1, winv, 1, st, (unsigned*)nullptr, 1 << 30);
+            else hipLaunchKernelGGL(trsm_tile2_kernel<4>, dim3(2 * (T - 1 + 1)), dim3(256), lds_trsm, 0, d, (long long)n, 0, 1, T - 1, winv, 1, st, (unsigned*)nullptr, 1 << 30);
             (void)hipEventRecord(e2, 0);
             (void)hipDeviceSynchronize();
             float a, b; (void)hipEventElapsedTime(&a, e0, e1); (void)hipEventElapsedTime(&b, e1, e2);
