@@ -527,7 +527,8 @@ syrk_update_f16_kernel(const bf16x8* __restrict__ planes, int NG, int ncols2, in
 // sub-tile and is a workgroup by itself: 16 Tloc of them, on every SIMD of the chip; the operands come straight from the planes
 // (the eight k-rows of a column a lane feeds to the matrix core are 16 contiguous bytes: one global_load_dwordx4 per fragment, no
 // LDS, no barrier), four k-steps in flight.  Twice the operand bytes per product of the tiled kernel, which is why the wide
-// updates stay there.  Sub-tiles are dealt to the XCDs by column range (an XCD's L2 holds its eighth of the column planes + the
+// updates stay there (measured for the tails as well: 4.52 against 4.36 ms factor + solve at F = 8 801).  The head launch takes 19 instead
+// of 32 us; the solve gains less than that (profiles/r05_experiments.txt: the chain waits for the previous group's tail, not for the head).  Sub-tiles are dealt to the XCDs by column range (an XCD's L2 holds its eighth of the column planes + the
 // four row panels).  One accumulator level (K <= 512), per k-step low x high, high x low, high x high.
 __global__ void __launch_bounds__(64)
 syrk_update_f16_fine_kernel(const f16x8* __restrict__ planes, int NG, int ncols2, int TlocF, float* __restrict__ C, long long ldc,
@@ -732,7 +733,7 @@ void sdm_launch_update_f16(const void* planes, int rows, int wcols, int wcols_fa
     if (sdm_first_use_on_device(attr))
         SDM_SET_ATTR((const void*)syrk_update_f16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     const int nI = I_hi - I_lo;
-    if ((nI <= 2 || fine_max_tiles >= 1000) && Tloc <= fine_max_tiles % 1000) {      // (>= 1000: experiment -- the tail as well)
+    if (nI <= 2 && Tloc <= fine_max_tiles) {
         // the head of the look-ahead over a narrow trailing matrix: one wave per 64 x 64 sub-tile (syrk_update_f16_fine_kernel)
         const int row_lo = 2 * I_lo, row_hi = 2 * I_hi < TlocF ? 2 * I_hi : TlocF;
         const int SR = 2 * (row_hi - row_lo), SC = 2 * ((Tloc - own_first + own_stride - 1) / own_stride), per = (SC + 7) / 8;

@@ -1208,7 +1208,7 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
                 const int first = (((me - (k + 1)) % W) + W) % W;   // first owned local column
                 sdm_launch_update_f16(aux->upd_planes, prow, ntr * TILE, Tloc * TILE, G + (long long)(k + 1) * TILE * ldg + (long long)(k + 1) * TILE, ldg,
                                       aux->upd_maxdiag, (k / LAZY) & 1, r0 / 2, tile_rows > 0 ? (r0 + tile_rows) / 2 : (1 << 30), first, W, st,
-                                      (overlap && ((r0 == 0 && tile_rows == LAZY) || fine_head_max >= 1000)) ? fine_head_max : 0);
+                                      (overlap && r0 == 0 && tile_rows == LAZY) ? fine_head_max : 0);
             };
             if (overlap && tail_pending) (void)hipStreamWaitEvent(stream, aux->tail_done, 0);   // head rows were tail rows of the last group (and its tail read the planes)
             if (f16u) sdm_launch_update_split_f16(panels + (long long)(k + 1) * TILE, ldg, prow, ntr * TILE, Tloc * TILE, aux->upd_planes, aux->upd_maxdiag, (k / LAZY) & 1, status, stream, fused_absmax);

@@ -71,3 +71,30 @@ def test_badly_scaled_columns(built, decades, expect_f32):
     print("column scales over +-%.1f decades: f32 updates %d, rows worst %.2e median %.2e, prediction %.2e" % (decades, took_f32, row_err.max(), np.median(row_err), pred))
     assert (took_f32 == 1) == expect_f32
     assert pred <= 2e-5 and np.median(row_err) <= 6e-5 and row_err.max() <= 1e-3
+
+
+def test_back_substitution_does_not_depend_on_the_column_chunking(built, monkeypatch):
+    """Round 5: the persistent back substitution runs one workgroup per tile row and CHUNK of right-hand-side column tiles; the rows of
+    two chunks share 128-byte lines of the solution, written and read by workgroups on different XCDs whose L2s are not coherent with
+    each other.  Before the solution tiles travelled through agent-scope accesses one solve in ~70 came out with a column tile wrong
+    from one tile row on.  Every chunking (SDM_SOLVE_BS_CAP = column tiles per workgroup, read at sdm_create) and every repetition must
+    give the same bits; 144 right-hand sides = nine column tiles, 24 tile rows."""
+    rng = np.random.default_rng(51)
+    F, N, M = 3000, 4096, 144
+    A = (rng.standard_normal((N, F)) * rng.uniform(0.05, 0.4, F)).astype(np.float32)
+    b = rng.standard_normal((N, M)).astype(np.float32)
+    ref = None
+    for cap in ("1", "2", "5", "3", "1"):
+        monkeypatch.setenv("SDM_SOLVE_BS_CAP", cap)
+        ctx = Context(0)
+        for _ in range(6):
+            R, _lam = ctx.solve_normal_equations(A, b, 0, 1.0, True)
+            R = np.ascontiguousarray(R)
+            if ref is None:
+                ref = R.copy()
+                G = A.astype(np.float64).T @ A.astype(np.float64) + np.eye(F)
+                want = np.linalg.solve(G, A.astype(np.float64).T @ b.astype(np.float64))
+                assert np.abs(R - want).max() <= 2e-5 * np.abs(want).max()
+            differing = int((R.view(np.uint32) != ref.view(np.uint32)).sum())
+            assert differing == 0, "cap %s: %d entries differ from the first solve" % (cap, differing)
+        ctx.close()
