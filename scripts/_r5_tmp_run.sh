@@ -2,5 +2,8 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-( timeout 1500 python -m pytest tests/test_gpu_solver_accuracy.py tests/test_gpu_sharded_solve.py -m gpu -q 2>&1 | tail -8 ) > gpurun_out/r5_newtest.log 2>&1
-tail -8 gpurun_out/r5_newtest.log
+for F in "27201 136" "8801 44"; do
+  set -- $F
+  ( timeout 900 python scripts/r5_solve_ab.py $1 $2 4096 - SDM_UPDATE_TPW=2 SDM_UPDATE_TPW=4 SDM_UPDATE_TPW=8 ) > gpurun_out/r5_tpw_ab_$1.log 2>&1
+done
+tail -n 5 gpurun_out/r5_tpw_ab_*.log
