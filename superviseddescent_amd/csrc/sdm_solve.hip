@@ -654,7 +654,7 @@ trsm_tile2_kernel(float* __restrict__ G, long long ldg, int k0, int tile_j0, int
 
 
 // ---- back substitution in ONE launch (round 3; the chain step shortened in round 5) -----------------------
-// One persistent workgroup per tile row i (and per chunk of <= 5 right-hand-side column tiles).  Y_i lives in the matrix-core
+// One persistent workgroup per tile row i and per chunk of right-hand-side column tiles (one tile per chunk).  Y_i lives in the matrix-core
 // accumulators of its 8 waves for the whole solve: for k = T-1 ... the workgroup waits for R_k (a flag in global memory, published
 // by workgroup k), multiplies it by its operand tile (fetched into registers while the previous product ran, staged in LDS before
 // the wait) and subtracts.  A workgroup takes its tile row from a ticket drawn when it STARTS (one counter per column chunk):
@@ -670,7 +670,11 @@ trsm_tile2_kernel(float* __restrict__ G, long long ldg, int k0, int tile_j0, int
 //     switch:   acc <- W_i acc                                 (while the chain is two rows away)
 //     R space:  acc -= V2_i R_{i+2};  acc -= V1_i R_{i+1};  R_i = acc
 // so that ONE product, with its operand already in LDS, stands between the arrival of R_{i+1} and the store of R_i.
-// Measured (rocprofv3 kernel trace, F = 8 801, 44 right-hand sides, round 3): 1.19 ms for the 69 steps against 69 launches x 19.9 us.
+// The solution tiles travel through agent-scope (sc1) loads and stores: with several chunks the rows of two chunks share 128-byte
+// lines that workgroups on different XCDs write, and the XCDs' L2s are not coherent with each other (one solve in ~70 came out with a
+// column tile wrong from one tile row on before; tests/test_gpu_solver_accuracy.py keeps the bits equal over chunkings).
+// Measured (rocprofv3 kernel trace, F = 8 801, 44 right-hand sides): 69 launches x 19.9 us (round 2) -> 1.19 ms in one launch (round 3)
+// -> 0.24 ms + 14 us for the pre-multiplied operands (round 5); F = 27 201, 136 right-hand sides: 7.5 -> 2.8 ms.
 #define BSP_WAVES 8
 #define BSP_SPIN_LIMIT (1 << 22)
 #define BSP_LDA (TILE + 4)
@@ -1230,8 +1234,8 @@ int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs
    
     int nj = nrhs / 16;   // nrhs is a multiple of 16, <= 144 (sharded: narrowed to this rank's column tiles below)
     {
-        // one persistent launch: Tf workgroups x chunks of <= 5 column tiles; flags (one int per tile row and chunk) behind the
-        // inverses in `work`, cleared on the stream
+        // one persistent launch: Tf workgroups x chunks of column tiles; flags (one int per tile row and chunk) behind the
+        // inverses in `work`, cleared on the stream; behind the flags the pre-multiplied operands of every tile row
         // Sharded: the right-hand-side columns are independent, so rank r substitutes the column tiles r per ... (r + 1) per - 1 only
         // (the same instructions per column as the replicated launch: bit-identical) and one all-gather of the column blocks gives
         // every rank the whole solution.  At W = 8 and 136 right-hand sides a rank substitutes 32 columns instead of 144.
