@@ -40,7 +40,7 @@ def child(nb, K):
             step()
         torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t0) / K)
     x = ctx.get_x()
-    np.save(os.path.join(ROOT, "gpurun_out", "r5_envab_x_%s.npy" % os.environ["R5_AB_VALUE"]), x)
+    np.save(os.path.join(ROOT, "gpurun_out", "r5_envab_x_%s.npy" % os.path.basename(os.environ["R5_AB_VALUE"])), x)
     print(json.dumps({os.environ["R5_AB_NAME"]: os.environ["R5_AB_VALUE"], "faces": nb, "ms_per_step": best * 1e3, "faces_per_s": nb / best}), flush=True)
 
 
@@ -57,7 +57,7 @@ if __name__ == "__main__":
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", str(nb), str(K)],
                                env=dict(os.environ, **{name: v, "R5_AB_NAME": name, "R5_AB_VALUE": v}), capture_output=True, text=True, timeout=900)
             line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-2000:]
-            f = os.path.join(ROOT, "gpurun_out", "r5_envab_x_%s.npy" % v)
+            f = os.path.join(ROOT, "gpurun_out", "r5_envab_x_%s.npy" % os.path.basename(v))
             if r.returncode == 0 and os.path.exists(f):
                 x = np.load(f)
                 if ref is None:

@@ -34,10 +34,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ inline double device_ied_rows(const float* __restrict__ xr, int L, const EyeIdxDev& e)
 {
     // get_ied, include/rcr/helpers.hpp:136-160 (same arithmetic as sdm_hog.hip::device_ied)
+    // (all coordinates requested at once -- clamped index, selected add -- instead of one memory round trip per eye landmark; same sums in the same order)
     float rx = 0.0f, ry = 0.0f, lx = 0.0f, ly = 0.0f;
-    for (int i = 0; i < e.nre; ++i) { rx += xr[e.re[i]]; ry += xr[e.re[i] + L]; }
+    float vrx[SDM_MAX_EYE], vry[SDM_MAX_EYE], vlx[SDM_MAX_EYE], vly[SDM_MAX_EYE];
+#pragma unroll
+    for (int i = 0; i < SDM_MAX_EYE; ++i) {
+        const int ir = e.re[i < e.nre ? i : 0], il = e.le[i < e.nle ? i : 0];
+        vrx[i] = xr[ir]; vry[i] = xr[ir + L]; vlx[i] = xr[il]; vly[i] = xr[il + L];
+    }
+#pragma unroll
+    for (int i = 0; i < SDM_MAX_EYE; ++i) {
+        if (i < e.nre) { rx += vrx[i]; ry += vry[i]; }
+        if (i < e.nle) { lx += vlx[i]; ly += vly[i]; }
+    }
     rx /= (float)e.nre; ry /= (float)e.nre;
-    for (int i = 0; i < e.nle; ++i) { lx += xr[e.le[i]]; ly += xr[e.le[i] + L]; }
     lx /= (float)e.nle; ly /= (float)e.nle;
     float dxf = rx - lx, dyf = ry - ly;
     double dx = dxf, dy = dyf;
@@ -388,16 +398,28 @@ __global__ void apply_reduce_kernel(const float* __restrict__ partial, int split
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)N * M) return;
     const int row = (int)(t / M), col = (int)(t - (long long)row * M);
-    float u = 0.0f;
-    for (int s = 0; s < splits; ++s) u += partial[((long long)s * N + row) * Mp + col];
     const float* xr = x_in + (long long)row * M;
+    const float xc = xr[col];
     float scale = 1.0f;
     if (eyes.nre > 0) {
         // normalisation(x) = ones / ied -> (float)(1.0/ied)  (model.hpp:97);  update.mul(1 / norm)
         const float n = (float)(1.0 / device_ied_rows(xr, L, eyes));
         scale = 1.0f / n;
     }
-    x_out[t] = xr[col] - u * scale;
+    // the partial sums in order, all loads of a batch in flight together (as "load, add, load, add" the 22 landmarks of a fused RCR-22
+    // level were 22 memory round trips in a row: 10 us for a 17 MB launch); the index is clamped and the add selected, not the load
+    float u = 0.0f;
+    const float* pp = partial + (long long)row * Mp + col;
+    const long long sstride = (long long)N * Mp;
+    constexpr int RB = 24;      // (the 22 landmarks of a fused RCR-22 level: one batch)
+    for (int s0 = 0; s0 < splits; s0 += RB) {
+        float v[RB];
+#pragma unroll
+        for (int j = 0; j < RB; ++j) v[j] = pp[(long long)(s0 + j < splits ? s0 + j : splits - 1) * sstride];
+#pragma unroll
+        for (int j = 0; j < RB; ++j) u = s0 + j < splits ? u + v[j] : u;
+    }
+    x_out[t] = xc - u * scale;
 }
 
 __global__ void targets_kernel(const float* __restrict__ x, const float* __restrict__ xstar, int N, int L,
