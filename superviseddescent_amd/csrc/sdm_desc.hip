@@ -225,6 +225,19 @@ desc_kernel(const float* __restrict__ cells, const int* __restrict__ cut, int N,
     const int kp = wave % KPARTS, ntl = wave / KPARTS;
     const int ks0 = kp * KBASE + (kp < KREM ? kp : KREM), nks = KBASE + (kp < KREM ? 1 : 0);
     f32x4 acc[MAXT][MT];
+    // what the epilogue of the k-part-0 waves needs from memory -- the column's scale and, for landmark 0, the bias row of the regressor --
+    // is requested here, in front of the products, instead of behind the last barrier (one more memory round trip at the end of every workgroup)
+    unsigned rmx[MAXT];
+    float biasv[MAXT];
+#pragma unroll
+    for (int ti = 0; ti < MAXT; ++ti) {
+        const int nt = ntl + ti * NW;
+        rmx[ti] = 0; biasv[ti] = 0.0f;
+        if (kp == 0 && nt < NT) {
+            rmx[ti] = rmax[16 * nt + li];
+            if (has_bias && l == 0) biasv[ti] = Rt[(long long)(16 * nt + li) * ldr + (long long)L * P];
+        }
+    }
 #pragma unroll
     for (int ti = 0; ti < MAXT; ++ti) {
         const int nt = ntl + ti * NW;
@@ -276,9 +289,9 @@ desc_kernel(const float* __restrict__ cells, const int* __restrict__ cut, int N,
             const int nt = ntl + ti * NW;
             if (nt >= NT) continue;
             const int col = 16 * nt + li;
-            const float unscale = __builtin_ldexpf(1.0f, -12 + (desc_f16_exponent(rmax[col]) - 14));
+            const float unscale = __builtin_ldexpf(1.0f, -12 + (desc_f16_exponent(rmx[ti]) - 14));
             // the bias feature 1.0f (adaptive_vlhog.hpp:182-183) times its regressor row, added once, by landmark 0's workgroups
-            const float bias = (has_bias && l == 0) ? Rt[(long long)col * ldr + (long long)L * P] : 0.0f;
+            const float bias = biasv[ti];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
