@@ -2,7 +2,15 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-( timeout 900 python bench.py --steps 20 --warmup 5 ) > gpurun_out/r5_final_bench.json 2> gpurun_out/r5_final_bench.err
-( timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -12 ) > gpurun_out/r5_final_tests.log 2>&1
-( timeout 300 python __graft_entry__.py smoke ) > gpurun_out/r5_final_smoke.log 2>&1
-tail -c 300 gpurun_out/r5_final_bench.json; tail -5 gpurun_out/r5_final_tests.log; tail -2 gpurun_out/r5_final_smoke.log
+L=$PWD/superviseddescent_amd/lib
+for v in old new old new; do
+  if [ $v = old ]; then export SDM_HIP_LIB=$L/libsdm_hip_old.so; else export SDM_HIP_LIB=$L/libsdm_hip.so; fi
+  echo "== $v" >> gpurun_out/r5_fold_ab.log
+  ( timeout 600 python scripts/r5_rcr68_train_probe.py 100000 22 ) 2>/dev/null | tail -1 >> gpurun_out/r5_fold_ab.log
+done
+for v in old new; do
+  if [ $v = old ]; then export SDM_HIP_LIB=$L/libsdm_hip_old.so; else export SDM_HIP_LIB=$L/libsdm_hip.so; fi
+  echo "== $v" >> gpurun_out/r5_fold_ab.log
+  ( timeout 600 python scripts/r5_rcr68_train_probe.py 100000 68 ) 2>/dev/null | tail -1 >> gpurun_out/r5_fold_ab.log
+done
+cat gpurun_out/r5_fold_ab.log | cut -c1-400
