@@ -1,16 +1,5 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-mkdir -p gpurun_out
-export TMPDIR=/tmp
-L=$PWD/superviseddescent_amd/lib
-for v in old new old new; do
-  if [ $v = old ]; then export SDM_HIP_LIB=$L/libsdm_hip_old.so; else export SDM_HIP_LIB=$L/libsdm_hip.so; fi
-  echo "== $v" >> gpurun_out/r5_fold_ab.log
-  ( timeout 600 python scripts/r5_rcr68_train_probe.py 100000 22 ) 2>/dev/null | tail -1 >> gpurun_out/r5_fold_ab.log
-done
-for v in old new; do
-  if [ $v = old ]; then export SDM_HIP_LIB=$L/libsdm_hip_old.so; else export SDM_HIP_LIB=$L/libsdm_hip.so; fi
-  echo "== $v" >> gpurun_out/r5_fold_ab.log
-  ( timeout 600 python scripts/r5_rcr68_train_probe.py 100000 68 ) 2>/dev/null | tail -1 >> gpurun_out/r5_fold_ab.log
-done
-cat gpurun_out/r5_fold_ab.log | cut -c1-400
+bash scripts/solve_timeline.sh 8801 44 $PWD/gpurun_out/r05_solve_timeline_rcr22.txt
+bash scripts/solve_timeline.sh 27201 136 $PWD/gpurun_out/r05_solve_timeline_rcr68.txt
+wc -l gpurun_out/r05_solve_timeline_*.txt; tail -4 gpurun_out/r05_solve_timeline_rcr68.txt
