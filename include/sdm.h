@@ -233,7 +233,7 @@ int sdm_solve(sdm_ctx* ctx, int level, int reg_type, float reg_param, int regula
  * regressors.hpp:318):
  *   SDM_SOLVER_CHOLESKY   (default) PartialPivLUSolver's role, regressors.hpp:199-234 -- blocked Cholesky, the SPD system needs no pivoting;
  *   SDM_SOLVER_COLPIV_QR  ColPivHouseholderQRSolver, regressors.hpp:242-306 -- Householder QR with column pivoting of AtA + reg on the
- *                         device (csrc/sdm_qr.hip), x = P R^-1 Q^T (At b); "much MUCH slower" there too (level-2 work, 2 F launches), and the
+ *                         device (csrc/sdm_qr.hip), x = P R^-1 Q^T (At b); "much MUCH slower" there too (level-2 work, 2 F launches: 0.5 s at F = 8 801), and the
  *                         one that can tell a singular system: sdm_last_rank.  As Eigen's solve() / inverse() the back substitution stops at the last
  *                         nonzero pivot (largest remaining squared column norm below max ||a_j||^2 eps^2 / F * (F - k), or zero) and
  *                         returns zero coefficients for the remaining columns: a singular system gives a finite regressor ("we continued

@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(256) qr_colnorm_kernel(const float* __restrict
 }
 
 // the right-hand-side columns as rows: Bt[c][i] = G[i][rhs0 + c] (32 x 32 tiles through LDS), and back
-__global__ void __launch_bounds__(1024) qr_rhs_rows_kernel(const float* __restrict__ G, long long ldg, int F, int rhs0, int nrhs, float* __restrict__ Bt)
+__global__ void __launch_bounds__(1024) qr_rhs_rows_kernel(const float* __restrict__ G, long long ldg, int F, int rhs0, int nrhs, float* __restrict__ Bt, int bts)
 {
     __shared__ float t[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(1024) qr_rhs_rows_kernel(const float* __restri
     t[ty][tx] = (i < F && c < nrhs) ? G[(long long)i * ldg + rhs0 + c] : 0.0f;
     __syncthreads();
     const int co = blockIdx.y * 32 + ty, io = blockIdx.x * 32 + tx;
-    if (co < nrhs && io < F) Bt[(size_t)co * F + io] = t[tx][ty];
+    if (co < nrhs && io < F) Bt[(size_t)co * bts + io] = t[tx][ty];
 }
 
 __device__ inline float block_sum_1024(float v, float* red)
@@ -163,13 +163,13 @@ __global__ void __launch_bounds__(1024) qr_pivot_kernel(float* __restrict__ G, l
 
 // step k, part 2: H_k = I - tau v v^T applied to the remaining columns of the matrix and to the right-hand sides, one wave per column
 // (a contiguous row of the buffer / of Bt): d = tau v^T a, a -= d v, then the norm down-date from the column's new entry k
-__global__ void __launch_bounds__(1024) qr_apply_kernel(float* __restrict__ G, long long ldg, int F, int k, float* __restrict__ Bt, int nrhs,
+__global__ void __launch_bounds__(1024) qr_apply_kernel(float* __restrict__ G, long long ldg, int F, int k, float* __restrict__ Bt, int bts, int nrhs,
                                                         float* __restrict__ cn, const int* __restrict__ perm, const float* __restrict__ v,
                                                         const float* __restrict__ scal)
 {
     const int lane = threadIdx.x & 63, w = blockIdx.x * 16 + (threadIdx.x >> 6), nmat = F - k - 1;
     if (w >= nmat + nrhs) return;
-    float* col = w < nmat ? G + (long long)perm[k + 1 + w] * ldg : Bt + (size_t)(w - nmat) * F;
+    float* col = w < nmat ? G + (long long)perm[k + 1 + w] * ldg : Bt + (size_t)(w - nmat) * bts;
     const float tk = scal[1];
     const int i0 = k & ~63;                            // (whole 256-byte lines; entries in front of k are skipped)
     float ak = 0.0f;                                   // the column's entry k after the reflection (lane k % 64)
@@ -188,6 +188,56 @@ __global__ void __launch_bounds__(1024) qr_apply_kernel(float* __restrict__ G, l
     if (w < nmat && lane == (k & 63)) cn[k + 1 + w] -= ak * ak;
 }
 
+// The same with the column kept in LDS between its dot product and its update (one read of the trailing matrix per step instead of
+// two), sixteen-byte accesses: WAVES columns per workgroup, chosen by the launcher so that WAVES columns of F - (k & ~63) floats fit
+// the LDS (columns longer than 9 728 floats -- F > 9 728 in the first steps -- take the two-pass kernel above).  Same sums in another
+// order than the two-pass kernel's (four partial sums per lane); which kernel runs depends on F and k only.
+typedef float qr_f4 __attribute__((ext_vector_type(4)));
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) qr_apply_lds_kernel(float* __restrict__ G, long long ldg, int F, int k, float* __restrict__ Bt, int bts, int nrhs,
+                                                                  float* __restrict__ cn, const int* __restrict__ perm, const float* __restrict__ v,
+                                                                  const float* __restrict__ scal, int n4)
+{
+    extern __shared__ __attribute__((aligned(16))) float qr_cache[];      // [WAVES][4 n4]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, w = blockIdx.x * WAVES + wv, nmat = F - k - 1;
+    if (w >= nmat + nrhs) return;
+    float* col = w < nmat ? G + (long long)perm[k + 1 + w] * ldg : Bt + (size_t)(w - nmat) * bts;
+    const float tk = scal[1];
+    const int i0 = k & ~63;
+    float ak = 0.0f;
+    if (tk != 0.0f) {
+        qr_f4* cache = (qr_f4*)qr_cache + (size_t)wv * n4;
+        const qr_f4* c4 = (const qr_f4*)(col + i0);
+        const qr_f4* v4 = (const qr_f4*)(v + i0);
+        qr_f4 ds = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 4
+        for (int q = lane; q < n4; q += 64) {
+            const qr_f4 a = c4[q], vv = v4[q];
+            cache[q] = a;
+            const int i = i0 + 4 * q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ds[e] += (i + e >= k && i + e < F) ? vv[e] * a[e] : 0.0f;
+        }
+        const float d = wave_sum_all((ds[0] + ds[1]) + (ds[2] + ds[3])) * tk;
+        qr_f4* o4 = (qr_f4*)(col + i0);
+#pragma unroll 4
+        for (int q = lane; q < n4; q += 64) {
+            qr_f4 a = cache[q];
+            const qr_f4 vv = v4[q];
+            const int i = i0 + 4 * q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (i + e >= k && i + e < F) a[e] -= d * vv[e];
+                if (i + e == k) ak = a[e];
+            }
+            o4[q] = a;
+        }
+        // (the lane that held entry k hands it to the lane that down-dates: same lane by construction -- entry k sits in group (k - i0) / 4 = lane (k & 63) / 4)
+        ak = __shfl(ak, (k & 63) >> 2, 64);
+    } else ak = col[k];
+    if (w < nmat && lane == 0) cn[k + 1 + w] -= ak * ak;
+}
+
 // rank by Eigen's threshold: |R_kk| > eps * F * max |R_kk|
 __global__ void __launch_bounds__(1024) qr_rank_kernel(const float* __restrict__ G, long long ldg, int F, const int* __restrict__ perm,
                                                        const float* __restrict__ scal, int* __restrict__ rank_out)
@@ -204,7 +254,7 @@ __global__ void __launch_bounds__(1024) qr_rank_kernel(const float* __restrict__
 // R x' = Q^T b for CB right-hand-side columns per workgroup (they live in LDS), as a column sweep -- x'_j = y_j / R_jj, then
 // y_i -= R_ij x'_j for i < j along column j of R, a contiguous buffer row -- and x[perm[j]] = x'[j]
 template <int CB>
-__global__ void __launch_bounds__(1024) qr_backsolve_kernel(const float* __restrict__ G, long long ldg, int F, const float* __restrict__ Bt, int nrhs,
+__global__ void __launch_bounds__(1024) qr_backsolve_kernel(const float* __restrict__ G, long long ldg, int F, const float* __restrict__ Bt, int bts, int nrhs,
                                                             const int* __restrict__ perm, float* __restrict__ R_out, long long ldr,
                                                             const float* __restrict__ scal)
 {
@@ -216,7 +266,7 @@ __global__ void __launch_bounds__(1024) qr_backsolve_kernel(const float* __restr
     const int c0 = blockIdx.x * CB;
     for (int i = t; i < F; i += 1024)
 #pragma unroll
-        for (int c = 0; c < CB; ++c) ys[c * F + i] = (c0 + c < nrhs && i < nzp) ? Bt[(size_t)(c0 + c) * F + i] : 0.0f;
+        for (int c = 0; c < CB; ++c) ys[c * F + i] = (c0 + c < nrhs && i < nzp) ? Bt[(size_t)(c0 + c) * bts + i] : 0.0f;
     for (int j = nzp - 1; j >= 0; --j) {
         __syncthreads();                               // y_j is final: every update of the columns behind j has been applied
         const int pj = perm[j];
@@ -240,44 +290,59 @@ __global__ void __launch_bounds__(1024) qr_backsolve_kernel(const float* __restr
 
 }  // namespace
 
-size_t sdm_colpiv_qr_work_floats(int F) { return (size_t)4 * F + 16 + (size_t)144 * F; }      // cn | v | tau | perm (ints) | scal[8] | rank | the right-hand sides as rows (<= 144)
+// cn | v (+ 64: sixteen-byte reads run to the end of the last 256-byte line) | tau | perm (ints) | scal[8] | rank | the right-hand sides as rows (<= 144, row stride F rounded up to 64)
+size_t sdm_colpiv_qr_work_floats(int F) { return (size_t)4 * F + 64 + 16 + (size_t)144 * (size_t)((F + 63) / 64 * 64) + 64; }
 
 bool sdm_colpiv_qr_supported(int F) { return F >= 1 && (size_t)F * sizeof(float) <= 150 * 1024; }
 
 void sdm_launch_colpiv_qr_solve(float* G, long long ldg, int F, int rhs0, int nrhs, float* R_out, long long ldr, int r_rows,
                                 float* work, int** rank_dev_out, hipStream_t stream)
 {
-    float* cn = work; float* v = work + F; float* tau = work + 2 * (size_t)F;
-    int* perm = (int*)(work + 3 * (size_t)F);
-    float* scal = work + 4 * (size_t)F;
+    float* cn = work; float* v = work + F; float* tau = work + 2 * (size_t)F + 64;
+    int* perm = (int*)(work + 3 * (size_t)F + 64);
+    float* scal = work + 4 * (size_t)F + 64;
     int* rank_dev = (int*)(scal + 8);
-    float* Bt = work + 4 * (size_t)F + 16;
+    const int bts = (F + 63) / 64 * 64;
+    float* Bt = (float*)(((unsigned long long)(scal + 16) + 255) & ~255ull);      // (rows on 256-byte lines)
     if (rank_dev_out) *rank_dev_out = rank_dev;
+    static unsigned long long attr_seen = 0;
+    if (sdm_first_use_on_device(attr_seen)) {
+        SDM_SET_ATTR((const void*)qr_backsolve_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        SDM_SET_ATTR((const void*)qr_backsolve_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        SDM_SET_ATTR((const void*)qr_backsolve_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        SDM_SET_ATTR((const void*)qr_apply_lds_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        SDM_SET_ATTR((const void*)qr_apply_lds_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+        SDM_SET_ATTR((const void*)qr_apply_lds_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    }
     const unsigned nt = (unsigned)((F + 31) / 32);
     (void)hipMemsetAsync(scal, 0, 8 * sizeof(float), stream);
     hipLaunchKernelGGL(qr_mirror_kernel, dim3(nt, nt), dim3(1024), 0, stream, G, ldg, F);
     hipLaunchKernelGGL(qr_colnorm_kernel, dim3((unsigned)((F + 3) / 4)), dim3(256), 0, stream, G, ldg, F, cn, perm, scal);
-    if (nrhs > 0) hipLaunchKernelGGL(qr_rhs_rows_kernel, dim3(nt, (unsigned)((nrhs + 31) / 32)), dim3(1024), 0, stream, G, ldg, F, rhs0, nrhs, Bt);
+    if (nrhs > 0) hipLaunchKernelGGL(qr_rhs_rows_kernel, dim3(nt, (unsigned)((nrhs + 31) / 32)), dim3(1024), 0, stream, G, ldg, F, rhs0, nrhs, Bt, bts);
     for (int k = 0; k < F; ++k) {
         hipLaunchKernelGGL(qr_pivot_kernel, dim3(1), dim3(1024), 0, stream, G, ldg, F, k, cn, perm, v, tau, scal);
         const int ncol = F - k - 1 + nrhs;
-        if (ncol > 0)
-            hipLaunchKernelGGL(qr_apply_kernel, dim3((unsigned)((ncol + 15) / 16)), dim3(1024), 0, stream, G, ldg, F, k, Bt, nrhs, cn, perm, v, scal);
+        if (ncol <= 0) continue;
+        // the column segment from the 256-byte line of entry k to the end of the line of entry F - 1, in sixteen-byte groups
+        const int seg = bts - (k & ~63), n4 = seg / 4;
+        const size_t seg_bytes = (size_t)seg * sizeof(float);
+        if (seg_bytes * 16 <= 152 * 1024)
+            hipLaunchKernelGGL(qr_apply_lds_kernel<16>, dim3((unsigned)((ncol + 15) / 16)), dim3(1024), seg_bytes * 16, stream, G, ldg, F, k, Bt, bts, nrhs, cn, perm, v, scal, n4);
+        else if (seg_bytes * 8 <= 152 * 1024)
+            hipLaunchKernelGGL(qr_apply_lds_kernel<8>, dim3((unsigned)((ncol + 7) / 8)), dim3(512), seg_bytes * 8, stream, G, ldg, F, k, Bt, bts, nrhs, cn, perm, v, scal, n4);
+        else if (seg_bytes * 4 <= 152 * 1024)
+            hipLaunchKernelGGL(qr_apply_lds_kernel<4>, dim3((unsigned)((ncol + 3) / 4)), dim3(256), seg_bytes * 4, stream, G, ldg, F, k, Bt, bts, nrhs, cn, perm, v, scal, n4);
+        else
+            hipLaunchKernelGGL(qr_apply_kernel, dim3((unsigned)((ncol + 15) / 16)), dim3(1024), 0, stream, G, ldg, F, k, Bt, bts, nrhs, cn, perm, v, scal);
     }
     hipLaunchKernelGGL(qr_rank_kernel, dim3(1), dim3(1024), 0, stream, G, ldg, F, perm, scal, rank_dev);
     (void)hipMemsetAsync(R_out, 0, (size_t)r_rows * ldr * sizeof(float), stream);
     // right-hand-side columns per workgroup: as many as fit the LDS beside each other (at most 4)
     const size_t col_bytes = (size_t)F * sizeof(float);
     const int cb = col_bytes * 4 <= 150 * 1024 ? 4 : (col_bytes * 2 <= 150 * 1024 ? 2 : 1);
-    static unsigned long long attr_seen = 0;
-    if (sdm_first_use_on_device(attr_seen)) {
-        SDM_SET_ATTR((const void*)qr_backsolve_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-        SDM_SET_ATTR((const void*)qr_backsolve_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-        SDM_SET_ATTR((const void*)qr_backsolve_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
-    }
     const unsigned nb = (unsigned)((nrhs + cb - 1) / cb);
     if (!nb) return;
-    if (cb == 4) hipLaunchKernelGGL(qr_backsolve_kernel<4>, dim3(nb), dim3(1024), col_bytes * 4, stream, G, ldg, F, Bt, nrhs, perm, R_out, ldr, scal);
-    else if (cb == 2) hipLaunchKernelGGL(qr_backsolve_kernel<2>, dim3(nb), dim3(1024), col_bytes * 2, stream, G, ldg, F, Bt, nrhs, perm, R_out, ldr, scal);
-    else hipLaunchKernelGGL(qr_backsolve_kernel<1>, dim3(nb), dim3(1024), col_bytes, stream, G, ldg, F, Bt, nrhs, perm, R_out, ldr, scal);
+    if (cb == 4) hipLaunchKernelGGL(qr_backsolve_kernel<4>, dim3(nb), dim3(1024), col_bytes * 4, stream, G, ldg, F, Bt, bts, nrhs, perm, R_out, ldr, scal);
+    else if (cb == 2) hipLaunchKernelGGL(qr_backsolve_kernel<2>, dim3(nb), dim3(1024), col_bytes * 2, stream, G, ldg, F, Bt, bts, nrhs, perm, R_out, ldr, scal);
+    else hipLaunchKernelGGL(qr_backsolve_kernel<1>, dim3(nb), dim3(1024), col_bytes, stream, G, ldg, F, Bt, bts, nrhs, perm, R_out, ldr, scal);
 }
