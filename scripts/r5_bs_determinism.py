@@ -12,7 +12,7 @@ ref = None
 for cap in ("1", "5", "2", "1", "3"):
     os.environ["SDM_SOLVE_BS_CAP"] = cap
     ctx = Context(0)
-    for rep in range(12):
+    for rep in range(int(os.environ.get("BS_REPS", "12"))):
         x, lam = ctx.solve_normal_equations(A, b, 0, 5.0, True)
         x = np.asarray(x)
         if ref is None:
