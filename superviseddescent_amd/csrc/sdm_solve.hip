@@ -808,12 +808,11 @@ backsolve_persistent_kernel(const float* __restrict__ G, long long ldg, int Tf, 
         const int k = n < ny ? Tf - 1 - n : kz - (n - ny - 1);
         if (t == 0) {
             // The two rows whose turn is next (k <= i + 2: the second one's product must be done when the first one publishes) poll with
-            // acquiring loads -- each a load + an invalidation of this compute unit's L1 and its XCD's L2, so that the poll cannot be
-            // served from a stale line.  Every other row has as many steps of slack as it is rows away from the chain: it polls with an atomic read-modify-write (performed at the
-            // memory side, no invalidation), the further away the less often, and acquires ONCE behind the loop.  (With acquiring polls
-            // by all 256 workgroups and a fence per wave the invalidations queued in the L2s: the row whose turn it was waited 13 us for
-            // R_k at 144 right-hand sides -- 0.8 us now.)  The invalidation serves the whole compute unit: the other waves load R_k
-            // behind the barrier.
+            // acquiring loads -- each a load + an invalidation of this compute unit's L1 and its XCD's L2.  Every other row has as many
+            // steps of slack as it is rows away from the chain: it polls with relaxed agent-scope loads (sc1: served coherently, no
+            // invalidation), the further away the less often, and acquires ONCE behind the loop.  (With acquiring polls by all 256
+            // workgroups and a fence per wave the invalidations queued in the L2s: the row whose turn it was waited 13 us for R_k at 144
+            // right-hand sides -- 0.8 us now.)  The invalidation serves the whole compute unit: the other waves load R_k behind the barrier.
             int spins = 0;
             const int d = k - i;
             if (d <= 2) {
@@ -823,7 +822,7 @@ backsolve_persistent_kernel(const float* __restrict__ G, long long ldg, int Tf, 
                 }
             } else {
                 const int naps = d < 10 ? d - 2 : 8;                  // (x ~0.5 us)
-                while (__hip_atomic_fetch_or(&flag[k], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                while (__hip_atomic_load(&flag[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
                     for (int z = 0; z < naps; ++z) __builtin_amdgcn_s_sleep(16);
                     if (++spins > BSP_SPIN_LIMIT) { atomicOr(status, 4); break; }
                 }
