@@ -26,6 +26,7 @@
 
 #include "sdm_kernels.h"
 #include <stdlib.h>
+#include <string.h>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -392,6 +393,72 @@ syrk_tn_split_w8p_kernel(const bf16x8* __restrict__ planes, int NG, int ncols2, 
             }
 }
 
+// ---- round 6: FOUR waves, one per SIMD, wave = 64 rows x the tile's 128 columns (eight accumulator tiles).  The wave's own 64
+// rows are nobody else's operand: their fragments come straight from the planes into registers (the eight k-rows a lane feeds
+// to the matrix core are 16 contiguous bytes of a plane: one global_load_dwordx4 per fragment, four per slab, four slabs in
+// flight) and never touch LDS; only the 128 column operands, which all four waves multiply with, go through LDS (8 KB per
+// slab, one kilobyte piece per wave and plane, four slots).  Per wave and 16-row slab: 24 matrix instructions for 8 fragment
+// reads from LDS + 4 loads + 2 LDS-direct pieces (the eight-wave kernel: 12 for 8 + 3).  With 128 + 128 accumulator registers
+// and the fragments a wave owns its SIMD; everything the eight-wave kernel hid behind the second wave is hidden by placement:
+// the instruction stream (registers, order, counted waits) is written out by scripts/gen_gram_w4_asm.py -> sdm_gram_w4_asm.inc,
+// whose header describes the step.  The second accumulator level is staggered there (one tile folded every other slab, between
+// the other tiles' products); CHECK = the eight-wave kernel's summation order, bit for bit (tests/test_gpu_gram_kernels.py).
+#include "sdm_gram_w4_asm.inc"
+
+struct GramW4Operands {
+    const unsigned char *ua0, *ua1, *ub0, *ub1;      // (uniform) the wave's rows / its two pieces of the column operand, pieces 0 and 1, slab 0
+    unsigned long long step;                         // bytes per slab
+    unsigned va, vb, baddr, lds;                     // lane offsets behind ua / ub, the lane's fragment address and the wave's piece address in slot 0
+};
+__device__ __forceinline__ GramW4Operands gram_w4_operands(const bf16x8* planes, int NG, int ncols2, int I, int j, const void* lds_base)
+{
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int lc = lane & 31, lh = lane >> 5;
+    const size_t plane = (size_t)NG * ncols2;
+    GramW4Operands o;
+    o.ua0 = (const unsigned char*)(planes + I * 256 + wave * 64);
+    o.ua1 = o.ua0 + plane * 16;
+    o.ub0 = (const unsigned char*)(planes + (size_t)(wave >> 1) * ncols2 + j * 128 + (wave & 1) * 64);
+    o.ub1 = o.ub0 + plane * 16;
+    o.step = (unsigned long long)2 * ncols2 * 16;
+    o.va = 16u * (unsigned)(lh * ncols2 + lc);
+    o.vb = 16u * (unsigned)lane;
+    const unsigned l0 = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)lds_base;
+    o.baddr = l0 + 16u * (unsigned)(lh * 128 + lc);
+    o.lds = __builtin_amdgcn_readfirstlane(l0 + 16u * (unsigned)((wave >> 1) * 128 + (wave & 1) * 64));
+    return o;
+}
+#define SDM_GRAM_W4_RUN(TEXT, O, NSLABS, CP, LDC, VC, UNSCALE, WRITES)                                                              \
+    asm volatile(TEXT                                                                                                                \
+                 :                                                                                                                   \
+                 : [ua0] "s"(O.ua0), [ua1] "s"(O.ua1), [ub0] "s"(O.ub0), [ub1] "s"(O.ub1), [step] "s"(O.step), [nslabs] "s"(NSLABS), \
+                   [lds] "s"(O.lds), [cp] "s"(CP), [ldc1] "s"((unsigned long long)(LDC) * 4), [ldc5] "s"((unsigned long long)(LDC) * 20), \
+                   [unscale] "s"(UNSCALE), [writes] "s"(WRITES), [va] "v"(O.va), [vb] "v"(O.vb), [baddr] "v"(O.baddr), [vc] "v"(VC) \
+                 : SDM_GRAM_W4_CLOBBERS)
+
+template <bool CHECK>
+__global__ void __launch_bounds__(256)
+syrk_tn_split_w4_kernel(const bf16x8* __restrict__ planes, int NG, int ncols2, int ncols, float* __restrict__ C, long long ldc,
+                        const int* __restrict__ order, int ntiles)
+{
+    if ((int)blockIdx.x >= ntiles) return;
+    const int packed = order[blockIdx.x];
+    if (packed < 0) return;
+    const int I = packed & 0xffff, j = packed >> 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char gb_raw[];
+    const GramW4Operands o = gram_w4_operands(planes, NG, ncols2, I, j, gb_raw);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long gi0 = (long long)I * 256 + wave * 64;
+    // only the 128 x 128 tiles on or above the tile diagonal, inside the matrix
+    const unsigned writes = __builtin_amdgcn_readfirstlane(((gi0 >> 7) > j || gi0 >= ncols) ? 0u : 1u);
+    const unsigned char* cp = (const unsigned char*)(C + gi0 * ldc + (long long)j * 128);
+    const unsigned vc = 4u * (unsigned)(4 * (lane >> 5) * (int)ldc + (lane & 31));
+    const unsigned unscale = __builtin_bit_cast(unsigned, GH_UNSCALE);
+    const int nslabs = NG / 2;                                    // (a multiple of 4)
+    if (CHECK) SDM_GRAM_W4_RUN(SDM_GRAM_W4_CHECK_ASM, o, nslabs, cp, ldc, vc, unscale, writes);
+    else SDM_GRAM_W4_RUN(SDM_GRAM_W4_ASM, o, nslabs, cp, ldc, vc, unscale, writes);
+}
+
 // ---- the Cholesky's trailing update C -= P^T P on the float16 matrix cores (round 3): P = the 512 rows of a panel group
 // (sdm_solve.hip), i.e. rows of the upper factor U and of the forward-substituted right-hand sides.  |U_kj| <= sqrt(G_jj) for a
 // positive definite matrix, so ONE power-of-two scale per factorisation, taken from the largest diagonal entry before the
@@ -633,14 +700,35 @@ static const std::vector<int>& gram_tile_order_w(int T, int j_lo = 0, int j_hi =
     return o;
 }
 
+// the float16 product over a list of tiles: the four-wave kernel; SDM_GRAM_KERNEL=w8p selects the eight-wave kernel of rounds 3-5,
+// SDM_GRAM_KERNEL=w4check the four-wave kernel with the eight-wave kernel's summation order (development A/B)
+static void launch_gram_f16_tiles(const bf16x8* planes, int NG, int ncols2, int ncols, float* C, long long ldc, const int* d_ow, int n, hipStream_t stream)
+{
+    static int which = -1;
+    if (which < 0) {
+        const char* e = getenv("SDM_GRAM_KERNEL");
+        which = !e ? 0 : !strcmp(e, "w8p") ? 1 : !strcmp(e, "w4check") ? 2 : 0;
+    }
+    static unsigned long long attr = 0;
+    if (sdm_first_use_on_device(attr))
+        SDM_SET_ATTR((const void*)syrk_tn_split_w8p_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (which == 1)
+        hipLaunchKernelGGL(syrk_tn_split_w8p_kernel<4>, dim3((unsigned)n), dim3(512), (size_t)4 * (2 * 2 * 384) * 16, stream, planes, NG, ncols2, ncols, C, ldc, d_ow, n);
+    else if (which == 2)
+        hipLaunchKernelGGL(syrk_tn_split_w4_kernel<true>, dim3((unsigned)n), dim3(256), (size_t)4 * 8192, stream, planes, NG, ncols2, ncols, C, ldc, d_ow, n);
+    else
+        hipLaunchKernelGGL(syrk_tn_split_w4_kernel<false>, dim3((unsigned)n), dim3(256), (size_t)4 * 8192, stream, planes, NG, ncols2, ncols, C, ldc, d_ow, n);
+}
+
 static size_t gram_order_bytes(int ncols) { const int T = ncols / GB_TILE; return ((size_t)(T * (T + 1) / 2 + 8 + 8 * 16) * sizeof(int) + 255) & ~(size_t)255; }      // (+ the padding of up to 16 ranges)
 
 size_t sdm_gram_bf16x3_plane_bytes(int N, int ncols, int pieces)
 {
     // pieces = 2: the float16 form (what a launch needs unless an operand leaves float16's range), 3: the bf16 repeat
-    const size_t NG = (size_t)((N + 31) / 32) * 4;
+    const size_t NG = (size_t)((N + 63) / 64) * 8;
     const size_t ncols2 = (size_t)((ncols + 255) / 256) * 256;
-    return (size_t)pieces * NG * ncols2 * 16 + gram_order_bytes(ncols);
+    // (+ four slabs: the four-wave kernel keeps requesting operands past the last slab -- never multiplied, but read)
+    return (size_t)pieces * NG * ncols2 * 16 + gram_order_bytes(ncols) + 4 * 2 * ncols2 * 16;
 }
 void sdm_launch_gram_bf16x3(const float* A, long long lda, int N, int ncols, void* planes, float* C, long long ldc, hipStream_t stream,
                             int* f16_flag)
@@ -648,7 +736,7 @@ void sdm_launch_gram_bf16x3(const float* A, long long lda, int N, int ncols, voi
     // f16_flag != null: the two-float16 form; *f16_flag (device, zeroed by the caller) is raised if an operand is out of float16's
     // range -- the caller then repeats the call with f16_flag == null (three bf16 pieces: float32's range)
     if (N <= 0 || ncols <= 0) return;
-    const int NG = ((N + 31) / 32) * 4;                  // row groups of 8, padded to whole 32-row slabs (the padding rows are zero)
+    const int NG = ((N + 63) / 64) * 8;                  // row groups of 8, padded to whole 64-row groups: four 16-row slabs (the padding rows are zero)
     const int ncols2 = ((ncols + 255) / 256) * 256;      // (columns beyond ncols: zero planes)
     if (f16_flag) hipLaunchKernelGGL(split_planes_f16_kernel, dim3((ncols2 + 255) / 256, NG), dim3(256), 0, stream, A, lda, N, ncols, ncols2, NG, (f16x8*)planes, f16_flag);
     else hipLaunchKernelGGL(split_planes_kernel, dim3((ncols2 + 255) / 256, NG), dim3(256), 0, stream, A, lda, N, ncols, ncols2, NG, (bf16x8*)planes);
@@ -661,8 +749,7 @@ void sdm_launch_gram_bf16x3(const float* A, long long lda, int N, int ncols, voi
     int* d_ow = (int*)((unsigned char*)planes + (f16_flag ? 2 : 3) * (size_t)NG * (size_t)ncols2 * 16);      // (the table lives behind the planes of this form; the vector is cached for the process)
     (void)hipMemcpyAsync(d_ow, ow.data(), ow.size() * sizeof(int), hipMemcpyHostToDevice, stream);
     if (f16_flag)
-        hipLaunchKernelGGL(syrk_tn_split_w8p_kernel<4>, dim3((unsigned)ow.size()), dim3(512), (size_t)4 * (2 * 2 * 384) * 16, stream,
-                           (const bf16x8*)planes, NG, ncols2, ncols, C, ldc, d_ow, (int)ow.size());
+        launch_gram_f16_tiles((const bf16x8*)planes, NG, ncols2, ncols, C, ldc, d_ow, (int)ow.size(), stream);
     else
         hipLaunchKernelGGL((syrk_tn_bf16x3_w_kernel<3, 3, false>), dim3((unsigned)ow.size()), dim3(1024), (size_t)3 * (3 * 2 * 384) * 16, stream,
                            (const bf16x8*)planes, NG, ncols2, ncols, C, ldc, d_ow, (int)ow.size());
@@ -675,22 +762,21 @@ void sdm_launch_gram_bf16x3(const float* A, long long lda, int N, int ncols, voi
 void sdm_launch_gram_f16_split(const float* A, long long lda, int N, int ncols, void* planes, hipStream_t stream, int* f16_flag)
 {
     if (N <= 0 || ncols <= 0) return;
-    const int NG = ((N + 31) / 32) * 4, ncols2 = ((ncols + 255) / 256) * 256;
+    const int NG = ((N + 63) / 64) * 8, ncols2 = ((ncols + 255) / 256) * 256;
     hipLaunchKernelGGL(split_planes_f16_kernel, dim3((ncols2 + 255) / 256, NG), dim3(256), 0, stream, A, lda, N, ncols, ncols2, NG, (f16x8*)planes, f16_flag);
 }
 
 int sdm_launch_gram_f16_product(const void* planes, int N, int ncols, float* C, long long ldc, int j_lo, int j_hi, int order_off, hipStream_t stream)
 {
     if (N <= 0 || ncols <= 0) return 0;
-    const int NG = ((N + 31) / 32) * 4, ncols2 = ((ncols + 255) / 256) * 256;
+    const int NG = ((N + 63) / 64) * 8, ncols2 = ((ncols + 255) / 256) * 256;
     static unsigned long long attr = 0;
     if (sdm_first_use_on_device(attr))
         SDM_SET_ATTR((const void*)syrk_tn_split_w8p_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     const std::vector<int>& ow = gram_tile_order_w(ncols / GB_TILE, j_lo, j_hi);
     int* d_ow = (int*)((unsigned char*)planes + 2 * (size_t)NG * (size_t)ncols2 * 16) + order_off;
     (void)hipMemcpyAsync(d_ow, ow.data(), ow.size() * sizeof(int), hipMemcpyHostToDevice, stream);
-    hipLaunchKernelGGL(syrk_tn_split_w8p_kernel<4>, dim3((unsigned)ow.size()), dim3(512), (size_t)4 * (2 * 2 * 384) * 16, stream,
-                       (const bf16x8*)planes, NG, ncols2, ncols, C, ldc, d_ow, (int)ow.size());
+    launch_gram_f16_tiles((const bf16x8*)planes, NG, ncols2, ncols, C, ldc, d_ow, (int)ow.size(), stream);
     return (int)ow.size();
 }
 
