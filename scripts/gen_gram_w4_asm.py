@@ -15,15 +15,20 @@ the fold, spills, and drains the load queue at the loop header.  Here the regist
     s[64:..]    pointers and counters (copied from the operands: they are advanced)
 
 One step = one 16-row slab S = 24 matrix instructions (per accumulator tile: low x high, high x low, high x high -- the
-eight-wave kernel's order):
-    wait: low column pieces of S           (lgkmcnt(4): LDS reads return in order, behind them only the high pieces are out)
-    8 x  acc[t] += fa[S][0][m] x fb[n][1]   -- in a fold step with the 16 read + add pairs of the folded tile in their shadow and that
-                                              tile's own product last, from the matrix core's zero operand
-    wait: this wave's column pieces of S+1  (vmcnt(10)); s_barrier: everybody's are there, everybody holds S's fragments
-    2 x  LDS-direct load of slab S+3 -> slot (S+3)&3;  4 x ds_read_b128 low pieces of S+1 (over the registers just consumed)
-    wait: high column pieces of S           (lgkmcnt(4))
-    16 x acc[t] += fa[S][1][m] x fb[n][0],  acc[t] += fa[S][0][m] x fb[n][0]
-    4 x  ds_read_b128 high pieces of S+1;  4 x global_load_dwordx4 rows of slab S+4 -> stage S&3
+eight-wave kernel's order).  The wave issues in order and has its SIMD to itself, so whatever is not a matrix instruction is
+placed BEHIND one -- a load or an LDS read and a few scalar instructions at a time -- and issues while the pipe works on it:
+    wait lgkmcnt(0): low column pieces of S
+    products 0-7    acc[t] += fa[S][0][m] x fb[n][1]      behind 0-3: ds_read_b128 high column pieces of S (slot S & 3)
+                                                          behind 4-5: global_load_dwordx4 rows of slab S+3, piece 0 -> stage (S-1)&3
+                    in a fold step also the 16 read + add pairs of the folded tile, whose own product is the last of the eight,
+                    from the matrix core's zero operand
+    wait vmcnt(10): this wave's column pieces of S+1;  s_barrier: everybody's are there, slot (S-1)&3 is read out
+    wait lgkmcnt(0): high column pieces of S
+    products 8-15   acc[t] += fa[S][1][m] x fb[n][0]      behind 8-9: LDS-direct loads of slab S+3 -> slot (S-1)&3
+                                                          behind 10-13: ds_read_b128 low column pieces of S+1
+    products 16-23  acc[t] += fa[S][0][m] x fb[n][0]      behind 16-17: global_load_dwordx4 rows of slab S+4, piece 1 -> stage S&3
+Vector-memory order per step: rows p0 (S+3) x 2, columns (S+3) x 2, rows p1 (S+4) x 2; "at most 10 outstanding" behind the
+step's first two therefore means: the columns of S+1, and with them the rows of S+1, have landed.
 Loads beyond the last slab read on into the planes' padding (sdm_gram_bf16x3_plane_bytes) and are never multiplied: the number
 of loads per step, and with it every vmcnt, is static.
 
@@ -86,26 +91,25 @@ def bump(s, lo):
     s.op(f"s_addc_u32 s{lo + 1}, s{lo + 1}, s{S_STEP + 1}")
 
 
-def load_a(s, st):
-    for p, base in ((0, S_UA0), (1, S_UA1)):
-        s.op(f"global_load_dwordx4 {fa(st, p, 0)}, v{VA}, s[{base}:{base + 1}]")
-        s.op(f"global_load_dwordx4 {fa(st, p, 1)}, v{VA}, s[{base}:{base + 1}] offset:512")
-    bump(s, S_UA0)
-    bump(s, S_UA1)
+def load_a(s, st, p, m):
+    base = S_UA0 if p == 0 else S_UA1
+    s.op(f"global_load_dwordx4 {fa(st, p, m)}, v{VA}, s[{base}:{base + 1}]" + (" offset:512" if m else ""))
+    if m == 1:
+        bump(s, base)
 
 
-def load_b(s, slot):
-    for p, base in ((0, S_UB0), (1, S_UB1)):
-        s.op(f"s_add_u32 m0, s{S_LDS}, {slot * SLOT_BYTES + p * 4096}")
-        s.op("s_nop 0")
-        s.op(f"global_load_lds_dwordx4 v{VB}, s[{base}:{base + 1}]")
-    bump(s, S_UB0)
-    bump(s, S_UB1)
+def set_m0(s, slot, p):
+    s.op(f"s_add_u32 m0, s{S_LDS}, {slot * SLOT_BYTES + p * 4096}")
 
 
-def read_b(s, p, slot, order):
-    for n in order:
-        s.op(f"ds_read_b128 {fb(n, p)}, v{VBADDR} offset:{slot * SLOT_BYTES + p * 4096 + n * 512}")
+def load_b(s, p):
+    base = S_UB0 if p == 0 else S_UB1
+    s.op(f"global_load_lds_dwordx4 v{VB}, s[{base}:{base + 1}]")
+    bump(s, base)
+
+
+def read_b(s, p, slot, n):
+    s.op(f"ds_read_b128 {fb(n, p)}, v{VBADDR} offset:{slot * SLOT_BYTES + p * 4096 + n * 512}")
 
 
 def fold_at(q, mode):
@@ -119,6 +123,8 @@ def fold_at(q, mode):
 
 
 def step(s, q, mode):
+    """One slab.  A wave issues in order and alone on its SIMD: whatever is not a matrix instruction is placed BEHIND one, a
+    load or an LDS read and a few scalar instructions at a time, so that it issues while the matrix pipe works on that one."""
     st = q & 3
     tf = fold_at(q, mode)
     # rotation of the tile order: the fold step 2 k + 2 (tile k) starts at k + 1 (tile k last), the step before it, 2 k + 1, at k
@@ -126,39 +132,48 @@ def step(s, q, mode):
     r = (q >> 1) & 7 if mode == "stagger" else 0
     order = [(r + k) & 7 for k in range(8)]
     s.note(f"---- step {q}: stage {st}, tile order from {r}" + (f", folds tile {tf}" if tf is not None else ""))
-    s.op("s_waitcnt lgkmcnt(4)", "low column pieces of this slab")
+    s.op("s_waitcnt lgkmcnt(0)", "low column pieces of this slab")
     if tf == "all":
         for t in range(8):
             for e in range(16):
                 s.op(f"v_accvgpr_read_b32 v{TMP + e % N_TMP}, {acc(t, e)}")
                 s.op(f"v_add_f32 {tot(t, e)}, {tot(t, e)}, v{TMP + e % N_TMP}")
-        for t in order:
-            s.mfma(t, fa(st, 0, t >> 2), fb(t & 3, 1), zero=True)
-    elif tf is not None:
-        assert order[7] == tf
-        for k in range(7):
-            t = order[k]
-            s.mfma(t, fa(st, 0, t >> 2), fb(t & 3, 1))
+    for k in range(8):
+        t = order[k]
+        fold_this = tf == "all" or (tf is not None and k == 7)
+        if tf is not None and tf != "all" and k == 7:
+            assert t == tf
+        s.mfma(t, fa(st, 0, t >> 2), fb(t & 3, 1), zero=fold_this)
+        if k < 4:
+            read_b(s, 0, q & 3, k)                               # high pieces of THIS slab (their registers were last read by the previous slab)
+        elif k < 6:
+            load_a(s, (q + 3) & 3, 0, k - 4)                     # rows of slab S + 3, piece 0 -> the stage the previous slab has left
+        elif k == 6:
+            set_m0(s, (q + 3) & 3, 0)
+        if tf is not None and tf != "all" and k < 7:
             es = list(range(16 * k // 7, 16 * (k + 1) // 7))
             for e in es:
                 s.op(f"v_accvgpr_read_b32 v{TMP + e % N_TMP}, {acc(tf, e)}")
             for e in es:
                 s.op(f"v_add_f32 {tot(tf, e)}, {tot(tf, e)}, v{TMP + e % N_TMP}")
-        s.mfma(tf, fa(st, 0, tf >> 2), fb(tf & 3, 1), zero=True)
-    else:
-        for t in order:
-            s.mfma(t, fa(st, 0, t >> 2), fb(t & 3, 1))
     s.op("s_waitcnt vmcnt(10)", "this wave's column pieces of the next slab")
-    s.op("s_barrier")
-    load_b(s, (q + 3) & 3)
-    read_b(s, 1, (q + 1) & 3, [0, 1, 2, 3])
-    s.op("s_waitcnt lgkmcnt(4)", "high column pieces of this slab")
-    for t in order:
+    s.op("s_barrier", "everybody's are there; everybody has read slab S - 1's slot for the last time")
+    s.op("s_waitcnt lgkmcnt(0)", "high column pieces of this slab")
+    for k in range(8):
+        t = order[k]
         s.mfma(t, fa(st, 1, t >> 2), fb(t & 3, 0))
-    for t in order:
+        if k == 0:
+            load_b(s, 0)                                         # slab S + 3 -> slot (S - 1) & 3
+            set_m0(s, (q + 3) & 3, 1)
+        elif k == 1:
+            load_b(s, 1)
+        elif k < 6:
+            read_b(s, 1, (q + 1) & 3, k - 2)                     # low pieces of the NEXT slab over the registers the first eight products have consumed
+    for k in range(8):
+        t = order[k]
         s.mfma(t, fa(st, 0, t >> 2), fb(t & 3, 0))
-    read_b(s, 0, (q + 1) & 3, [0, 1, 2, 3])
-    load_a(s, st)
+        if k < 2:
+            load_a(s, st, 1, k)                                  # rows of slab S + 4, piece 1 -> this stage (its piece 1 is consumed)
 
 
 def c_walk(s, body):
@@ -202,14 +217,23 @@ def generate(mode, update):
         s.op(f"v_accvgpr_write_b32 a{i}, 0")
     # the issue order of the steady state from the start: rows (0), columns (0), rows (1), columns (1), rows (2), columns (2), rows (3)
     s.note("---- prologue")
+    load_a(s, 0, 1, 0)
+    load_a(s, 0, 1, 1)
     for k in range(3):
-        load_a(s, k)
-        load_b(s, k)
-    load_a(s, 3)
-    s.op("s_waitcnt vmcnt(16)", "rows and column pieces of slab 0")
+        load_a(s, k, 0, 0)
+        load_a(s, k, 0, 1)
+        set_m0(s, k, 0)
+        s.op("s_nop 0")
+        load_b(s, 0)
+        set_m0(s, k, 1)
+        s.op("s_nop 0")
+        load_b(s, 1)
+        load_a(s, k + 1, 1, 0)
+        load_a(s, k + 1, 1, 1)
+    s.op("s_waitcnt vmcnt(14)", "rows and column pieces of slab 0")
     s.op("s_barrier")
-    read_b(s, 1, 0, [0, 1, 2, 3])
-    read_b(s, 0, 0, [0, 1, 2, 3])
+    for n in range(4):
+        read_b(s, 1, 0, n)
     s.op("L_loop_%=:")
     n_before = len(s.mfma_tiles)
     for q in range(16):

@@ -405,6 +405,14 @@ syrk_tn_split_w8p_kernel(const bf16x8* __restrict__ planes, int NG, int ncols2, 
 // the other tiles' products); CHECK = the eight-wave kernel's summation order, bit for bit (tests/test_gpu_gram_kernels.py).
 #include "sdm_gram_w4_asm.inc"
 
+// (an "s" operand the compiler keeps in a vector register is printed as one: values compared on the vector unit go through this)
+__device__ __forceinline__ unsigned gram_w4_to_sgpr(unsigned v)
+{
+    unsigned r;
+    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(r) : "v"(v));
+    return r;
+}
+
 struct GramW4Operands {
     const unsigned char *ua0, *ua1, *ub0, *ub1;      // (uniform) the wave's rows / its two pieces of the column operand, pieces 0 and 1, slab 0
     unsigned long long step;                         // bytes per slab
@@ -450,7 +458,8 @@ syrk_tn_split_w4_kernel(const bf16x8* __restrict__ planes, int NG, int ncols2, i
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long gi0 = (long long)I * 256 + wave * 64;
     // only the 128 x 128 tiles on or above the tile diagonal, inside the matrix
-    const unsigned writes = __builtin_amdgcn_readfirstlane(((gi0 >> 7) > j || gi0 >= ncols) ? 0u : 1u);
+    const int gi0i = I * 256 + wave * 64;                     // (32-bit: the comparisons stay on the scalar unit)
+    const unsigned writes = gram_w4_to_sgpr(((gi0i >> 7) > j || gi0i >= ncols) ? 0u : 1u);
     const unsigned char* cp = (const unsigned char*)(C + gi0 * ldc + (long long)j * 128);
     const unsigned vc = 4u * (unsigned)(4 * (lane >> 5) * (int)ldc + (lane & 31));
     const unsigned unscale = __builtin_bit_cast(unsigned, GH_UNSCALE);
@@ -586,6 +595,46 @@ syrk_update_f16_kernel(const bf16x8* __restrict__ planes, int NG, int ncols2, in
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 Cw[(long long)(m * 32 + (e & 3) + 8 * (e >> 2)) * ldc + n * 32] = cin[m][n][e] - acc[m][n][e] * unscale;
+}
+
+// The same update on the four-wave instruction stream (round 6, SDM_UPDATE_W4_ASM): the wave's 64 x 128 of C is requested before
+// anything else into the registers that hold the Gram kernel's second accumulator level (K <= 512 rows: one level), the products
+// run as in the Gram kernel, the epilogue writes C - acc * unscale.
+__global__ void __launch_bounds__(256)
+syrk_update_f16_w4_kernel(const bf16x8* __restrict__ planes, int NG, int ncols2, int Tloc, int TlocF, float* __restrict__ C, long long ldc,
+                          const unsigned* __restrict__ scales, int slot, int I_lo, int I_hi, int own_first, int own_stride, int chunk)
+{
+    int I, j;      // (the eight-wave kernel's workgroup -> (super-row, tile column) map)
+    if (!chunk) {
+        const int nI = I_hi - I_lo;
+        I = I_lo + (int)(blockIdx.x % nI);
+        j = (int)(blockIdx.x / nI);
+    } else {
+        const int x = blockIdx.x & 7, q = blockIdx.x >> 3, NJB = (Tloc + 7) / 8, G = (I_hi - I_lo + 3) / 4;
+        int b = x * chunk + (q >> 5), Ig = 0, jb0 = 0;
+        if ((q >> 5) >= chunk) return;
+        for (;; ++Ig) {
+            if (Ig >= G) return;
+            jb0 = (I_lo + 4 * Ig) / 4;
+            if (b < NJB - jb0) break;
+            b -= NJB - jb0;
+        }
+        I = I_lo + 4 * Ig + ((q & 31) >> 3);
+        j = (jb0 + b) * 8 + (q & 7);
+    }
+    if (I >= I_hi || j >= Tloc || j < 2 * I || j < own_first || (j - own_first) % own_stride) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char gb_raw[];
+    const GramW4Operands o = gram_w4_operands(planes, NG, ncols2, I, j, gb_raw);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long gi0 = (long long)I * 256 + wave * 64;
+    const int gi0i = I * 256 + wave * 64;                     // (32-bit: the comparisons stay on the scalar unit)
+    const unsigned writes = gram_w4_to_sgpr(((gi0i >> 7) > j || gi0i >= TlocF * 128) ? 0u : 1u);      // (rows below the factor: right-hand sides x right-hand sides, never read)
+    const unsigned char* cp = (const unsigned char*)(C + gi0 * ldc + (long long)j * 128);
+    const unsigned vc = 4u * (unsigned)(4 * (lane >> 5) * (int)ldc + (lane & 31));
+    const int ef = f16_factor_exponent(scales);
+    const unsigned unscale = gram_w4_to_sgpr(__builtin_bit_cast(unsigned, __builtin_ldexpf(1.0f, (ef - 14) + ((j >= TlocF ? f16_rhs_exponent(scales, slot) : ef) - 14))));
+    const int nslabs = NG / 2;                                    // (whole 128-row panels: a multiple of 8)
+    SDM_GRAM_W4_RUN(SDM_UPDATE_W4_ASM, o, nslabs, cp, ldc, vc, unscale, writes);
 }
 
 // The same update for the HEAD of the look-ahead (the next group's four tile rows, on the factorisation's serial chain) while the
@@ -783,8 +832,8 @@ int sdm_launch_gram_f16_product(const void* planes, int N, int ncols, float* C, 
 // ---- trailing update of the blocked Cholesky on the float16 matrix cores (see syrk_update_f16_kernel) ----
 size_t sdm_update_f16_plane_bytes(int rows_max, int ncols)
 {
-    const size_t NG = (size_t)((rows_max + 31) / 32) * 4;
-    return 2 * NG * ((size_t)((ncols + 255) / 256) * 256) * 16;
+    const size_t NG = (size_t)((rows_max + 31) / 32) * 4, ncols2 = (size_t)((ncols + 255) / 256) * 256;
+    return 2 * NG * ncols2 * 16 + 4 * 2 * ncols2 * 16;      // (+ four slabs the four-wave kernel reads past the end)
 }
 
 void sdm_launch_diag_absmax(const float* G, long long ldg, int F, unsigned* scales, hipStream_t stream)
@@ -839,6 +888,12 @@ void sdm_launch_update_f16(const void* planes, int rows, int wcols, int wcols_fa
         grid = (unsigned)(8 * chunk * 32);
     }
     if (!grid) return;
-    hipLaunchKernelGGL(syrk_update_f16_kernel<4>, dim3(grid), dim3(512), (size_t)4 * (2 * 2 * 384) * 16, stream,
-                       (const bf16x8*)planes, NG, ncols2, Tloc, TlocF, C, ldc, scales, slot, I_lo, I_hi, own_first, own_stride, chunk);
+    static int w8p = -1;
+    if (w8p < 0) { const char* e = getenv("SDM_GRAM_KERNEL"); w8p = e && !strcmp(e, "w8p") ? 1 : 0; }
+    if (w8p)
+        hipLaunchKernelGGL(syrk_update_f16_kernel<4>, dim3(grid), dim3(512), (size_t)4 * (2 * 2 * 384) * 16, stream,
+                           (const bf16x8*)planes, NG, ncols2, Tloc, TlocF, C, ldc, scales, slot, I_lo, I_hi, own_first, own_stride, chunk);
+    else
+        hipLaunchKernelGGL(syrk_update_f16_w4_kernel, dim3(grid), dim3(256), (size_t)4 * 8192, stream,
+                           (const bf16x8*)planes, NG, ncols2, Tloc, TlocF, C, ldc, scales, slot, I_lo, I_hi, own_first, own_stride, chunk);
 }
