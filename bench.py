@@ -44,7 +44,7 @@ def gram_report(exec_flops, useful_flops, ms):
     if ms <= 0:
         return None
     tf = exec_flops / (ms * 1e-3) / 1e12
-    return {"kernel": "split_planes_f16_kernel+syrk_tn_split_w8p_kernel", "bound": "mfma", "unit": "TFLOP/s (f32-equivalent)",
+    return {"kernel": "split_planes_f16_kernel+syrk_tn_split_w4_kernel", "bound": "mfma", "unit": "TFLOP/s (f32-equivalent)",
             "peak": MFMA_F16_PEAK_TF / 3.0, "achieved": tf, "frac": tf / (MFMA_F16_PEAK_TF / 3.0),
             "useful_tflops": useful_flops / (ms * 1e-3) / 1e12, "times_f32_mfma_peak": tf / MFMA_F32_PEAK_TF,
             "stage_ms": ms,

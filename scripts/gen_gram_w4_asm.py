@@ -297,8 +297,6 @@ def main():
              "// clang-format off", ""]
     parts.append(render("SDM_GRAM_W4_ASM", generate("stagger", False)))
     parts.append("")
-    parts.append(render("SDM_GRAM_W4_CHECK_ASM", generate("all", False)))
-    parts.append("")
     parts.append(render("SDM_UPDATE_W4_ASM", generate("none", True)))
     parts.append("")
     parts.append("#define SDM_GRAM_W4_CLOBBERS " + ", ".join(clob))

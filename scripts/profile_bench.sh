@@ -34,7 +34,7 @@ try:
         for f in glob.glob(out+"/trace68/*kernel_trace.csv"):
             for r in csv.DictReader(open(f)):
                 k=short(r["Kernel_Name"])
-                if k in ("hog_packed_kernel","desc_kernel","apply_partial_kernel","apply_tiled_kernel","apply_tiled_f16_kernel","apply_reduce_kernel","syrk_tn_glds_kernel","syrk_tn_gldsw_kernel","syrk_tn_split_w8p_kernel","syrk_tn_bf16x3_w_kernel","split_planes_f16_kernel","backsolve_persistent_kernel"):
+                if k in ("hog_packed_kernel","desc_kernel","apply_partial_kernel","apply_tiled_kernel","apply_tiled_f16_kernel","apply_reduce_kernel","syrk_tn_glds_kernel","syrk_tn_gldsw_kernel","syrk_tn_split_w4_kernel","syrk_update_f16_w4_kernel","syrk_tn_split_w8p_kernel","syrk_tn_bf16x3_w_kernel","split_planes_f16_kernel","backsolve_persistent_kernel"):
                     geo[(k,"x".join(r.get(c,"?") for c in ("Grid_Size_X","Grid_Size_Y","Grid_Size_Z")))].append((float(r["End_Timestamp"])-float(r["Start_Timestamp"]))/1e3)
         fh.write("\n== by launch geometry (avg over dispatches) ==\n%-32s %16s %7s %11s\n" % ("kernel","grid","calls","avg_us"))
         for (k,g),v in sorted(geo.items(), key=lambda kv:(kv[0][0],-len(kv[1]))):
@@ -61,7 +61,7 @@ with open(out+"/summary.txt","w") as fh:
     for f in glob.glob(out+"/trace/*kernel_trace.csv"):
         for r in csv.DictReader(open(f)):
             k=short(r["Kernel_Name"])
-            if k in ("hog_packed_kernel","desc_kernel","hog_fast_kernel","apply_partial_kernel","apply_tiled_kernel","apply_tiled_f16_kernel","apply_reduce_kernel","syrk_tn_kernel","syrk_tn_glds_kernel","syrk_tn_gldsw_kernel","syrk_tn_split_w8p_kernel","split_planes_f16_kernel"):
+            if k in ("hog_packed_kernel","desc_kernel","hog_fast_kernel","apply_partial_kernel","apply_tiled_kernel","apply_tiled_f16_kernel","apply_reduce_kernel","syrk_tn_kernel","syrk_tn_glds_kernel","syrk_tn_gldsw_kernel","syrk_tn_split_w4_kernel","syrk_update_f16_w4_kernel","syrk_tn_split_w8p_kernel","split_planes_f16_kernel"):
                 geo[(k,"x".join(r.get(c,"?") for c in ("Grid_Size_X","Grid_Size_Y","Grid_Size_Z")))].append((float(r["End_Timestamp"])-float(r["Start_Timestamp"]))/1e3)
     fh.write("\n== kernel trace by launch geometry (avg over dispatches; the detect steps of bench.py are the rows with the most calls) ==\n")
     fh.write("%-28s %12s %7s %11s\n" % ("kernel","grid","calls","avg_us"))
@@ -71,7 +71,7 @@ with open(out+"/summary.txt","w") as fh:
     for f in glob.glob(out+"/p*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             k=short(r["Kernel_Name"])
-            if k not in ("hog_packed_kernel","desc_kernel","hog_fast_kernel","apply_partial_kernel","apply_tiled_kernel","apply_tiled_f16_kernel","syrk_tn_kernel","syrk_tn_glds_kernel","syrk_tn_gldsw_kernel","syrk_tn_split_w8p_kernel","split_planes_f16_kernel"): continue
+            if k not in ("hog_packed_kernel","desc_kernel","hog_fast_kernel","apply_partial_kernel","apply_tiled_kernel","apply_tiled_f16_kernel","syrk_tn_kernel","syrk_tn_glds_kernel","syrk_tn_gldsw_kernel","syrk_tn_split_w4_kernel","syrk_update_f16_w4_kernel","syrk_tn_split_w8p_kernel","split_planes_f16_kernel"): continue
             k="%s grid=%s" % (k, r.get("Grid_Size","?"))
             rows[k][r["Counter_Name"]]+=float(r["Counter_Value"]); cnt[(k,r["Counter_Name"])]+=1
     # one kernel is launched with several problem sizes (training rows, detect batch): keep, per kernel, the launch

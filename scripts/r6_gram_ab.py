@@ -2,7 +2,8 @@
   1. accuracy + bits on real HOG features (F = 3 169, 20 000 rows): distance from a float64 product; w4check must equal w8p bit for bit
   2. time of the Gram stage at RCR-22 / 100 000 rows and (optionally) RCR-68 / 100 000 rows
     python scripts/r6_gram_ab.py [--big]
-Every kernel runs in its own process under a timeout (a hand-placed instruction stream that waits wrongly hangs)."""
+(The w8p / w4check legs need scripts/experiments/gram_w8p_kernels.patch applied in reverse: the shipped library has the four-wave kernel only;
+the recorded run is profiles/r06_gram_ab.txt.)  Every kernel runs in its own process under a timeout (a hand-placed instruction stream that waits wrongly hangs)."""
 import json
 import os
 import subprocess

@@ -16,17 +16,20 @@
 //   split_planes_*_kernel     features [N][lda] f32  ->  planes [pieces][N/8][ncols][8] 16-bit: the eight consecutive ROWS of a
 //                             column that one lane feeds to v_mfma_f32_32x32x16_{f16,bf16} are 16 contiguous bytes, consecutive
 //                             columns follow each other -- a wave's LDS-direct load of 64 lanes x 16 bytes is one contiguous kilobyte
-//   syrk_tn_split_w8p_kernel  two float16 pieces; workgroup = 256 x 128 tile (two tile rows x one tile column of the upper
-//                             triangle + right-hand-side columns), eight waves of 64 x 64, K in slabs of 16 rows: 24 KB straight
-//                             into LDS (four buffers), fragments of slab s + 1 read while slab s is multiplied
+//   syrk_tn_split_w4_kernel   two float16 pieces; workgroup = 256 x 128 tile (two tile rows x one tile column of the upper
+//                             triangle + right-hand-side columns), four waves of 64 x 128, one per SIMD, K in slabs of 16 rows:
+//                             the wave's rows straight from the planes into registers, the columns through LDS; hand-placed
+//                             instruction stream (scripts/gen_gram_w4_asm.py -> sdm_gram_w4_asm.inc)
+//   syrk_update_f16_w4_kernel the same stream as the Cholesky's trailing update C -= P^T P
 //   syrk_tn_bf16x3_w_kernel   the same tile on sixteen waves of 64 x 32, compiler-scheduled: three bf16 pieces (the fallback)
 // What was tried on the way (128 x 128 and 256 x 256 tiles, register-staged and in-kernel splitting, 32-row slabs, two bf16 pieces,
-// deeper load queues, eight waves without the fragment prefetch, ablations of loads / fragment reads / barriers) is kept as
-// scripts/experiments/gram_16bit_variants.patch with the measurements in profiles/r03_gram_16bit_experiments.txt.
+// deeper load queues, ablations of loads / fragment reads / barriers) is kept as scripts/experiments/gram_16bit_variants.patch with
+// the measurements in profiles/r03_gram_16bit_experiments.txt; the eight-wave kernels of rounds 3-5 (two waves per SIMD, both
+// operands through LDS: matrix pipe busy 65 % of the clocks) as scripts/experiments/gram_w8p_kernels.patch, the compiler-scheduled
+// form of the four-wave kernel as gram_w4_cxx.patch, the A/B in profiles/r06_gram_ab.txt.
 
 #include "sdm_kernels.h"
 #include <stdlib.h>
-#include <string.h>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -229,180 +232,18 @@ syrk_tn_bf16x3_w_kernel(const bf16x8* __restrict__ planes, int NG, int ncols2, i
         }
 }
 
-// ---- the eight-wave kernel with the fragment reads of slab s + 1 issued BEFORE the matrix instructions of slab s (two fragment
-// sets, 64 more registers): read right behind the slab's barrier, the fragments make the matrix instructions wait for the LDS round trip
-// (an eight-wave kernel without loads: 26 ms with the barrier, 20 ms without).  Slab s + 1 has to be in LDS one step earlier, so one more buffer keeps the same load depth (NBUF >= 4).  The
-// compiler's own wait insertion puts lgkmcnt(0) in front of the matrix instructions at the loop header, which undoes the overlap,
-// so the fragment reads are issued by hand (ds_read_b128) and waited for by count: LDS reads return in order, eight reads per set.
-// Two float16 pieces only; eight waves make the load schedule static (three pieces per wave and slab, two on the diagonal).
-#define G8P_READ(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
-template <int NBUF, bool DIAG, bool FOLD = true>      // FOLD: 256-row chunks folded into the second accumulator set `tot`
-__device__ inline void gram_w8p_body(const bf16x8* __restrict__ planes, int NG, int ncols2, int I, int j, bf16x8* lds,
-                                     f32x16 (&acc)[2][2], f32x16 (&tot)[2][2])
-{
-    constexpr int KGS = 2, NP = 2;
-    constexpr int GW_A = NP * KGS * 256, GW_B = NP * KGS * 128, GW_BUF = GW_A + GW_B;      // 16-byte units
-    constexpr int MINE = DIAG ? 2 : 3;                        // pieces per wave and slab: 16 (A) + 8 (B) over eight waves
-    constexpr int BSTRIDE = DIAG ? 256 : 128;
-    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-    const size_t plane = (size_t)NG * ncols2;
-    // piece c = wave + 8 q: q = 0, 1 -> A (plane q, row group wave >> 2, quarter wave & 3); q = 2 -> B (plane wave >> 2, row group (wave >> 1) & 1, half wave & 1)
-    const bf16x8* src0 = planes + (size_t)(wave >> 2) * ncols2 + I * 256 + (wave & 3) * 64 + lane;
-    const bf16x8* src1 = src0 + plane;
-    const bf16x8* src2 = planes + (size_t)(wave >> 2) * plane + (size_t)((wave >> 1) & 1) * ncols2 + j * 128 + (wave & 1) * 64 + lane;
-    const int d0 = (wave >> 2) * 256 + (wave & 3) * 64, d1 = d0 + KGS * 256;
-    const int d2 = GW_A + ((wave >> 2) * KGS + ((wave >> 1) & 1)) * 128 + (wave & 1) * 64;
-    const size_t slab_step = (size_t)KGS * ncols2;
-    auto issue = [&](int s, int buf) {
-        glds16_b(src0 + (size_t)s * slab_step, lds + buf * GW_BUF + d0);
-        glds16_b(src1 + (size_t)s * slab_step, lds + buf * GW_BUF + d1);
-        if (!DIAG) glds16_b(src2 + (size_t)s * slab_step, lds + buf * GW_BUF + d2);
-    };
-    const int nslabs = NG / KGS;
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    const unsigned aaddr = lds0 + 16u * (unsigned)((lane >> 5) * 256 + wr * 64 + (lane & 31));
-    const unsigned baddr = lds0 + 16u * (unsigned)((DIAG ? (j & 1) * 128 + wc * 64 : GW_A + wc * 64) + (lane >> 5) * BSTRIDE + (lane & 31));
-    bf16x8 fa[2][2][2], fb[2][2][2];          // [set][tile][piece]
-#define G8P_READSET(SET, S)                                                                      \
-    {                                                                                            \
-        const unsigned bo_ = (unsigned)((S) % NBUF) * (unsigned)(GW_BUF * 16);                   \
-        const unsigned aa_ = aaddr + bo_, ba_ = baddr + bo_;                                     \
-        G8P_READ(fa[SET][0][0], aa_, 0);                                                         \
-        G8P_READ(fa[SET][1][0], aa_, 512);                                                       \
-        G8P_READ(fb[SET][0][0], ba_, 0);                                                         \
-        G8P_READ(fb[SET][1][0], ba_, 512);                                                       \
-        G8P_READ(fa[SET][0][1], aa_, KGS * 256 * 16);                                            \
-        G8P_READ(fa[SET][1][1], aa_, KGS * 256 * 16 + 512);                                      \
-        G8P_READ(fb[SET][0][1], ba_, KGS * BSTRIDE * 16);                                        \
-        G8P_READ(fb[SET][1][1], ba_, KGS * BSTRIDE * 16 + 512);                                  \
-    }
-#define G8P_M(SET, PA, PB)                                                                                                       \
-    _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                                                \
-    _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                                                \
-        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[SET][m][PA]),                            \
-                                                           __builtin_bit_cast(f16x8, fb[SET][n][PB]), acc[m][n], 0, 0, 0);
-    // the product of the two low pieces is at most 2^-22 of the product (2^-26 typically, either sign): below float32's own rounding
-    // of the sum, and a quarter of the matrix instructions (SDM_GRAM_4PRODUCTS=1 at build time keeps it, A/B)
-#ifdef SDM_GRAM_4PRODUCTS
-#define G8P_LL(SET) G8P_M(SET, 1, 1)
-#else
-#define G8P_LL(SET)
-#endif
-#define G8P_FOLD(S)                                                                                               \
-    if (FOLD && (((S) + 1) & (GB_CHUNK_SLABS - 1)) == 0) {                                                                \
-        _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                             \
-        _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                             \
-        _Pragma("unroll") for (int e = 0; e < 16; ++e) { tot[m][n][e] += acc[m][n][e]; acc[m][n][e] = 0.0f; }    \
-    }
-    // steady state: slab S (fragments in set CUR, requested half a step ago) is multiplied in two halves -- the first is in the
-    // matrix pipe while the wave waits for slab S + 1 at the barrier, the second covers the LDS round trip of set NXT -- and slab
-    // S + NBUF - 1 is requested; in flight behind slab S + 1: NBUF - 3 slabs
-#define G8P_STEP(CUR, NXT, S)                                                                      \
-    {                                                                                              \
-        __builtin_amdgcn_s_waitcnt(0xc07f);          /* lgkmcnt(0): set CUR has arrived */         \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-        G8P_LL(CUR) G8P_M(CUR, 0, 1)                                                               \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-        __builtin_amdgcn_s_waitcnt(0x0f70 | (MINE * (NBUF - 3)));                                  \
-        __builtin_amdgcn_s_barrier();                                                              \
-        issue((S) + NBUF - 1, ((S) + NBUF - 1) % NBUF);                                            \
-        G8P_READSET(NXT, (S) + 1)                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-        G8P_M(CUR, 1, 0) G8P_M(CUR, 0, 0)                                                          \
-        G8P_FOLD(S)                                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-    }
-    // the last steps: nothing left to request (or a single slab), every load awaited
-#define G8P_TAIL(CUR, NXT, S)                                                                      \
-    {                                                                                              \
-        __builtin_amdgcn_s_waitcnt(0xc07f);                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-        G8P_LL(CUR) G8P_M(CUR, 0, 1)                                                               \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-        if ((S) + 1 < nslabs) {                                                                    \
-            __builtin_amdgcn_s_waitcnt(0x0f70);                                                    \
-            __builtin_amdgcn_s_barrier();                                                          \
-            if ((S) + NBUF - 1 < nslabs) issue((S) + NBUF - 1, ((S) + NBUF - 1) % NBUF);           \
-            G8P_READSET(NXT, (S) + 1)                                                              \
-        }                                                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-        G8P_M(CUR, 1, 0) G8P_M(CUR, 0, 0)                                                          \
-        G8P_FOLD(S)                                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-    }
-#pragma unroll
-    for (int q = 0; q < NBUF - 1; ++q)
-        if (q < nslabs) issue(q, q);
-    {
-        const int rest = nslabs - 1;
-        gb_wait_vm_keep(MINE * (rest < NBUF - 2 ? rest : NBUF - 2));
-        __builtin_amdgcn_s_barrier();
-        G8P_READSET(0, 0)
-    }
-    int s = 0;
-    for (; s + NBUF < nslabs; s += 2) {          // (nslabs is even: the rows are padded to 32)
-        G8P_STEP(0, 1, s)
-        G8P_STEP(1, 0, s + 1)
-    }
-    for (; s < nslabs; s += 2) {
-        G8P_TAIL(0, 1, s)
-        G8P_TAIL(1, 0, s + 1)
-    }
-#undef G8P_TAIL
-#undef G8P_STEP
-#undef G8P_FOLD
-#undef G8P_LL
-#undef G8P_M
-#undef G8P_READSET
-}
-
-template <int NBUF>
-__global__ void __launch_bounds__(512)
-syrk_tn_split_w8p_kernel(const bf16x8* __restrict__ planes, int NG, int ncols2, int ncols, float* __restrict__ C, long long ldc,
-                         const int* __restrict__ order, int ntiles)
-{
-    if ((int)blockIdx.x >= ntiles) return;
-    const int packed = order[blockIdx.x];
-    if (packed < 0) return;
-    const int I = packed & 0xffff, j = packed >> 16;
-    extern __shared__ __attribute__((aligned(16))) unsigned char gb_raw[];
-    bf16x8* lds = (bf16x8*)gb_raw;
-    f32x16 acc[2][2], tot[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { acc[m][n][e] = 0.0f; tot[m][n][e] = 0.0f; }
-    if ((j >> 1) == I) gram_w8p_body<NBUF, true>(planes, NG, ncols2, I, j, lds, acc, tot);      // the column panel is one half of the row panel
-    else gram_w8p_body<NBUF, false>(planes, NG, ncols2, I, j, lds, acc, tot);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
-    const long long gi0 = (long long)I * 256 + wr * 64;
-    if ((gi0 >> 7) > j || gi0 >= ncols) return;
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int r = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                const long long gi = gi0 + m * 32 + r;
-                const long long gj = (long long)j * 128 + wc * 64 + n * 32 + (lane & 31);
-                C[gi * ldc + gj] = (tot[m][n][e] + acc[m][n][e]) * GH_UNSCALE;
-            }
-}
-
 // ---- round 6: FOUR waves, one per SIMD, wave = 64 rows x the tile's 128 columns (eight accumulator tiles).  The wave's own 64
 // rows are nobody else's operand: their fragments come straight from the planes into registers (the eight k-rows a lane feeds
 // to the matrix core are 16 contiguous bytes of a plane: one global_load_dwordx4 per fragment, four per slab, four slabs in
 // flight) and never touch LDS; only the 128 column operands, which all four waves multiply with, go through LDS (8 KB per
 // slab, one kilobyte piece per wave and plane, four slots).  Per wave and 16-row slab: 24 matrix instructions for 8 fragment
-// reads from LDS + 4 loads + 2 LDS-direct pieces (the eight-wave kernel: 12 for 8 + 3).  With 128 + 128 accumulator registers
-// and the fragments a wave owns its SIMD; everything the eight-wave kernel hid behind the second wave is hidden by placement:
-// the instruction stream (registers, order, counted waits) is written out by scripts/gen_gram_w4_asm.py -> sdm_gram_w4_asm.inc,
-// whose header describes the step.  The second accumulator level is staggered there (one tile folded every other slab, between
-// the other tiles' products); CHECK = the eight-wave kernel's summation order, bit for bit (tests/test_gpu_gram_kernels.py).
+// reads from LDS + 4 loads + 2 LDS-direct pieces (the eight-wave kernel of rounds 3-5: 12 for 8 + 3).  With 128 + 128
+// accumulator registers and the fragments a wave owns its SIMD; what that kernel hid behind the SIMD's second wave is hidden by
+// placement: the instruction stream (registers, order, counted waits) is written out by scripts/gen_gram_w4_asm.py ->
+// sdm_gram_w4_asm.inc, whose header describes the step.  The second accumulator level is staggered there (one tile folded every
+// other slab, between the other tiles' products).  With the eight-wave kernel's fold points the results were that kernel's bit
+// for bit (profiles/r06_gram_ab.txt); measured (profiles/r06_gram_pmc.txt): matrix pipe busy 93 % of the clocks, which the
+// power limit holds at 1.35 GHz under this load.
 #include "sdm_gram_w4_asm.inc"
 
 // (an "s" operand the compiler keeps in a vector register is printed as one: values compared on the vector unit go through this)
@@ -444,7 +285,6 @@ __device__ __forceinline__ GramW4Operands gram_w4_operands(const bf16x8* planes,
                    [unscale] "s"(UNSCALE), [writes] "s"(WRITES), [va] "v"(O.va), [vb] "v"(O.vb), [baddr] "v"(O.baddr), [vc] "v"(VC) \
                  : SDM_GRAM_W4_CLOBBERS)
 
-template <bool CHECK>
 __global__ void __launch_bounds__(256)
 syrk_tn_split_w4_kernel(const bf16x8* __restrict__ planes, int NG, int ncols2, int ncols, float* __restrict__ C, long long ldc,
                         const int* __restrict__ order, int ntiles)
@@ -464,8 +304,7 @@ syrk_tn_split_w4_kernel(const bf16x8* __restrict__ planes, int NG, int ncols2, i
     const unsigned vc = 4u * (unsigned)(4 * (lane >> 5) * (int)ldc + (lane & 31));
     const unsigned unscale = __builtin_bit_cast(unsigned, GH_UNSCALE);
     const int nslabs = NG / 2;                                    // (a multiple of 4)
-    if (CHECK) SDM_GRAM_W4_RUN(SDM_GRAM_W4_CHECK_ASM, o, nslabs, cp, ldc, vc, unscale, writes);
-    else SDM_GRAM_W4_RUN(SDM_GRAM_W4_ASM, o, nslabs, cp, ldc, vc, unscale, writes);
+    SDM_GRAM_W4_RUN(SDM_GRAM_W4_ASM, o, nslabs, cp, ldc, vc, unscale, writes);
 }
 
 // ---- the Cholesky's trailing update C -= P^T P on the float16 matrix cores (round 3): P = the 512 rows of a panel group
@@ -534,69 +373,6 @@ split_planes_f16_scaled_kernel(const float* __restrict__ A, long long lda, int N
     if (big) atomicOr(status, 8);
 }
 
-// Workgroup -> (super-row I, tile column j).  The dispatcher deals consecutive workgroups round-robin to the eight XCDs, 32 CUs each
-// with one workgroup per CU: the upper triangle is listed in blocks of 4 super-rows x 8 columns, the list cut into eight equal
-// chunks, one per XCD, so the 32 workgroups in flight on an XCD share four row panels and eight column panels (4 x 512 KB +
-// 8 x 256 KB at 512 rows: the L2 of the XCD).
-template <int NBUF>
-__global__ void __launch_bounds__(512)
-syrk_update_f16_kernel(const bf16x8* __restrict__ planes, int NG, int ncols2, int Tloc, int TlocF, float* __restrict__ C, long long ldc,
-                       const unsigned* __restrict__ scales, int slot, int I_lo, int I_hi, int own_first, int own_stride, int chunk)
-{
-    // workgroup = super-row I (local tile rows 2 I, 2 I + 1) x local tile column j; C points at the trailing matrix' origin
-    int I, j;
-    if (!chunk) {     // a few super-rows (the head of the look-ahead): column by column over all XCDs
-        const int nI = I_hi - I_lo;
-        I = I_lo + (int)(blockIdx.x % nI);
-        j = (int)(blockIdx.x / nI);
-    } else {
-        // block b of the list (groups of four super-rows, each from its diagonal block to the right); XCD x = blockIdx.x % 8 serves
-        // the blocks x chunk ... (x + 1) chunk - 1, 32 workgroups per block
-        const int x = blockIdx.x & 7, q = blockIdx.x >> 3, NJB = (Tloc + 7) / 8, G = (I_hi - I_lo + 3) / 4;
-        int b = x * chunk + (q >> 5), Ig = 0, jb0 = 0;
-        if ((q >> 5) >= chunk) return;
-        for (;; ++Ig) {
-            if (Ig >= G) return;
-            jb0 = (I_lo + 4 * Ig) / 4;                      // column block of the group's first diagonal tile (2 I / 8)
-            if (b < NJB - jb0) break;
-            b -= NJB - jb0;
-        }
-        I = I_lo + 4 * Ig + ((q & 31) >> 3);
-        j = (jb0 + b) * 8 + (q & 7);
-    }
-    if (I >= I_hi || j >= Tloc || j < 2 * I || j < own_first || (j - own_first) % own_stride) return;
-    extern __shared__ __attribute__((aligned(16))) unsigned char gb_raw[];
-    bf16x8* lds = (bf16x8*)gb_raw;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
-    const long long gi0 = (long long)I * 256 + wr * 64;
-    const bool writes = !((gi0 >> 7) > j || gi0 >= (long long)TlocF * 128);      // (rows below the factor: right-hand sides x right-hand sides, never read)
-    // this wave's part of C is requested before the products (at most 512 rows, i.e. two 256-row chunks: one accumulator level,
-    // the registers of the second hold C): the read of the read-modify-write costs no time behind the last slab
-    float* Cw = C + (gi0 + 4 * (lane >> 5)) * ldc + (long long)j * 128 + wc * 64 + (lane & 31);
-    f32x16 acc[2][2], cin[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                acc[m][n][e] = 0.0f;
-                cin[m][n][e] = writes ? Cw[(long long)(m * 32 + (e & 3) + 8 * (e >> 2)) * ldc + n * 32] : 0.0f;
-            }
-    if ((j >> 1) == I) gram_w8p_body<NBUF, true, false>(planes, NG, ncols2, I, j, lds, acc, acc);
-    else gram_w8p_body<NBUF, false, false>(planes, NG, ncols2, I, j, lds, acc, acc);
-    if (!writes) return;
-    const int ef = f16_factor_exponent(scales);
-    const float unscale = __builtin_ldexpf(1.0f, (ef - 14) + ((j >= TlocF ? f16_rhs_exponent(scales, slot) : ef) - 14));
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                Cw[(long long)(m * 32 + (e & 3) + 8 * (e >> 2)) * ldc + n * 32] = cin[m][n][e] - acc[m][n][e] * unscale;
-}
-
 // The same update on the four-wave instruction stream (round 6, SDM_UPDATE_W4_ASM): the wave's 64 x 128 of C is requested before
 // anything else into the registers that hold the Gram kernel's second accumulator level (K <= 512 rows: one level), the products
 // run as in the Gram kernel, the epilogue writes C - acc * unscale.
@@ -604,7 +380,11 @@ __global__ void __launch_bounds__(256)
 syrk_update_f16_w4_kernel(const bf16x8* __restrict__ planes, int NG, int ncols2, int Tloc, int TlocF, float* __restrict__ C, long long ldc,
                           const unsigned* __restrict__ scales, int slot, int I_lo, int I_hi, int own_first, int own_stride, int chunk)
 {
-    int I, j;      // (the eight-wave kernel's workgroup -> (super-row, tile column) map)
+    // Workgroup -> (super-row I, tile column j).  The dispatcher deals consecutive workgroups round-robin to the eight XCDs, 32 CUs each
+    // with one workgroup per CU: the upper triangle is listed in blocks of 4 super-rows x 8 columns, the list cut into eight equal
+    // chunks, one per XCD, so the 32 workgroups in flight on an XCD share four row panels and eight column panels (4 x 512 KB +
+    // 8 x 256 KB at 512 rows: the L2 of the XCD).  A few super-rows (the head of the look-ahead): column by column over all XCDs.
+    int I, j;
     if (!chunk) {
         const int nI = I_hi - I_lo;
         I = I_lo + (int)(blockIdx.x % nI);
@@ -749,24 +529,10 @@ static const std::vector<int>& gram_tile_order_w(int T, int j_lo = 0, int j_hi =
     return o;
 }
 
-// the float16 product over a list of tiles: the four-wave kernel; SDM_GRAM_KERNEL=w8p selects the eight-wave kernel of rounds 3-5,
-// SDM_GRAM_KERNEL=w4check the four-wave kernel with the eight-wave kernel's summation order (development A/B)
+// the float16 product over a list of tiles
 static void launch_gram_f16_tiles(const bf16x8* planes, int NG, int ncols2, int ncols, float* C, long long ldc, const int* d_ow, int n, hipStream_t stream)
 {
-    static int which = -1;
-    if (which < 0) {
-        const char* e = getenv("SDM_GRAM_KERNEL");
-        which = !e ? 0 : !strcmp(e, "w8p") ? 1 : !strcmp(e, "w4check") ? 2 : 0;
-    }
-    static unsigned long long attr = 0;
-    if (sdm_first_use_on_device(attr))
-        SDM_SET_ATTR((const void*)syrk_tn_split_w8p_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (which == 1)
-        hipLaunchKernelGGL(syrk_tn_split_w8p_kernel<4>, dim3((unsigned)n), dim3(512), (size_t)4 * (2 * 2 * 384) * 16, stream, planes, NG, ncols2, ncols, C, ldc, d_ow, n);
-    else if (which == 2)
-        hipLaunchKernelGGL(syrk_tn_split_w4_kernel<true>, dim3((unsigned)n), dim3(256), (size_t)4 * 8192, stream, planes, NG, ncols2, ncols, C, ldc, d_ow, n);
-    else
-        hipLaunchKernelGGL(syrk_tn_split_w4_kernel<false>, dim3((unsigned)n), dim3(256), (size_t)4 * 8192, stream, planes, NG, ncols2, ncols, C, ldc, d_ow, n);
+    hipLaunchKernelGGL(syrk_tn_split_w4_kernel, dim3((unsigned)n), dim3(256), (size_t)4 * 8192, stream, planes, NG, ncols2, ncols, C, ldc, d_ow, n);
 }
 
 static size_t gram_order_bytes(int ncols) { const int T = ncols / GB_TILE; return ((size_t)(T * (T + 1) / 2 + 8 + 8 * 16) * sizeof(int) + 255) & ~(size_t)255; }      // (+ the padding of up to 16 ranges)
@@ -790,10 +556,8 @@ void sdm_launch_gram_bf16x3(const float* A, long long lda, int N, int ncols, voi
     if (f16_flag) hipLaunchKernelGGL(split_planes_f16_kernel, dim3((ncols2 + 255) / 256, NG), dim3(256), 0, stream, A, lda, N, ncols, ncols2, NG, (f16x8*)planes, f16_flag);
     else hipLaunchKernelGGL(split_planes_kernel, dim3((ncols2 + 255) / 256, NG), dim3(256), 0, stream, A, lda, N, ncols, ncols2, NG, (bf16x8*)planes);
     static unsigned long long attr = 0;
-    if (sdm_first_use_on_device(attr)) {
-        SDM_SET_ATTR((const void*)syrk_tn_split_w8p_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (sdm_first_use_on_device(attr))
         SDM_SET_ATTR((const void*)syrk_tn_bf16x3_w_kernel<3, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
     const std::vector<int>& ow = gram_tile_order_w(ncols / GB_TILE);
     int* d_ow = (int*)((unsigned char*)planes + (f16_flag ? 2 : 3) * (size_t)NG * (size_t)ncols2 * 16);      // (the table lives behind the planes of this form; the vector is cached for the process)
     (void)hipMemcpyAsync(d_ow, ow.data(), ow.size() * sizeof(int), hipMemcpyHostToDevice, stream);
@@ -819,9 +583,6 @@ int sdm_launch_gram_f16_product(const void* planes, int N, int ncols, float* C, 
 {
     if (N <= 0 || ncols <= 0) return 0;
     const int NG = ((N + 63) / 64) * 8, ncols2 = ((ncols + 255) / 256) * 256;
-    static unsigned long long attr = 0;
-    if (sdm_first_use_on_device(attr))
-        SDM_SET_ATTR((const void*)syrk_tn_split_w8p_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     const std::vector<int>& ow = gram_tile_order_w(ncols / GB_TILE, j_lo, j_hi);
     int* d_ow = (int*)((unsigned char*)planes + 2 * (size_t)NG * (size_t)ncols2 * 16) + order_off;
     (void)hipMemcpyAsync(d_ow, ow.data(), ow.size() * sizeof(int), hipMemcpyHostToDevice, stream);
@@ -864,9 +625,6 @@ void sdm_launch_update_f16(const void* planes, int rows, int wcols, int wcols_fa
     const int TI = (TlocF + 1) / 2;                      // super-rows that hold factor rows
     if (I_hi > TI) I_hi = TI;
     if (I_lo >= I_hi || own_first >= Tloc) return;
-    static unsigned long long attr = 0;
-    if (sdm_first_use_on_device(attr))
-        SDM_SET_ATTR((const void*)syrk_update_f16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     const int nI = I_hi - I_lo;
     if (nI <= 2 && Tloc <= fine_max_tiles) {
         // the head of the look-ahead over a narrow trailing matrix: one wave per 64 x 64 sub-tile (syrk_update_f16_fine_kernel)
@@ -888,12 +646,6 @@ void sdm_launch_update_f16(const void* planes, int rows, int wcols, int wcols_fa
         grid = (unsigned)(8 * chunk * 32);
     }
     if (!grid) return;
-    static int w8p = -1;
-    if (w8p < 0) { const char* e = getenv("SDM_GRAM_KERNEL"); w8p = e && !strcmp(e, "w8p") ? 1 : 0; }
-    if (w8p)
-        hipLaunchKernelGGL(syrk_update_f16_kernel<4>, dim3(grid), dim3(512), (size_t)4 * (2 * 2 * 384) * 16, stream,
-                           (const bf16x8*)planes, NG, ncols2, Tloc, TlocF, C, ldc, scales, slot, I_lo, I_hi, own_first, own_stride, chunk);
-    else
-        hipLaunchKernelGGL(syrk_update_f16_w4_kernel, dim3(grid), dim3(256), (size_t)4 * 8192, stream,
-                           (const bf16x8*)planes, NG, ncols2, Tloc, TlocF, C, ldc, scales, slot, I_lo, I_hi, own_first, own_stride, chunk);
+    hipLaunchKernelGGL(syrk_update_f16_w4_kernel, dim3(grid), dim3(256), (size_t)4 * 8192, stream,
+                       (const bf16x8*)planes, NG, ncols2, Tloc, TlocF, C, ldc, scales, slot, I_lo, I_hi, own_first, own_stride, chunk);
 }
