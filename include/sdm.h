@@ -253,6 +253,13 @@ int sdm_last_rank(sdm_ctx* ctx, int* rank, int* full_rank);
 int sdm_solve_normal_equations(sdm_ctx* ctx, const float* A_host, int n_rows, int n_features,
                                const float* b_host, int n_outputs, int reg_type, float reg_param,
                                int regularise_last_row, float* R_host, float* lambda_out);
+/* The same with the solver named PER CALL (SDM_SOLVER_*): the handle's sdm_set_solver choice is neither read nor changed, so two
+ * LinearRegressor<Solver> objects with different solvers can share a handle (what the header layer's PartialPivLUSolver /
+ * ColPivHouseholderQRSolver do, regressors.hpp:174-306).  rank / full_rank (either may be NULL) receive what qr_of_AtA.rank() and
+ * the matrix order are at regressors.hpp:288-292; with SDM_SOLVER_CHOLESKY a successful solve reports full rank. */
+int sdm_solve_normal_equations_with(sdm_ctx* ctx, int solver, const float* A_host, int n_rows, int n_features,
+                                    const float* b_host, int n_outputs, int reg_type, float reg_param,
+                                    int regularise_last_row, float* R_host, float* lambda_out, int* rank, int* full_rank);
 /* Convenience: the four calls above + sdm_apply. */
 int sdm_train_level(sdm_ctx* ctx, int level, int reg_type, float reg_param, int regularise_last_row,
                     long long n_train_global);

@@ -323,8 +323,9 @@ def col_piv_householder_qr_f32(A: np.ndarray):
     I - tau v v^T is applied to the remaining columns and their norms are down-dated by the new row-k entries.  Returns
     (qr, tau, perm, rank, nonzero_pivots): R on and above the diagonal of qr, the vectors below it; rank = #{k < nonzero_pivots:
     |R_kk| > eps * n * max |R_kk|} (Eigen's default threshold, what rank() / isInvertible() at regressors.hpp:289-290 use).
-    nonzero_pivots: Eigen stops the elimination at the first step whose largest remaining (down-dated) squared column norm falls
-    below max_j ||a_j||^2 * eps^2 / n * (n - k) (3.2: "terminate to avoid generating nan/inf values") or is exactly zero (3.3);
+    nonzero_pivots: Eigen stops the elimination at the first step at which the selected column's squared norm -- recomputed exactly,
+    not the down-dated table entry it was selected by -- falls below max_j ||a_j||^2 * eps^2 / n * (n - k) (3.2: "terminate to avoid
+    generating nan/inf values") or is exactly zero (3.3);
     solve() / inverse() then use the leading nonzero_pivots x nonzero_pivots block only and return zero rows for the rest."""
     f32 = np.float32
     qr = np.array(A, dtype=f32, order="C")
@@ -338,9 +339,15 @@ def col_piv_householder_qr_f32(A: np.ndarray):
     thr_helper = f32(f32(cn.max() if n else 0.0) * f32(np.finfo(f32).eps) * f32(np.finfo(f32).eps) / f32(n)) if n else f32(0.0)
     nzp = n
     for k in range(n):
-        p = k + int(np.argmax(cn[k:]))                        # first of the maxima
-        if cn[p] < f32(thr_helper * f32(n - k)) or cn[p] == 0:
-            nzp = k                                           # (no further reflections: tau = 0, nothing below the diagonal)
+        p = k + int(np.argmax(cn[k:]))                        # first of the maxima (chosen by the down-dated norms)
+        # Eigen 3.2 recomputes the EXACT squared norm of the selected column before it decides to stop: the down-dated table
+        # accumulates cancellation error, and on an ill-conditioned but non-singular matrix its late entries are noise
+        col = qr[k + 1:, p]
+        tail = f32(np.sum((col * col).astype(f32), dtype=f32)) if col.size else f32(0.0)
+        c0 = qr[k, p]
+        exact = f32(f32(c0 * c0) + tail)
+        if exact < f32(thr_helper * f32(n - k)) or exact == 0:
+            nzp = k                                           # (no swap, no further reflections: tau = 0, nothing below the diagonal)
             qr[k:, k:] = np.triu(qr[k:, k:])
             break
         if p != k:
@@ -348,11 +355,9 @@ def col_piv_householder_qr_f32(A: np.ndarray):
             cn[[k, p]] = cn[[p, k]]
             perm[[k, p]] = perm[[p, k]]
         col = qr[k + 1:, k]
-        tail = f32(np.sum((col * col).astype(f32), dtype=f32)) if col.size else f32(0.0)
-        c0 = qr[k, k]
         beta, t = c0, f32(0.0)
         if tail > 0:
-            beta = f32(np.sqrt(f32(c0 * c0 + tail)))
+            beta = f32(np.sqrt(exact))
             if c0 >= 0:
                 beta = f32(-beta)
             qr[k + 1:, k] = (col / f32(c0 - beta)).astype(f32)

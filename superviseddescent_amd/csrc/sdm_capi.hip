@@ -1485,7 +1485,15 @@ int sdm_solve(sdm_ctx* c, int level, int reg_type, float reg_param, int regulari
 int sdm_solve_normal_equations(sdm_ctx* c, const float* A, int N, int F, const float* b, int M, int reg_type,
                                float reg_param, int regularise_last_row, float* R_host, float* lambda_out)
 {
+    if (!c) return fail(SDM_ERR_INVALID, "bad arguments");
+    return sdm_solve_normal_equations_with(c, c->solver_kind, A, N, F, b, M, reg_type, reg_param, regularise_last_row, R_host, lambda_out, nullptr, nullptr);
+}
+
+int sdm_solve_normal_equations_with(sdm_ctx* c, int solver, const float* A, int N, int F, const float* b, int M, int reg_type,
+                                    float reg_param, int regularise_last_row, float* R_host, float* lambda_out, int* rank, int* full_rank)
+{
     if (!c || !A || !b || !R_host || N <= 0 || F <= 0 || M <= 0) return fail(SDM_ERR_INVALID, "bad arguments");
+    if (solver != SDM_SOLVER_CHOLESKY && solver != SDM_SOLVER_COLPIV_QR) return fail(SDM_ERR_INVALID, "unknown solver");
     if (M > 144) return fail(SDM_ERR_INVALID, "at most 144 outputs supported");
     if (reg_type != SDM_REG_MANUAL && reg_type != SDM_REG_MATRIX_NORM) return fail(SDM_ERR_INVALID, "bad regulariser type");
     HIP_TRY(hipSetDevice(c->device));
@@ -1506,7 +1514,7 @@ int sdm_solve_normal_equations(sdm_ctx* c, const float* A, int N, int F, const f
         if (reg_type == SDM_REG_MATRIX_NORM) sdm_launch_fro2_upper(dG.p, ncols, F, dfro.p, c->stream);
         sdm_launch_add_diag(dG.p, ncols, F, dfro.p + F, reg_type, reg_param, N, regularise_last_row, c->lambda_dev.p, c->stream);
     }
-    if (c->solver_kind == SDM_SOLVER_COLPIV_QR) {
+    if (solver == SDM_SOLVER_COLPIV_QR) {
         Timer t(c, SDM_T_FACTOR);
         if ((rc = qr_solve(c, dG.p, ncols, F, Fp, Mp, dR.p))) return rc;
     } else {
@@ -1520,6 +1528,9 @@ int sdm_solve_normal_equations(sdm_ctx* c, const float* A, int N, int F, const f
     HIP_TRY(hipStreamSynchronize(c->stream));
     rc = check_status(c);
     dA.release(); dG.release(); dR.release(); dW.release(); dfro.release();
+    // (a Cholesky that went through has full rank; qr_solve has left the QR's count in the handle)
+    if (rank) *rank = solver == SDM_SOLVER_COLPIV_QR ? c->last_rank : F;
+    if (full_rank) *full_rank = F;
     return rc;
 }
 

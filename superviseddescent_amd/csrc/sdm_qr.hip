@@ -123,28 +123,36 @@ __global__ void __launch_bounds__(1024) qr_pivot_kernel(float* __restrict__ G, l
     if (t == 0) {
         float b = bestv[0]; int p = besti[0];
         for (int w = 1; w < 16; ++w) if (bestv[w] > b || (bestv[w] == b && besti[w] < p)) { b = bestv[w]; p = besti[w]; }
-        // ColPivHouseholderQR::compute: biggest_col_sq_norm < max_j ||a_j||^2 eps^2 / rows * (rows - k) (Eigen 3.2, "terminate to avoid
-        // generating nan/inf values"), or exactly zero (Eigen 3.3's count of nonzero pivots): nonzero_pivots = k
-        const float thr_helper = __builtin_bit_cast(float, ((const unsigned*)scal)[3]) * 1.1920929e-07f * 1.1920929e-07f / (float)F;
-        if (b < thr_helper * (float)(F - k) || b == 0.0f) { p = -1; scal[2] = (float)(k + 1); tau[k] = 0.0f; scal[1] = 0.0f; }
-        if (p >= 0 && p != k) {      // the swap of two columns = two entries of the permutation (column j lives in buffer row perm[j])
-            const float c = cn[k]; cn[k] = cn[p]; cn[p] = c;
-            const int q = perm[k]; perm[k] = perm[p]; perm[p] = q;
-        }
-        p_sh = p >= 0 ? perm[k] : -1;
+        p_sh = p;
     }
     __syncthreads();
-    const int r = p_sh;
-    if (r < 0) return;                                   // (the elimination has ended at this step)
-    // ---- Householder vector of column k below the diagonal: one contiguous row ----
+    const int p = p_sh;
+    const int r = perm[p];                               // (column j lives in buffer row perm[j]; nothing is swapped yet)
+    // ---- the selected column below the diagonal: one contiguous row ----
     float* col = G + (long long)r * ldg;
     float part = 0.0f;
     for (int i = k + 1 + t; i < F; i += 1024) { const float a = col[i]; part += a * a; }
     const float tail = block_sum_1024(part, red);
     const float c0 = col[k];
+    // ColPivHouseholderQR::compute (Eigen 3.2): the column is CHOSEN by the down-dated norms, but the decision to stop is taken on
+    // its exact squared norm, recomputed here (the down-dated table accumulates cancellation error: on an ill-conditioned but
+    // non-singular matrix its late entries are noise) -- biggest_col_sq_norm < max_j ||a_j||^2 eps^2 / rows * (rows - k)
+    // ("terminate to avoid generating nan/inf values"), or exactly zero (Eigen 3.3's count of nonzero pivots): nonzero_pivots = k,
+    // no swap, no reflection from here on
+    const float exact = c0 * c0 + tail;
+    const float thr_helper = __builtin_bit_cast(float, ((const unsigned*)scal)[3]) * 1.1920929e-07f * 1.1920929e-07f / (float)F;
+    if (exact < thr_helper * (float)(F - k) || exact == 0.0f) {
+        if (t == 0) { scal[2] = (float)(k + 1); tau[k] = 0.0f; scal[1] = 0.0f; }
+        return;
+    }
+    if (t == 0 && p != k) {      // the swap of two columns = two entries of the permutation
+        const float c = cn[k]; cn[k] = cn[p]; cn[p] = c;
+        const int q = perm[k]; perm[k] = r; perm[p] = q;
+    }
+    // ---- its Householder vector ----
     float beta = c0, tk = 0.0f;
     if (tail > 0.0f) {
-        beta = sqrtf(c0 * c0 + tail);
+        beta = sqrtf(exact);
         if (c0 >= 0.0f) beta = -beta;
         const float den = c0 - beta;
         for (int i = k + 1 + t; i < F; i += 1024) v[i] = col[i] / den;
@@ -290,17 +298,19 @@ __global__ void __launch_bounds__(1024) qr_backsolve_kernel(const float* __restr
 
 }  // namespace
 
-// cn | v (+ 64: sixteen-byte reads run to the end of the last 256-byte line) | tau | perm (ints) | scal[8] | rank | the right-hand sides as rows (<= 144, row stride F rounded up to 64)
-size_t sdm_colpiv_qr_work_floats(int F) { return (size_t)4 * F + 64 + 16 + (size_t)144 * (size_t)((F + 63) / 64 * 64) + 64; }
+// cn | v (+ 64: sixteen-byte reads run to the end of the last 256-byte line) | tau | perm (ints) | scal[8] | rank | the right-hand sides as rows
+// (<= 144, row stride F rounded up to 64); every section starts on a 256-byte line (F rounded up to 64 floats: v is read in sixteen-byte groups)
+size_t sdm_colpiv_qr_work_floats(int F) { const size_t Fa = (size_t)((F + 63) / 64 * 64); return 4 * Fa + 64 + 16 + 144 * Fa + 64; }
 
 bool sdm_colpiv_qr_supported(int F) { return F >= 1 && (size_t)F * sizeof(float) <= 150 * 1024; }
 
 void sdm_launch_colpiv_qr_solve(float* G, long long ldg, int F, int rhs0, int nrhs, float* R_out, long long ldr, int r_rows,
                                 float* work, int** rank_dev_out, hipStream_t stream)
 {
-    float* cn = work; float* v = work + F; float* tau = work + 2 * (size_t)F + 64;
-    int* perm = (int*)(work + 3 * (size_t)F + 64);
-    float* scal = work + 4 * (size_t)F + 64;
+    const size_t Fa = (size_t)((F + 63) / 64 * 64);
+    float* cn = work; float* v = work + Fa; float* tau = work + 2 * Fa + 64;
+    int* perm = (int*)(work + 3 * Fa + 64);
+    float* scal = work + 4 * Fa + 64;
     int* rank_dev = (int*)(scal + 8);
     const int bts = (F + 63) / 64 * 64;
     float* Bt = (float*)(((unsigned long long)(scal + 16) + 255) & ~255ull);      // (rows on 256-byte lines)

@@ -369,15 +369,26 @@ class Context:
         return r.value, f.value
 
     def solve_normal_equations(self, data: np.ndarray, labels: np.ndarray, reg_type: int = 0, reg_param: float = 0.0,
-                               regularise_last_row: bool = True):
-        """Solver::solve(data, labels, regulariser) of regressors.hpp:199-234 on the GPU, for host matrices."""
+                               regularise_last_row: bool = True, solver=None, return_rank: bool = False):
+        """Solver::solve(data, labels, regulariser) of regressors.hpp:199-234 on the GPU, for host matrices.  ``solver``: None = the
+        handle's (``set_solver``), or "cholesky" / "colpivqr" for this call only (the handle's choice is left alone);
+        ``return_rank``: also return (rank, full rank) as regressors.hpp:288-292 sees them."""
         A = np.ascontiguousarray(data, np.float32)
         b = np.ascontiguousarray(labels, np.float32)
         R = np.empty((A.shape[1], b.shape[1]), np.float32)
         lam = ctypes.c_float(0.0)
-        check(self._lib.sdm_solve_normal_equations(self._h, _fp(A), A.shape[0], A.shape[1], _fp(b), b.shape[1], reg_type,
-                                                   reg_param, int(regularise_last_row), _fp(R), ctypes.byref(lam)))
-        return R, lam.value
+        if solver is None and not return_rank:
+            check(self._lib.sdm_solve_normal_equations(self._h, _fp(A), A.shape[0], A.shape[1], _fp(b), b.shape[1], reg_type,
+                                                       reg_param, int(regularise_last_row), _fp(R), ctypes.byref(lam)))
+            return R, lam.value
+        kind = {"cholesky": 0, "lu": 0, "colpivqr": 1, "qr": 1}.get(solver, solver) if isinstance(solver, str) else solver
+        if kind is None:
+            raise ValueError("return_rank needs the solver named for the call")
+        rank, full = ctypes.c_int(-1), ctypes.c_int(0)
+        check(self._lib.sdm_solve_normal_equations_with(self._h, int(kind), _fp(A), A.shape[0], A.shape[1], _fp(b), b.shape[1], reg_type,
+                                                        reg_param, int(regularise_last_row), _fp(R), ctypes.byref(lam),
+                                                        ctypes.byref(rank), ctypes.byref(full)))
+        return (R, lam.value, (rank.value, full.value)) if return_rank else (R, lam.value)
 
     def train_level(self, level: int, reg_type: int, reg_param: float, regularise_last_row: bool,
                     n_train_global: int = 0):

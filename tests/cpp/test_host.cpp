@@ -96,7 +96,99 @@ TEST(LinearRegressor, NDimManyExamplesNDimYBiasRegularisationButNotBias)   // ND
     EXPECT_TRUE(lr.test(test, groundtruth) <= 0.000011);
 }
 
-// (ColPivHouseholderQRSolver runs on the device: its known-answer test is in rcr_gpu.cpp, run by tests/test_cpp_layer.py -m gpu)
+// ---- ColPivHouseholderQRSolver on the host (regressors.hpp:242-306; small systems and boxes without a device) ----
+TEST(ColPivHouseholderQRSolver, ReproducesTheLuGoldens)   // the coefficients ND.cpp:174-195 pins, through the other solver
+{
+    LinearRegressor<ColPivHouseholderQRSolver> lr(Regulariser(Regulariser::RegularisationType::Manual, 50.0f, true));
+    EXPECT_TRUE(!detail::solve_on_device(5, 3, 2));
+    lr.learn(nd_data(), nd_labels());
+    const float want[3][2] = {{0.282755911f, -0.0989616f}, {0.03607957f, 0.330635577f}, {0.291039944f, 0.217046738f}};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 2; ++j) EXPECT_NEAR(want[i][j], lr.x.at<float>(i, j), 1e-6);
+}
+
+TEST(ColPivHouseholderQRSolver, ReportsASingularSystemAndStaysFinite)   // regressors.hpp:288-293
+{
+    // two identical columns and an empty one, no regularisation: rank 3 of 5, "we continued learning" -- a finite solution whose
+    // coefficient for the empty column is zero (Eigen's solve() stops at the last nonzero pivot)
+    Mat data(12, 5, CV_32FC1), labels(12, 2, CV_32FC1);
+    unsigned s = 12345u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
+    for (int i = 0; i < 12; ++i) {
+        for (int j = 0; j < 5; ++j) data.at<float>(i, j) = rnd();
+        data.at<float>(i, 3) = data.at<float>(i, 1);
+        data.at<float>(i, 4) = 0.0f;
+        labels.at<float>(i, 0) = rnd(); labels.at<float>(i, 1) = rnd();
+    }
+    ColPivHouseholderQRSolver solver;
+    Mat x = solver.solve(data, labels, Regulariser());
+    EXPECT_EQ(solver.full_rank, 5);
+    EXPECT_EQ(solver.rank, 3);
+    for (int i = 0; i < 5; ++i)
+        for (int j = 0; j < 2; ++j) EXPECT_TRUE(std::isfinite(x.at<float>(i, j)));
+    EXPECT_EQ(x.at<float>(4, 0), 0.0f);
+    EXPECT_EQ(x.at<float>(4, 1), 0.0f);
+    // the reference's remedy: "Increase lambda"
+    Mat x2 = solver.solve(data, labels, Regulariser(Regulariser::RegularisationType::Manual, 0.1f, true));
+    EXPECT_EQ(solver.rank, 5);
+}
+
+TEST(ColPivHouseholderQRSolver, IllConditionedButNonSingularIsSolvedToTheEnd)   // the stop rule looks at the exact column norm
+{
+    // G = Q diag(1 ... 1e-5) Q^T through its square root: the down-dated column norms are noise at the end, the exact ones are not
+    const int n = 48;
+    std::vector<double> Q((size_t)n * n);
+    unsigned s = 99u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (double)((s >> 8) & 0xffff) / 65536.0 - 0.5; };
+    for (auto& q : Q) q = rnd();
+    for (int j = 0; j < n; ++j) {      // Gram-Schmidt, twice
+        for (int pass = 0; pass < 2; ++pass)
+            for (int k = 0; k < j; ++k) {
+                double d = 0.0;
+                for (int i = 0; i < n; ++i) d += Q[(size_t)i * n + j] * Q[(size_t)i * n + k];
+                for (int i = 0; i < n; ++i) Q[(size_t)i * n + j] -= d * Q[(size_t)i * n + k];
+            }
+        double nn = 0.0;
+        for (int i = 0; i < n; ++i) nn += Q[(size_t)i * n + j] * Q[(size_t)i * n + j];
+        for (int i = 0; i < n; ++i) Q[(size_t)i * n + j] /= std::sqrt(nn);
+    }
+    Mat A(n, n, CV_32FC1), b(n, 2, CV_32FC1);      // A = diag(sqrt s) Q^T: A^T A = Q diag(s) Q^T
+    std::vector<double> Gd((size_t)n * n, 0.0), rhs((size_t)n * 2, 0.0);
+    for (int i = 0; i < n; ++i) {
+        const double si = std::pow(10.0, -5.0 * i / (n - 1));
+        for (int j = 0; j < n; ++j) A.at<float>(i, j) = (float)(std::sqrt(si) * Q[(size_t)j * n + i]);
+        b.at<float>(i, 0) = (float)rnd(); b.at<float>(i, 1) = (float)rnd();
+    }
+    for (int r = 0; r < n; ++r)
+        for (int i = 0; i < n; ++i) {
+            for (int j = 0; j < n; ++j) Gd[(size_t)i * n + j] += (double)A.at<float>(r, i) * (double)A.at<float>(r, j);
+            for (int c = 0; c < 2; ++c) rhs[(size_t)i * 2 + c] += (double)A.at<float>(r, i) * (double)b.at<float>(r, c);
+        }
+    // float64 reference: Gaussian elimination with partial pivoting
+    for (int k = 0; k < n; ++k) {
+        int p = k;
+        for (int r = k + 1; r < n; ++r) if (std::fabs(Gd[(size_t)r * n + k]) > std::fabs(Gd[(size_t)p * n + k])) p = r;
+        for (int c = 0; c < n; ++c) std::swap(Gd[(size_t)k * n + c], Gd[(size_t)p * n + c]);
+        for (int c = 0; c < 2; ++c) std::swap(rhs[(size_t)k * 2 + c], rhs[(size_t)p * 2 + c]);
+        for (int r = k + 1; r < n; ++r) {
+            const double l = Gd[(size_t)r * n + k] / Gd[(size_t)k * n + k];
+            for (int c = k; c < n; ++c) Gd[(size_t)r * n + c] -= l * Gd[(size_t)k * n + c];
+            for (int c = 0; c < 2; ++c) rhs[(size_t)r * 2 + c] -= l * rhs[(size_t)k * 2 + c];
+        }
+    }
+    for (int i = n - 1; i >= 0; --i)
+        for (int c = 0; c < 2; ++c) {
+            for (int j = i + 1; j < n; ++j) rhs[(size_t)i * 2 + c] -= Gd[(size_t)i * n + j] * rhs[(size_t)j * 2 + c];
+            rhs[(size_t)i * 2 + c] /= Gd[(size_t)i * n + i];
+        }
+    ColPivHouseholderQRSolver solver;
+    Mat x = solver.solve(A, b, Regulariser());
+    EXPECT_EQ(solver.rank, n);      // (an early stop would have zeroed the last coefficients: error of order one)
+    double num = 0.0, den = 0.0;
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < 2; ++c) { const double d = x.at<float>(i, c) - rhs[(size_t)i * 2 + c]; num += d * d; den += rhs[(size_t)i * 2 + c] * rhs[(size_t)i * 2 + c]; }
+    EXPECT_TRUE(std::sqrt(num / den) < 0.05);
+}
 
 // ---- SupervisedDescentOptimiser (SDO.cpp) ----------------------------------------------------------------------
 template <typename ForwardIterator, typename T>

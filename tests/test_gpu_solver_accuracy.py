@@ -73,28 +73,41 @@ def test_badly_scaled_columns(built, decades, expect_f32):
     assert pred <= 2e-5 and np.median(row_err) <= 6e-5 and row_err.max() <= 1e-3
 
 
+def _same_bits_over_chunkings(monkeypatch, F, N, M, caps, reps, seed, check_f64):
+    rng = np.random.default_rng(seed)
+    A = (rng.standard_normal((N, F)) * rng.uniform(0.05, 0.4, F)).astype(np.float32)
+    b = rng.standard_normal((N, M)).astype(np.float32)
+    ref, solves = None, 0
+    for cap in caps:
+        monkeypatch.setenv("SDM_SOLVE_BS_CAP", cap)
+        ctx = Context(0)
+        for _ in range(reps):
+            R, _lam = ctx.solve_normal_equations(A, b, 0, 1.0, True)
+            R = np.ascontiguousarray(R)
+            solves += 1
+            if ref is None:
+                ref = R.copy()
+                if check_f64:
+                    G = A.astype(np.float64).T @ A.astype(np.float64) + np.eye(F)
+                    want = np.linalg.solve(G, A.astype(np.float64).T @ b.astype(np.float64))
+                    assert np.abs(R - want).max() <= 2e-5 * np.abs(want).max()
+            differing = int((R.view(np.uint32) != ref.view(np.uint32)).sum())
+            assert differing == 0, "cap %s, solve %d: %d entries differ from the first solve" % (cap, solves, differing)
+        ctx.close()
+    return solves
+
+
 def test_back_substitution_does_not_depend_on_the_column_chunking(built, monkeypatch):
     """Round 5: the persistent back substitution runs one workgroup per tile row and CHUNK of right-hand-side column tiles; the rows of
     two chunks share 128-byte lines of the solution, written and read by workgroups on different XCDs whose L2s are not coherent with
-    each other.  Before the solution tiles travelled through agent-scope accesses one solve in ~70 came out with a column tile wrong
+    each other.  Before the solution tiles travelled through agent-scope accesses one solve in 74 came out with a column tile wrong
     from one tile row on.  Every chunking (SDM_SOLVE_BS_CAP = column tiles per workgroup, read at sdm_create) and every repetition must
-    give the same bits; 144 right-hand sides = nine column tiles, 24 tile rows."""
-    rng = np.random.default_rng(51)
-    F, N, M = 3000, 4096, 144
-    A = (rng.standard_normal((N, F)) * rng.uniform(0.05, 0.4, F)).astype(np.float32)
-    b = rng.standard_normal((N, M)).astype(np.float32)
-    ref = None
-    for cap in ("1", "2", "5", "3", "1"):
-        monkeypatch.setenv("SDM_SOLVE_BS_CAP", cap)
-        ctx = Context(0)
-        for _ in range(6):
-            R, _lam = ctx.solve_normal_equations(A, b, 0, 1.0, True)
-            R = np.ascontiguousarray(R)
-            if ref is None:
-                ref = R.copy()
-                G = A.astype(np.float64).T @ A.astype(np.float64) + np.eye(F)
-                want = np.linalg.solve(G, A.astype(np.float64).T @ b.astype(np.float64))
-                assert np.abs(R - want).max() <= 2e-5 * np.abs(want).max()
-            differing = int((R.view(np.uint32) != ref.view(np.uint32)).sum())
-            assert differing == 0, "cap %s: %d entries differ from the first solve" % (cap, differing)
-        ctx.close()
+    give the same bits; 144 right-hand sides = nine column tiles, 24 tile rows.  300 solves: a bug of that rate is seen with
+    probability 1 - (73 / 74)^300 = 98 % (the 30 solves of round 5 would have missed it two times in three)."""
+    assert _same_bits_over_chunkings(monkeypatch, 3000, 4096, 144, ("1", "2", "5", "3", "1"), 60, 51, True) == 300
+
+
+def test_back_substitution_same_bits_with_the_chip_full(built, monkeypatch):
+    """The RCR-68 geometry (F = 27 201: 213 tile rows x nine column tiles, more workgroups than compute units, every XCD polling):
+    the chunkings 1 and 3 and the default, six solves each."""
+    assert _same_bits_over_chunkings(monkeypatch, 27201, 2048, 144, ("1", "3", "9"), 6, 52, False) == 18

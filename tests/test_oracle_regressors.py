@@ -266,3 +266,28 @@ def test_col_piv_qr_factorisation_properties():
     G = data.astype(np.float64).T @ data.astype(np.float64) + 0.5 * np.eye(12)
     x64 = np.linalg.solve(G, data.astype(np.float64).T @ y.astype(np.float64))
     assert np.linalg.norm(x - x64) / np.linalg.norm(x64) < 2e-6
+
+
+def ill_conditioned_system(n, cond, seed):
+    """A (n x n) with A^T A = Q diag(1 ... 1 / cond) Q^T, and right-hand sides: non-singular, but the late entries of a
+    down-dated column-norm table are rounding noise."""
+    rng = np.random.default_rng(seed)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    s = np.logspace(0.0, -np.log10(cond), n)
+    A = (np.sqrt(s)[:, None] * Q.T).astype(f32)
+    b = rng.standard_normal((n, 3)).astype(f32)
+    return A, b
+
+
+@pytest.mark.parametrize("n,cond", [(40, 1e5), (80, 1e6)])
+def test_col_piv_qr_ill_conditioned_but_non_singular_is_factored_to_the_end(n, cond):
+    """Eigen 3.2 decides to stop on the EXACT squared norm of the selected column (recomputed), not on the down-dated
+    table entry -- on these matrices the table entries go non-positive 2 to 17 steps early (the round-5 restatement stopped there
+    and returned zero coefficients for the rest: a finite, wrong regressor); with the exact norm the factorisation runs to the end."""
+    A, b = ill_conditioned_system(n, cond, seed=int(cond) % 1000 + n)
+    solver = o.ColPivHouseholderQRSolver()
+    x = solver.solve(A, b, o.Regulariser())
+    assert solver.nonzero_pivots == n
+    G = A.astype(np.float64).T @ A.astype(np.float64)
+    x64 = np.linalg.solve(G, A.astype(np.float64).T @ b.astype(np.float64))
+    assert np.linalg.norm(x - x64) / np.linalg.norm(x64) < 0.05
