@@ -563,7 +563,7 @@ def main():
         ctx68.set_templates(None)
         ctx68.enable_timing(False)
         ctx68.set_x_device(d_x068.data_ptr(), nb68)
-        hog_bytes68 = 0      # 2L = 136 > 64: this cascade runs through the feature matrix (csrc/sdm_capi.hip fused_ok): SURVEY 8d's full byte count
+        hog_bytes68 = 0      # 2L = 136 > 64: this cascade runs through the feature matrix (csrc/sdm_capi_detect.hip fused_ok): SURVEY 8d's full byte count
         idx68_levels = []      # (half-width and cvRound'ed centres per level: the integer decisions of the parity block)
         for l in range(n_levels):
             ctx68.hog_features(l)

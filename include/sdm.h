@@ -59,12 +59,12 @@ typedef struct sdm_ctx sdm_ctx;
  * measured with HIP events on the handle's stream.  The solver slots mirror the four stages
  * VerbosePartialPivLUSolver prints (include/superviseddescent/verbose_solver.hpp:66-97). */
 enum {
-    SDM_T_HOG = 0,      /* hog_batch_kernel                                  */
-    SDM_T_APPLY = 1,    /* apply_partial_kernel + apply_reduce_kernel        */
-    SDM_T_GRAM = 2,     /* "A^T * A" and A^T * b                             */
-    SDM_T_REG = 3,      /* "AtA + Reg"                                       */
-    SDM_T_FACTOR = 4,   /* "Decomposition" + forward substitution            */
-    SDM_T_BACKSOLVE = 5,/* "solve()"                                         */
+    SDM_T_HOG = 0,      /* feature extraction: hog_packed_kernel (hog_fast_kernel / hog_batch_kernel for the shapes it does not serve)   */
+    SDM_T_APPLY = 1,    /* detect: desc_kernel<FUSED> + apply_reduce_kernel; otherwise apply_tiled_f16_kernel (apply_tiled_kernel) + apply_reduce_kernel */
+    SDM_T_GRAM = 2,     /* "A^T * A" and A^T * b: split_planes_f16_kernel + syrk_tn_split_w4_kernel                                     */
+    SDM_T_REG = 3,      /* "AtA + Reg"                                                                                                    */
+    SDM_T_FACTOR = 4,   /* "Decomposition" + both substitutions (blocked Cholesky; or the column-pivoted QR)                              */
+    SDM_T_BACKSOLVE = 5,/* "solve()" -- 0 since the back substitution runs inside the factorisation's launch sequence                     */
     SDM_T_ALLREDUCE = 6,
     SDM_T_COUNT = 8
 };

@@ -1071,9 +1071,9 @@ hog_fast_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float* 
 #define HP_RAWSQRT 1
 #endif             /* plan: among equally dense group sizes prefer one with at least two passes per wave (measured: the smaller group wins, 1.54 -> 1.50 ms) */
 #endif
-#ifndef HP_ABL
-#define HP_ABL 0                    /* experiments: 1 no folds, 2 no finish, 3 no column read-modify-write, 4 no image loads, 5 no gradient, 6 folds without their matrix instructions, 7 no per-row LDS table reads, 8 no resize arithmetic, 9 no binning, 10 no square root */
-#endif
+// (The ablation switches of rounds 3-6 -- HP_ABL = 1 ... 15: no folds, no read-modify-write, no image loads, conflict-free operand
+//  reads, ... -- are scripts/experiments/hog_packed_ablations.patch; scripts/r6_hog_lds_variants.sh applies it to a copy and builds
+//  the variants.  Their measurements: profiles/r04_hog_ablations.txt, profiles/r06_hog_lds.txt.)
 #define HP_ROWS_BYTES(O) ((size_t)2 * (O) * HP_ST * 8)
 #define HP_HIST_BYTES(O, CC) ((size_t)2 * (O) * (CC) * 4)
 #ifndef HP_STAGE_TEX
@@ -1378,7 +1378,7 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
     asm volatile("" : "+v"(spread_sel));
     const int li = lane & 15, lq = lane >> 4;
 
-    for (int t = t_first; t < (HP_ABL == 13 ? t_first : npass); ++t) {
+    for (int t = t_first; t < npass; ++t) {
         const int pt = pass0 + t;
         // ---- this lane's column in this pass -----------------------------------------------------------------------------
         const unsigned desc = plan.lane_tab[pt * 64 + lane];
@@ -1438,23 +1438,18 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
 
         // ---- row loop ----------------------------------------------------------------------------------------------------------
         // the image loads of row y: the two source rows' byte offsets come from the row table (one broadcast 8-byte LDS read)
-        const i32x2 abl_rr = *(const i32x2*)&rowtab[0], abl_bb = *((const i32x2*)&rowtab[0] + 1);
-        const f32x2 abl_ws = SPEC ? wstab[0] : (f32x2){0.5f, 0.5f};
         auto issue_row = [&](int y, unsigned short& q0, unsigned short& q1) {
-            const i32x2 rr = (HP_ABL == 7 || HP_ABL == 11) ? abl_rr : *(const i32x2*)&rowtab[SPEC ? (y >= 2 ? y - 2 : y + S - 2) : y];
-            if (HP_ABL == 4) { q0 = (unsigned short)(vb + rr.x); q1 = (unsigned short)(vb + rr.y); return; }
+            const i32x2 rr = *(const i32x2*)&rowtab[SPEC ? (y >= 2 ? y - 2 : y + S - 2) : y];
             // (the row offset stays in the VECTOR offset: the hardware range check that yields the black canvas covers voffset only)
             q0 = __builtin_amdgcn_raw_buffer_load_b16(img_rsrc, vb + rr.x, 0, 0);
             q1 = __builtin_amdgcn_raw_buffer_load_b16(img_rsrc, vb + rr.y, 0, 0);
         };
         auto horizontal = [&](unsigned short q0, unsigned short q1, int& H0, int& H1) {
-            if (HP_ABL == 8) { H0 = q0; H1 = q1; return; }
             H0 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, spread_bytes(q0, spread_sel)), wpk2, 0u, false);
             H1 = (int)__builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, spread_bytes(q1, spread_sel)), wpk2, 0u, false);
         };
         auto vertical = [&](int H0, int H1, int y) -> float {
-            if (HP_ABL == 8) return (float)(H0 + H1);
-            const i32x2 bb = (HP_ABL == 7 || HP_ABL == 12) ? abl_bb : *((const i32x2*)&rowtab[y] + 1);      // the row's two weights << 12
+            const i32x2 bb = *((const i32x2*)&rowtab[y] + 1);      // the row's two weights << 12
             const int out = (int)((mul_hi_u24_vv((unsigned)bb.x, (unsigned)H0 & ~15u) + mul_hi_u24_vv((unsigned)bb.y, (unsigned)H1 & ~15u) + 2u) >> 2);
             return (float)out;
         };
@@ -1476,7 +1471,6 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
         // matrix-core rows 0..7, the 8 of band b + 1's slot the rows 8..15 (idle until now) -- used for the last two bands of a pass,
         // which are complete at the same pixel row: four fold events per pass instead of five.
         auto fold_band = [&](const int b, const bool pair = false) __attribute__((always_inline)) {
-            if (HP_ABL == 1) return;
             const int sl = b & 1;
             wave_sync();
             f32x4 fa0[MT], fa1[MT];
@@ -1538,11 +1532,6 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
                 if (kp < 6 || kp < nkp) {      // (a 55-column pass leaves the last 8 lanes without a column: 14 products instead of 16)
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
-                        if (HP_ABL == 6) {      // (timing experiment: the fold's LDS traffic without its matrix instructions)
-                            fa0[mt][0] += a0v[mt][kp % 3] * wq[(2 * kp) >> 2][(2 * kp) & 3];
-                            fa1[mt][0] += a1v[mt][kp % 3] * wq[(2 * kp + 1) >> 2][(2 * kp + 1) & 3];
-                            continue;
-                        }
                         fa0[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0v[mt][kp % 3], wq[(2 * kp) >> 2][(2 * kp) & 3], fa0[mt], 0, 0, 0);
                         fa1[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1v[mt][kp % 3], wq[(2 * kp + 1) >> 2][(2 * kp + 1) & 3], fa1[mt], 0, 0, 0);
                     }
@@ -1600,14 +1589,14 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
             horizontal(q0[j], q1[j], H0, H1);
             if (!SPEC || y + 2 < S) issue_row(y + 2, q0[j], q1[j]);      // (generic: past the last row a harmless extra load of the last row)
             f32x2 qv = {0.0f, 0.0f};
-            if (grad && HP_ABL != 3) qv = *pend_p;
+            if (grad) qv = *pend_p;
             const float r0 = vertical(H0, H1, y);
-            if (grad && HP_ABL != 5) {
+            if (grad) {
                 const int yy = y - 1;                      // gradient of row y - 1 (hog.c:616-672)
                 const float gx = from_right(rm1) - from_left(rm1);
                 const float gy = r0 - rm2;
                 const float g2 = gx * gx + gy * gy;
-                const float gm = HP_ABL == 10 ? g2 : ((HP_RAWSQRT && RAW) ? __builtin_amdgcn_sqrtf(g2) : sqrt_int_up(g2));
+                const float gm = (HP_RAWSQRT && RAW) ? __builtin_amdgcn_sqrtf(g2) : sqrt_int_up(g2);
                 bool b0 = false, b1 = false, b2 = false;
                 int bin_any = 0;
                 unsigned rot_ux = 0, rot_uy = 0, rot_uw = 0;
@@ -1623,13 +1612,11 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
                     rot_ux = __builtin_bit_cast(unsigned, rx1); rot_uy = __builtin_bit_cast(unsigned, ry1); rot_uw = __builtin_bit_cast(unsigned, rw);
                 } else if constexpr (TO == 4) bin_sector4_bits(gx, gy, lv, b0, b1, b2);
                 else bin_sector<TO>(gx, gy, lv, TO, bin_any);      // (a zero gradient lands in bin 0 with magnitude 0)
-                if (HP_ABL == 3) { f32x2 dz = __builtin_elementwise_fma(pend_v, (f32x2){pend_g, pend_g}, qv); asm volatile("" :: "v"(dz), "v"(pend_p)); }
-                else if (HP_PKFMA) *pend_p = __builtin_elementwise_fma(pend_v, (f32x2){pend_g, pend_g}, qv);
+                if (HP_PKFMA) *pend_p = __builtin_elementwise_fma(pend_v, (f32x2){pend_g, pend_g}, qv);
                 else *pend_p = qv + pend_v;
                 const float* rt = lv.row_tab[yy];
                 f32x2 wsv;
-                if (HP_ABL == 7 || HP_ABL == 12) wsv = abl_ws;
-                else if (SPEC) wsv = wstab[yy];
+                if (SPEC) wsv = wstab[yy];
                 else wsv = (f32x2){rt[0], rt[1]};
                 const float ws0 = wsv.x, ws1 = wsv.y;
                 // (specialised instance: yy and with it the band are constants after unrolling; prev_by folds away)
@@ -1638,8 +1625,7 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
                     if (prev_by >= 0) fold_band(prev_by);
                     prev_by = cby;
                 }
-                if constexpr (HP_ABL == 9) pend_p = (lds_f32x2*)(size_t)cadr0;
-                else if constexpr (ROTB && HP_SIGNBITS) {
+                if constexpr (ROTB && HP_SIGNBITS) {
                     // the octant code straight from the three sign bits (shifts and shift-ors instead of three compares and three selects)
 #if HP_ALIGNBIT_CODE
                     // v_alignbit_b32(hi, lo, 31) = (hi << 1) | (lo >> 31): one instruction per further sign bit
@@ -1659,10 +1645,6 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
         };
         row_step(0, 0, false);
         row_step(1, 1, false);
-        if constexpr (HP_ABL == 14) {      // (timing experiment: the set-up of a pass without its rows)
-            asm volatile("" :: "v"(wq[0]), "v"(wq[1]), "v"(wq[2]), "v"(wq[3]), "v"(hrecv), "v"(recv), "v"(rm1));
-            continue;
-        }
         if constexpr (CELL > 0) {
 #pragma unroll
             for (int yrow = 2; yrow < SC; ++yrow) row_step(yrow & 1, yrow, true);
@@ -1689,7 +1671,7 @@ hog_packed_kernel(ImageSetDev imgs, const int* __restrict__ img_idx, const float
             const int ps = dfirst + j, lmp = lm0 + ps;
             if (!CELLS) {
                 float* hp = hist + hist_slot(ps) * HSTR;
-                if (HP_ABL != 2) hog_finish_direct<TO, TC>(hp, scratch, out_row + (long long)lmp * lv.P, lv, lane);
+                hog_finish_direct<TO, TC>(hp, scratch, out_row + (long long)lmp * lv.P, lv, lane);
                 if (HP_OVERLAY)      // the scratch sat on the column rows, which the next pass expects to be zero
                     for (int i = lane; i < (int)(packed_scratch_bytes(C, O) / 16); i += 64) ((f32x4*)scratch)[i] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
             }

@@ -1,4 +1,4 @@
-// sdm_kernels.h -- internal launch interface between the C-ABI (sdm_capi.hip) and the gfx950 kernels.
+// sdm_kernels.h -- internal launch interface between the C-ABI (sdm_capi_*.hip) and the gfx950 kernels.
 // Not part of the public boundary (that is include/sdm.h).
 #pragma once
 #include <hip/hip_runtime.h>
