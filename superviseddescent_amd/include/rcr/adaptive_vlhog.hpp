@@ -8,6 +8,7 @@
 //     kernel launch (detail::BatchedBackend in rcr/model.hpp) and operator() is never called;
 //   * operator()(parameters, level, training_index) itself -- the reference's per-sample entry point -- runs the
 //     same kernel for a batch of one row and returns the 1 x F feature row.
+// FixedHogTransform: the non-adaptive transform of examples/landmark_detection.cpp:158-269 as a library type.
 #pragma once
 
 #ifndef ADAPTIVE_VLHOG_HPP_
@@ -65,10 +66,33 @@ struct HogDeviceState {
     bool images_uploaded = false;
 };
 
+// the images of a transform -> the handle: colour images (cv::imread's BGR) are converted to gray once per image ON THE DEVICE
+// (sdm_upload_images_bgr_u8); only a list that mixes gray and colour images converts its colour members on the host first
+inline void upload_images(superviseddescent::hip::Handle& h, const std::vector<cv::Mat>& images)
+{
+    using superviseddescent::hip::check;
+    bool all_colour = !images.empty(), any_colour = false;
+    for (const auto& im : images) { all_colour = all_colour && im.channels() == 3; any_colour = any_colour || im.channels() == 3; }
+    std::vector<cv::Mat> gray;
+    std::vector<const uint8_t*> ptrs;
+    std::vector<int> w, hh, st;
+    for (const auto& im : images) {
+        gray.push_back((any_colour && !all_colour) ? to_gray(im) : im);
+        ptrs.push_back(gray.back().ptr<uint8_t>(0));
+        w.push_back(gray.back().cols);
+        hh.push_back(gray.back().rows);
+        st.push_back((int)gray.back().step());
+    }
+    if (all_colour)
+        check(sdm_upload_images_bgr_u8(h.get(), ptrs.data(), w.data(), hh.data(), st.data(), (int)ptrs.size(), 14), "sdm_upload_images_bgr_u8");
+    else
+        check(sdm_upload_images_u8(h.get(), ptrs.data(), w.data(), hh.data(), st.data(), (int)ptrs.size()), "sdm_upload_images_u8");
+}
+
 inline void configure(superviseddescent::hip::Handle& h, const std::vector<cv::Mat>& images,
                       const std::vector<HoGParam>& hog_params, const std::vector<std::string>& landmark_ids,
                       const std::vector<std::string>& right_eye_ids, const std::vector<std::string>& left_eye_ids,
-                      bool upload_images)
+                      bool upload)
 {
     using superviseddescent::hip::check;
     const std::vector<int> re = positions_of(landmark_ids, right_eye_ids, "rightEyeIdentifiers");
@@ -80,26 +104,17 @@ inline void configure(superviseddescent::hip::Handle& h, const std::vector<cv::M
     check(sdm_set_model_geometry(h.get(), (int)landmark_ids.size(), re.data(), (int)re.size(), le.data(), (int)le.size(),
                                  (int)lv.size(), lv.data()),
           "sdm_set_model_geometry");
-    if (upload_images) {
-        // colour images (cv::imread's BGR) are converted to gray once per image ON THE DEVICE (sdm_upload_images_bgr_u8);
-        // only a list that mixes gray and colour images converts its colour members on the host first
-        bool all_colour = !images.empty(), any_colour = false;
-        for (const auto& im : images) { all_colour = all_colour && im.channels() == 3; any_colour = any_colour || im.channels() == 3; }
-        std::vector<cv::Mat> gray;
-        std::vector<const uint8_t*> ptrs;
-        std::vector<int> w, hh, st;
-        for (const auto& im : images) {
-            gray.push_back((any_colour && !all_colour) ? to_gray(im) : im);
-            ptrs.push_back(gray.back().ptr<uint8_t>(0));
-            w.push_back(gray.back().cols);
-            hh.push_back(gray.back().rows);
-            st.push_back((int)gray.back().step());
-        }
-        if (all_colour)
-            check(sdm_upload_images_bgr_u8(h.get(), ptrs.data(), w.data(), hh.data(), st.data(), (int)ptrs.size(), 14), "sdm_upload_images_bgr_u8");
-        else
-            check(sdm_upload_images_u8(h.get(), ptrs.data(), w.data(), hh.data(), st.data(), (int)ptrs.size()), "sdm_upload_images_u8");
-    }
+    if (upload) upload_images(h, images);
+}
+
+// the geometry of the NON-adaptive transform (examples/landmark_detection.cpp:158-269): the same fixed-size patch at every
+// cascade level, no eye landmarks (NoNormalisation), no bias column -- sdm_hog_param::relative_patch_size == 0
+inline void configure_fixed(superviseddescent::hip::Handle& h, VlHogVariant variant, int num_cells, int cell_size, int num_bins,
+                            int num_landmarks, int n_levels)
+{
+    std::vector<sdm_hog_param> lv((size_t)(n_levels > 0 ? n_levels : 1),
+                                  sdm_hog_param{variant == VlHogVariantUoctti ? SDM_VARIANT_UOCTTI : SDM_VARIANT_DALALTRIGGS, num_cells, cell_size, num_bins, 0.0f});
+    superviseddescent::hip::check(sdm_set_model_geometry(h.get(), num_landmarks, nullptr, 0, nullptr, 0, (int)lv.size(), lv.data()), "sdm_set_model_geometry");
 }
 
 }  // namespace detail
@@ -153,6 +168,60 @@ private:
     std::vector<std::string> rightEyeIdentifiers;
     std::vector<std::string> leftEyeIdentifiers;
     std::shared_ptr<detail::HogDeviceState> state;
+};
+
+/** The HogTransform of the reference's examples/landmark_detection.cpp:158-269 -- the example defines it in its own source file;
+ *  here it is a library type so that the optimiser can route it to the batched device path (detail::BatchedBackend in
+ *  rcr/model.hpp, with superviseddescent::NoNormalisation): HoG features of a FIXED patch of num_cells * (cell_size / 2)
+ *  pixels half-width around every landmark, not resized, the same at every cascade level, no bias column.  Same constructor
+ *  and call signature as the example's class (`using HogTransform = rcr::FixedHogTransform;` ports it).  cell_size must be even (the example's patch is num_cells * cell_size pixels wide only then). */
+class FixedHogTransform {
+public:
+    FixedHogTransform(std::vector<cv::Mat> images, VlHogVariant vlhog_variant, int num_cells, int cell_size, int num_bins)
+        : images(std::move(images)), vlhog_variant(vlhog_variant), num_cells(num_cells), cell_size(cell_size), num_bins(num_bins),
+          state(std::make_shared<detail::HogDeviceState>())
+    {
+    }
+
+    /** Features of ONE sample (landmark_detection.cpp:203-262): 1 x (L * num_cells^2 * dim).  regressor_level is not used, as in the example. */
+    cv::Mat operator()(cv::Mat parameters, size_t /*regressor_level*/, int training_index = 0)
+    {
+        using superviseddescent::hip::check;
+        if (parameters.rows != 1) throw std::runtime_error("FixedHogTransform: parameters must be a single row");
+        std::lock_guard<std::mutex> lock(state->mu);   // the device handle is not thread-safe
+        if (!state->handle) state->handle.reset(new superviseddescent::hip::Handle(superviseddescent::hip::device()));
+        sdm_ctx* c = state->handle->get();
+        if (!state->images_uploaded || state_landmarks != parameters.cols / 2) {
+            detail::configure_fixed(*state->handle, vlhog_variant, num_cells, cell_size, num_bins, parameters.cols / 2, 1);
+            if (!state->images_uploaded) detail::upload_images(*state->handle, images);
+            state->images_uploaded = true;
+            state_landmarks = parameters.cols / 2;
+        }
+        cv::Mat row = parameters.isContinuous() ? parameters : parameters.clone();
+        check(sdm_set_sample_image_index(c, &training_index, 1), "sdm_set_sample_image_index");
+        check(sdm_set_x(c, row.ptr<float>(0), 1), "sdm_set_x");
+        const int F = sdm_feature_dim(c, 0);
+        check(F, "sdm_feature_dim");
+        cv::Mat features(1, F, CV_32FC1);
+        check(sdm_hog_features(c, 0, features.ptr<float>(0)), "sdm_hog_features");
+        return features;
+    }
+
+    // read access for the batched backend
+    const std::vector<cv::Mat>& get_images() const { return images; }
+    VlHogVariant get_variant() const { return vlhog_variant; }
+    int get_num_cells() const { return num_cells; }
+    int get_cell_size() const { return cell_size; }
+    int get_num_bins() const { return num_bins; }
+    /** Optional sample -> image map for batched calls; empty = row i uses image i (the example's training_index). */
+    std::vector<int> sample_image_index;
+
+private:
+    std::vector<cv::Mat> images;      // (by value as in the example -- `HogTransform({ image }, ...)` at :466 is a temporary; the pixel data is shared, not copied)
+    VlHogVariant vlhog_variant;
+    int num_cells, cell_size, num_bins;
+    std::shared_ptr<detail::HogDeviceState> state;
+    int state_landmarks = -1;
 };
 
 }  // namespace rcr

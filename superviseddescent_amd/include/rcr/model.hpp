@@ -67,13 +67,31 @@ private:
 }  // namespace rcr
 
 // ---------------------------------------------------------------------------------------------------------
-// Batched device path for (HogTransform, LinearRegressor<Solver>, InterEyeDistanceNormalisation).
+// Batched device path for (HogTransform, LinearRegressor<Solver>, InterEyeDistanceNormalisation) and for
+// (FixedHogTransform, LinearRegressor<Solver>, NoNormalisation).
 // ---------------------------------------------------------------------------------------------------------
 namespace superviseddescent {
 namespace detail {
 
-template <class Solver>
-struct BatchedBackend<rcr::HogTransform, LinearRegressor<Solver>, rcr::InterEyeDistanceNormalisation, void> {
+// What differs between the two transforms the device serves: how the geometry reaches the handle.
+inline void bind_transform(hip::Handle& h, rcr::HogTransform& hog, int /*num_landmarks*/, size_t n_levels)
+{
+    if (hog.get_hog_params().size() != n_levels) throw std::runtime_error("one HoGParam per regressor level expected");
+    rcr::detail::configure(h, hog.get_images(), hog.get_hog_params(), hog.get_landmark_ids(), hog.get_right_eye_ids(),
+                           hog.get_left_eye_ids(), true);
+}
+inline void bind_transform(hip::Handle& h, rcr::FixedHogTransform& hog, int num_landmarks, size_t n_levels)
+{
+    // landmark_detection.cpp:214-216: the same patch at every level ("we could use the regressorLevel to choose the window size ...")
+    rcr::detail::configure_fixed(h, hog.get_variant(), hog.get_num_cells(), hog.get_cell_size(), hog.get_num_bins(), num_landmarks, (int)n_levels);
+    rcr::detail::upload_images(h, hog.get_images());
+}
+
+/** The launch sequences of a cascade level for a transform the device serves (`Hog`: rcr::HogTransform with
+ *  rcr::InterEyeDistanceNormalisation, or rcr::FixedHogTransform with NoNormalisation -- no eye landmarks in the geometry: the
+ *  kernels then normalise by one). */
+template <class Hog, class Solver, class Normalisation>
+struct HogBackend {
     static constexpr bool available = true;
     using Regressors = std::vector<LinearRegressor<Solver>>;
 
@@ -84,14 +102,13 @@ struct BatchedBackend<rcr::HogTransform, LinearRegressor<Solver>, rcr::InterEyeD
         return x;
     }
 
-    static void bind(hip::Handle& h, rcr::HogTransform& hog, int n_rows)
+    static void bind(hip::Handle& h, Hog& hog, int n_rows, int num_landmarks, size_t n_levels)
     {
-        rcr::detail::configure(h, hog.get_images(), hog.get_hog_params(), hog.get_landmark_ids(), hog.get_right_eye_ids(),
-                               hog.get_left_eye_ids(), true);
+        bind_transform(h, hog, num_landmarks, n_levels);
         if (hog.sample_image_index.empty()) {
             hip::check(sdm_set_sample_image_index(h.get(), nullptr, 0), "sdm_set_sample_image_index");
         } else {
-            if ((int)hog.sample_image_index.size() != n_rows) throw std::runtime_error("HogTransform::sample_image_index: one entry per row expected");
+            if ((int)hog.sample_image_index.size() != n_rows) throw std::runtime_error("sample_image_index: one entry per row expected");
             hip::check(sdm_set_sample_image_index(h.get(), hog.sample_image_index.data(), n_rows), "sdm_set_sample_image_index");
         }
     }
@@ -107,15 +124,14 @@ struct BatchedBackend<rcr::HogTransform, LinearRegressor<Solver>, rcr::InterEyeD
 
     /** reference superviseddescent.hpp:165-219: per level HOG -> targets/Gram/RHS -> solve -> apply. */
     template <class Callback>
-    static void train(Regressors& regressors, rcr::InterEyeDistanceNormalisation&, cv::Mat parameters, cv::Mat initialisations,
-                      cv::Mat templates, rcr::HogTransform& hog, Callback on_training_epoch_callback)
+    static void train(Regressors& regressors, Normalisation&, cv::Mat parameters, cv::Mat initialisations,
+                      cv::Mat templates, Hog& hog, Callback on_training_epoch_callback)
     {
-        if (hog.get_hog_params().size() != regressors.size()) throw std::runtime_error("one HoGParam per regressor level expected");
         hip::Handle h(hip::device());
         sdm_ctx* c = h.get();
         cv::Mat x0 = initialisations.isContinuous() ? initialisations : initialisations.clone();
         cv::Mat xs = parameters.isContinuous() ? parameters : parameters.clone();
-        bind(h, hog, x0.rows);
+        bind(h, hog, x0.rows, x0.cols / 2, regressors.size());
         set_templates(c, templates, x0.rows);
         hip::check(sdm_set_x(c, x0.ptr<float>(0), x0.rows), "sdm_set_x");
         hip::check(sdm_set_targets(c, xs.ptr<float>(0), xs.rows), "sdm_set_targets");
@@ -141,14 +157,13 @@ struct BatchedBackend<rcr::HogTransform, LinearRegressor<Solver>, rcr::InterEyeD
 
     /** reference superviseddescent.hpp:262-306 / 323-344. */
     template <class Callback>
-    static cv::Mat test(Regressors& regressors, rcr::InterEyeDistanceNormalisation&, cv::Mat initialisations, cv::Mat templates,
-                        rcr::HogTransform& hog, Callback on_regressor_iteration_callback)
+    static cv::Mat test(Regressors& regressors, Normalisation&, cv::Mat initialisations, cv::Mat templates,
+                        Hog& hog, Callback on_regressor_iteration_callback)
     {
-        if (hog.get_hog_params().size() != regressors.size()) throw std::runtime_error("one HoGParam per regressor level expected");
         hip::Handle h(hip::device());
         sdm_ctx* c = h.get();
         cv::Mat x0 = initialisations.isContinuous() ? initialisations : initialisations.clone();
-        bind(h, hog, x0.rows);
+        bind(h, hog, x0.rows, x0.cols / 2, regressors.size());
         for (size_t level = 0; level < regressors.size(); ++level) {
             cv::Mat R = regressors[level].x.isContinuous() ? regressors[level].x : regressors[level].x.clone();
             if (R.rows != sdm_feature_dim(c, (int)level) || R.cols != x0.cols) throw std::runtime_error("regressor does not match the HOG geometry");
@@ -167,6 +182,15 @@ struct BatchedBackend<rcr::HogTransform, LinearRegressor<Solver>, rcr::InterEyeD
         return fetch_x(c, x0.rows, x0.cols);
     }
 };
+
+// rcr::HogTransform + InterEyeDistanceNormalisation: the RCR cascade (apps/rcr/rcr-train.cpp, rcr::detection_model)
+template <class Solver>
+struct BatchedBackend<rcr::HogTransform, LinearRegressor<Solver>, rcr::InterEyeDistanceNormalisation, void>
+    : HogBackend<rcr::HogTransform, Solver, rcr::InterEyeDistanceNormalisation> {};
+// the non-adaptive transform + NoNormalisation: examples/landmark_detection.cpp:158-269, 433-436
+template <class Solver>
+struct BatchedBackend<rcr::FixedHogTransform, LinearRegressor<Solver>, NoNormalisation, void>
+    : HogBackend<rcr::FixedHogTransform, Solver, NoNormalisation> {};
 
 }  // namespace detail
 }  // namespace superviseddescent
