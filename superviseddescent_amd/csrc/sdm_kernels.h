@@ -290,6 +290,13 @@ inline size_t sdm_solve_shard_stage_tiles(int ncols, int world) { return (size_t
 //  pre-multiplied operands U_ii^-1 U_{i,i+1}, U_ii^-1 U_{i,i+2})
 inline size_t sdm_backsolve_flag_ints(int Fp) { return (((size_t)9 * (size_t)(Fp / 128) + 64) + 3) & ~(size_t)3; }
 inline size_t sdm_backsolve_flag_floats(int Fp) { return sdm_backsolve_flag_ints(Fp) + (size_t)2 * (size_t)(Fp / 128) * 128 * 128; }
+// LAYOUT CONTRACT of the factor left in G (round 5): U (upper, G = U^T U) overwrites the upper 128 x 128 tiles.  Inside every
+// factored DIAGONAL tile the strictly lower triangles of its eight 16 x 16 diagonal blocks are NOT zero: potrf_tile2_kernel stores
+// M_j = U_jj^-T (the inverse factors of the 16 x 16 blocks) there, and trsm_tile2_kernel -- also across the sharded broadcast of a
+// diagonal tile -- reads them instead of inverting again.  The other readers (row updates, trailing updates, the float16 split, the
+// back substitution through winv_t) touch off-diagonal tiles or the upper triangle only.  Anything that wants U_kk as a plain
+// upper-triangular tile (an export of the factor, a log-determinant, a second solve on the same G) must mask those triangles; the two
+// kernels must be replaced together (tests/test_gpu_solver_accuracy.py::test_two_and_three_tile_systems_pin_the_tile_kernels_contract).
 int sdm_launch_cholesky_solve(float* G, long long ldg, int F, int rhs0, int nrhs, float* R_out,
                               long long ldr, float* work, int* status, hipStream_t stream, const SolveAux* aux = nullptr,
                               const SolveShard* shard = nullptr);

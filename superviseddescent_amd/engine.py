@@ -674,21 +674,22 @@ class SupervisedDescentOptimiser:
         c.set_templates(templates)                                           # superviseddescent.hpp:195-197
         c.set_x(x0)
         c.set_targets(np.asarray(parameters, np.float32))
-        if rccl is not None:
-            if allreduce is not None or solve_collectives is not None or reduce_scatter is not None:
-                raise ValueError("train: pass either the RCCL communicator or the collective callbacks, not both")
-            rccl.install(c, shard_solve=rccl_shard_solve, reduce_scatter=rccl_shard_solve)
-        else:
-            c.set_allreduce(allreduce, world_size)
-            if hasattr(c, "set_solve_sharding"):
-                if solve_collectives is not None and rank is not None:
-                    c.set_solve_sharding(rank, world_size, *solve_collectives)
-                else:
-                    c.set_solve_sharding(0, 0, None, None)
-            if hasattr(c, "set_reduce_scatter"):
-                c.set_reduce_scatter(reduce_scatter if (solve_collectives is not None and rank is not None) else None)
+        if rccl is not None and (allreduce is not None or solve_collectives is not None or reduce_scatter is not None):
+            raise ValueError("train: pass either the RCCL communicator or the collective callbacks, not both")
         n_glob = n_train_global or c.N
         try:
+            # (inside the try: an install that fails half-way must not leave the communicator registered on a shared context)
+            if rccl is not None:
+                rccl.install(c, shard_solve=rccl_shard_solve, reduce_scatter=rccl_shard_solve)
+            else:
+                c.set_allreduce(allreduce, world_size)
+                if hasattr(c, "set_solve_sharding"):
+                    if solve_collectives is not None and rank is not None:
+                        c.set_solve_sharding(rank, world_size, *solve_collectives)
+                    else:
+                        c.set_solve_sharding(0, 0, None, None)
+                if hasattr(c, "set_reduce_scatter"):
+                    c.set_reduce_scatter(reduce_scatter if (solve_collectives is not None and rank is not None) else None)
             return self._train_levels(c, n_glob, on_training_epoch_callback)
         finally:
             if hasattr(c, "set_solver"):

@@ -146,13 +146,14 @@ def test_teacher_forced_training_level_by_level(built, name):
     # float32 PartialPivLU is; this is what backs the widened free-running bound of the test above.  Both distances are single
     # realisations of float32 rounding noise (3e-5 px rms per coordinate at the last RCR-22 level): over the eleven levels of the three
     # configurations the round-5 factorisation kernels sit at 0.32 ... 0.78 of the oracle's distance at ten and at 1.52 at one, the
-    # round-3 kernels they replace at 0.25 ... 0.99 at all eleven -- neither closer overall (five levels each way).  Asserted: over a
-    # configuration's levels the device is on average no further than the oracle (measured 0.47 ... 0.79), and at no single level more
-    # than twice as far.
+    # round-3 kernels they replace at 0.25 ... 0.99 at all eleven -- neither closer overall (five levels each way).  Asserted PER
+    # LEVEL (a mean hides a level): no level further than 1.75 x the oracle's distance, and over a configuration's
+    # levels no further on average (measured 0.47 ... 0.79).
     if vs64:
         ratios = [dg / dl for dg, dl in vs64]
+        print(name, "device / oracle distance from float64 per level:", " ".join("%.2f" % r for r in ratios))
+        assert max(ratios) <= 1.75, (name, ratios)
         assert float(np.mean(ratios)) <= 1.0, (name, ratios)
-        assert max(ratios) <= 2.0, (name, ratios)
 
 
 def test_rcr68_detect_shard_matches_oracle(built):

@@ -73,6 +73,23 @@ def test_badly_scaled_columns(built, decades, expect_f32):
     assert pred <= 2e-5 and np.median(row_err) <= 6e-5 and row_err.max() <= 1e-3
 
 
+@pytest.mark.parametrize("F", [129, 256, 300, 384])
+def test_two_and_three_tile_systems_pin_the_tile_kernels_contract(built, F):
+    """potrf_tile2_kernel leaves the inverses of a diagonal tile's 16 x 16 blocks in that tile's strictly lower block triangles and
+    trsm_tile2_kernel consumes them (csrc/sdm_kernels.h: LAYOUT CONTRACT).  With two or three tile rows every panel solve is exactly
+    that pair and nothing else hides an error: the solution against float64, tightly."""
+    rng = np.random.default_rng(F)
+    N, M = 4 * F, 20
+    A = rng.standard_normal((N, F)).astype(np.float32)
+    b = rng.standard_normal((N, M)).astype(np.float32)
+    ctx = Context(0)
+    R, _ = ctx.solve_normal_equations(A, b, 0, 0.5, True)
+    ctx.close()
+    A64 = A.astype(np.float64)
+    want = np.linalg.solve(A64.T @ A64 + 0.5 * np.eye(F), A64.T @ b.astype(np.float64))
+    assert np.linalg.norm(R - want) / np.linalg.norm(want) < 3e-6
+
+
 def _same_bits_over_chunkings(monkeypatch, F, N, M, caps, reps, seed, check_f64):
     rng = np.random.default_rng(seed)
     A = (rng.standard_normal((N, F)) * rng.uniform(0.05, 0.4, F)).astype(np.float32)
