@@ -109,3 +109,5 @@ for k,v in rows.items():
 json.dump({"batch": 4096, "source": "scripts/profile_bench.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of python bench.py --steps 20 --warmup 2 --no-cpu --train-rows 20000 --rcr68-shard 0; FETCH_SIZE x2 (gfx950), KB units", "kernels": hbm}, open(out+"/hbm_traffic.json","w"), indent=1)
 print(open(out+"/summary.txt").read())
 PY
+# the raw traces are tens of megabytes: only the summaries travel back (gpurun merges at most 64 MiB)
+rm -rf $OUT/trace $OUT/trace68 $OUT/p1 $OUT/p2 $OUT/p3 $OUT/p4
