@@ -219,7 +219,7 @@ int sdm_set_solve_sharding_rccl(sdm_ctx* ctx, void* nccl_comm, int rank, int wor
  * Without it, or with a replicated solve, the exchange stays the all-reduce.  NULL / enable = 0 removes it.
  * From 128 tile columns on (RCR-68) the callback is invoked once per RANGE of tile columns (four ranges), on the handle's second queue,
  * while sdm_gram_rhs' kernel is still multiplying the ranges behind it (round 4: the exchange runs behind the Gram kernel); the sums are
- * those of the one-piece exchange, bit for bit.  SDM_GRAM_XBLOCKS=1 in the environment keeps the single call. */
+ * those of the one-piece exchange, bit for bit.  sdm_debug_set_option(ctx, "gram_xblocks", 1) keeps the single call. */
 typedef int (*sdm_reduce_scatter_fn)(const void* send_ptr, void* recv_ptr, size_t count_f32, void* hip_stream, void* user);
 int sdm_set_reduce_scatter(sdm_ctx* ctx, sdm_reduce_scatter_fn fn, void* user);
 /* The same through RCCL on the communicator given to sdm_set_allreduce_rccl; the address may be NULL (looked up as ncclReduceScatter). */
@@ -283,9 +283,15 @@ int sdm_debug_patch(sdm_ctx* ctx, int level, int sample, int landmark, uint8_t* 
  * [0] geometry/tables [1] histogram clear [2] row loop [3] barrier [4] normalisation [5] output stores, [7] waves. */
 int sdm_debug_hog_profile(sdm_ctx* ctx, int level, unsigned long long* out8);
 int sdm_debug_gradient_table(sdm_ctx* ctx, int level, float* g_511x511, int* bin_511x511);
+/* Development switches by name (A/B handles of kernels kept as fallbacks, test knobs; the list is at the definition in
+ * csrc/sdm_capi_debug.hip).  The library reads no environment variable. */
+int sdm_debug_set_option(sdm_ctx* ctx, const char* name, int value);
+/* The Cholesky's trailing update C -= P^T P on the float16 matrix cores, by itself (unit test of syrk_update_f16_w4_kernel at panel
+ * groups of 128 ... 512 rows): P rows x wcols host, C wcols x wcols host in/out (upper 128 x 128 tiles with tile row < wcols_factor / 128). */
+int sdm_debug_update_f16(sdm_ctx* ctx, const float* P_host, int rows, int wcols, int wcols_factor, float factor_bound, float* C_host);
 /* The first n images (all width x height) of the context-owned single-channel image set, back to the host. */
 int sdm_debug_download_images(sdm_ctx* ctx, uint8_t* out, int n, int width, int height);
-/* Lane packing of the HOG launch (default on; also SDM_HOG_NO_PACK=1 in the environment at sdm_create): in SDM_HOG_COLUMNS
+/* Lane packing of the HOG launch (default on; also sdm_debug_set_option(ctx, "hog_no_pack", 1)): in SDM_HOG_COLUMNS
  * mode a wave walks a GROUP of patches of one sample in passes of 64 pixel columns instead of one patch per wave (a 50-column
  * ROI then fills the wave).  Same integer decisions; a patch cut by a pass boundary sums its cells from two partial folds.
  * Off = one patch (or one landmark pair) per wave, for A/B comparison in tests. */
@@ -306,12 +312,12 @@ int sdm_debug_hog_plan(int num_cells, int cell_size, int num_bins, int num_landm
 /* cut[num_landmarks]: 1 where the landmark's patch is cut by a pass boundary of that plan (its raw cell histograms arrive in two
  * parts, csrc/sdm_hog_fast.hip CELLS form); host only.  Returns SDM_ERR_INVALID when the geometry has no packed instance. */
 int sdm_debug_hog_plan_cut(int num_cells, int cell_size, int num_bins, int num_landmarks, int* cut);
-/* Round 4, A/B and tests: which launches the packed default mode uses.  fused != 0 (default; env SDM_DETECT_UNFUSED=1 turns it
+/* Round 4, A/B and tests: which launches the packed default mode uses.  fused != 0 (default; sdm_debug_set_option "detect_unfused" turns it
  * off): sdm_detect_batch runs  pixel kernel -> raw cell histograms -> descriptors x regressor slices on the 16-bit matrix cores
  * (csrc/sdm_desc.hip) -> landmark update, and never writes the N x F feature matrix (LinearRegressor::predict,
  * regressors.hpp:377-381, fused behind HogTransform::operator(), adaptive_vlhog.hpp:109-185) when 2L <= 64 (wider outputs stay on the
  * feature-matrix path, which is faster there; fused == 2 fuses them too).  split_store != 0 (default 0; env
- * SDM_HOG_SPLIT_STORE=1): sdm_hog_features / training produce the feature rows through the same raw cells + the store form of
+ * option "hog_split_store"): sdm_hog_features / training produce the feature rows through the same raw cells + the store form of
  * that kernel instead of normalising inside the pixel kernel (identical arithmetic, last-bit differences from the summation order
  * of the four clamped block terms). */
 int sdm_debug_set_detect_path(sdm_ctx* ctx, int fused, int split_store);

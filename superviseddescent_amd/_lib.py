@@ -28,7 +28,7 @@ EXPORTED = [
     "sdm_detect_batch", "sdm_detect_level", "sdm_set_targets", "sdm_gram_rhs", "sdm_set_allreduce", "sdm_set_allreduce_rccl", "sdm_allreduce_gram_rhs",
     "sdm_set_solve_sharding", "sdm_set_solve_sharding_rccl", "sdm_set_reduce_scatter", "sdm_set_reduce_scatter_rccl",
     "sdm_set_templates", "sdm_init_from_boxes", "sdm_normalised_errors", "sdm_solve", "sdm_set_solver", "sdm_last_rank", "sdm_solve_normal_equations", "sdm_solve_normal_equations_with", "sdm_train_level", "sdm_gram_device_ptr", "sdm_x_device_ptr", "sdm_features_device_ptr",
-    "sdm_enable_timing", "sdm_get_timing", "sdm_debug_patch", "sdm_debug_hog_profile", "sdm_debug_gradient_table",
+    "sdm_enable_timing", "sdm_get_timing", "sdm_debug_patch", "sdm_debug_hog_profile", "sdm_debug_gradient_table", "sdm_debug_update_f16", "sdm_debug_set_option",
     "sdm_debug_set_hog_packing", "sdm_debug_gram_fallbacks", "sdm_debug_update_fallbacks", "sdm_debug_hog_plan", "sdm_debug_hog_plan_cut", "sdm_debug_set_detect_path", "sdm_upload_images_bgr_u8", "sdm_debug_download_images",
 ]
 
@@ -148,6 +148,8 @@ def lib() -> ctypes.CDLL:
             "sdm_debug_patch": [c_void_p, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_uint8),
                                 ctypes.POINTER(ctypes.c_uint8), c_float_p, c_float_p],
             "sdm_debug_gradient_table": [c_void_p, c_int, c_float_p, c_int_p],
+            "sdm_debug_set_option": [c_void_p, ctypes.c_char_p, c_int],
+            "sdm_debug_update_f16": [c_void_p, c_float_p, c_int, c_int, c_int, ctypes.c_float, c_float_p],
             "sdm_debug_hog_profile": [c_void_p, c_int, ctypes.POINTER(ctypes.c_ulonglong)],
             "sdm_debug_set_hog_packing": [c_void_p, c_int],
             "sdm_debug_gram_fallbacks": [c_void_p],

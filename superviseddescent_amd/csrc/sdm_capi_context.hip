@@ -45,23 +45,10 @@ sdm_ctx* sdm_create(int device)
         fail(SDM_ERR_HIP, "hipStreamCreate failed"); delete c; return nullptr;
     }
     if (c->status.ensure(1, true, c->stream) || c->lambda_dev.ensure(1, true, c->stream)) { delete c; return nullptr; }
-    { const char* np = getenv("SDM_HOG_NO_PACK"); c->packing = !(np && np[0] == '1'); }
-    { const char* np = getenv("SDM_HOG_SPLIT_STORE"); c->split_store = np && np[0] == '1'; }
-    { const char* np = getenv("SDM_DETECT_UNFUSED"); c->fuse_apply = !(np && np[0] == '1'); }
-    auto env_on = [](const char* name) { const char* v = getenv(name); return v && v[0] == '1'; };
     for (int b = 0; b < sdm_ctx::XBLOCKS_MAX; ++b)
         if (hipEventCreateWithFlags(&c->gram_ev[b], hipEventDisableTiming) != hipSuccess) { fail(SDM_ERR_HIP, "hipEventCreate failed"); delete c; return nullptr; }
     if (hipEventCreateWithFlags(&c->gram_xdone, hipEventDisableTiming) != hipSuccess) { fail(SDM_ERR_HIP, "hipEventCreate failed"); delete c; return nullptr; }
-    { const char* v = getenv("SDM_GRAM_XBLOCKS"); c->env_xblocks = v ? atoi(v) : -1; }
-    c->env_fuse_wide = env_on("SDM_DETECT_FUSE_WIDE");
-    c->env_apply_f32 = env_on("SDM_APPLY_F32");
-    c->env_gram_f32 = env_on("SDM_GRAM_F32");
-    c->env_gram_bf16 = env_on("SDM_GRAM_BF16X3");
-    c->solve_aux.upd_f32_only = env_on("SDM_UPDATE_F32") ? 1 : 0;
-    { const char* v = getenv("SDM_SOLVE_UPD_MIN_TILES"); c->solve_aux.upd_min_tiles = v ? atoi(v) : 0; }
-    { const char* v = getenv("SDM_SOLVE_FINE_HEAD"); c->solve_aux.fine_head_max = v ? atoi(v) : 0; }
-    { const char* v = getenv("SDM_SOLVE_BS_CAP"); c->solve_aux.bs_cap = v ? atoi(v) : 0; }
-    { const char* v = getenv("SDM_SOLVE_SHARD_EMULATE"); c->env_shard_emulate = v ? atoi(v) : 0; }
+    // (the library reads no environment variable: the development switches are sdm_debug_set_option, sdm_capi_debug.hip)
     return c;
 }
 

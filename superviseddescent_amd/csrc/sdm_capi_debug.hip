@@ -167,5 +167,63 @@ int sdm_debug_gradient_table(sdm_ctx* c, int level, float* g, int* bin)
     return SDM_OK;
 }
 
+// Development switches (A/B handles of kernels that remain as fallbacks, knobs the tests turn): the library itself reads no environment
+// variable; the Python mirror forwards SDM_<NAME>=<value> of ITS environment through this call when it creates a context
+// (superviseddescent_amd/engine.py), which is what the A/B scripts and two tests use.  Names (value 0 / 1 unless noted):
+//   hog_no_pack (one patch per wave), hog_split_store (feature rows through cells + descriptor kernel), detect_unfused, detect_fuse_wide,
+//   apply_f32, gram_f32, gram_bf16x3, update_f32 (the f32 matrix-core kernels of rounds 1-2 / the three-bf16 form),
+//   gram_xblocks (n: exchange ranges behind the Gram kernel; -1 automatic), solve_upd_min_tiles (n), solve_fine_head (n),
+//   solve_bs_cap (n: right-hand-side column tiles per back-substitution workgroup), solve_shard_emulate (timing harness)
+int sdm_debug_set_option(sdm_ctx* c, const char* name, int value)
+{
+    if (!c || !name) return fail(SDM_ERR_INVALID, "bad arguments");
+    const std::string n(name);
+    if (n == "hog_no_pack") c->packing = value == 0;
+    else if (n == "hog_split_store") c->split_store = value != 0;
+    else if (n == "detect_unfused") c->fuse_apply = value == 0;
+    else if (n == "detect_fuse_wide") c->env_fuse_wide = value != 0;
+    else if (n == "apply_f32") c->env_apply_f32 = value != 0;
+    else if (n == "gram_f32") c->env_gram_f32 = value != 0;
+    else if (n == "gram_bf16x3") c->env_gram_bf16 = value != 0;
+    else if (n == "update_f32") c->solve_aux.upd_f32_only = value != 0 ? 1 : 0;
+    else if (n == "gram_xblocks") c->env_xblocks = value;
+    else if (n == "solve_upd_min_tiles") c->solve_aux.upd_min_tiles = value;
+    else if (n == "solve_fine_head") c->solve_aux.fine_head_max = value;
+    else if (n == "solve_bs_cap") c->solve_aux.bs_cap = value;
+    else if (n == "solve_shard_emulate") c->env_shard_emulate = value;
+    else return fail(SDM_ERR_INVALID, "sdm_debug_set_option: unknown option " + n);
+    return SDM_OK;
+}
+
+// The Cholesky's trailing update C -= P^T P on the float16 matrix cores by itself (csrc/sdm_gram_bf16.hip: split_planes_f16_scaled_kernel +
+// syrk_update_f16_w4_kernel, the four-wave instruction stream): P is rows x wcols (rows = a panel group: 128, 256, 384 or 512), the first
+// wcols_factor columns factor columns, the rest right-hand sides; C is wcols x wcols, its 128 x 128 tiles with tile row <= tile column and
+// tile row < wcols_factor / 128 are updated in place, the others left alone.  factor_bound = what the factorisation passes as its largest
+// diagonal entry (|P_ij| <= sqrt(factor_bound) for the factor columns).  For tests/test_gpu_gram_kernels.py: the factorisation itself
+// runs short panel groups only where the f32 kernel serves them.
+int sdm_debug_update_f16(sdm_ctx* c, const float* P_host, int rows, int wcols, int wcols_factor, float factor_bound, float* C_host)
+{
+    if (!c || !P_host || !C_host || rows <= 0 || rows > 512 || rows % 128 || wcols <= 0 || wcols % 128 || wcols_factor <= 0 || wcols_factor > wcols || wcols_factor % 128)
+        return fail(SDM_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    ScopedBuf<float> dP, dC; ScopedBuf<unsigned char> planes; ScopedBuf<unsigned> scales; ScopedBuf<int> status;
+    int rc;
+    if ((rc = dP.ensure((size_t)rows * wcols)) || (rc = dC.ensure((size_t)wcols * wcols)) || (rc = planes.ensure(sdm_update_f16_plane_bytes(512, wcols))) ||
+        (rc = scales.ensure(4)) || (rc = status.ensure(1, true, c->stream)))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(dP.p, P_host, (size_t)rows * wcols * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(dC.p, C_host, (size_t)wcols * wcols * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    const unsigned sc[4] = {__builtin_bit_cast(unsigned, factor_bound), 0u, 0u, __builtin_bit_cast(unsigned, factor_bound)};
+    HIP_TRY(hipMemcpyAsync(scales.p, sc, sizeof(sc), hipMemcpyHostToDevice, c->stream));
+    sdm_launch_update_split_f16(dP.p, wcols, rows, wcols, wcols_factor, planes.p, scales.p, 0, status.p, c->stream, false);
+    sdm_launch_update_f16(planes.p, rows, wcols, wcols_factor, dC.p, wcols, scales.p, 0, 0, 1 << 30, 0, 1, c->stream, 0);
+    HIP_TRY(hipGetLastError());
+    int st = 0;
+    HIP_TRY(hipMemcpyAsync(&st, status.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(C_host, dC.p, (size_t)wcols * wcols * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (st & 8) return fail(SDM_ERR_INVALID, "sdm_debug_update_f16: an operand left float16's range under the given factor_bound");
+    return SDM_OK;
+}
 
 }  // extern "C"

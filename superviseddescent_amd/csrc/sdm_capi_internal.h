@@ -101,16 +101,16 @@ struct sdm_ctx {
     DevBuf<float> qr_work;
     // The feature ROWS (training, sdm_hog_features) still come from the launch that normalises inside the pixel kernel: writing the
     // rows is HBM-bound on its own (55 us per 4 096 x 22 patches) and hides behind the pixel work there; measured 5 % slower split.
-    bool split_store = false;       // SDM_HOG_SPLIT_STORE=1: feature rows through cells + sdm_desc.hip's store form (A/B, tests)
-    bool fuse_apply = true;         // SDM_DETECT_UNFUSED=1: sdm_detect_batch through the feature matrix + apply GEMM (A/B)
+    bool split_store = false;       // option hog_split_store: feature rows through cells + sdm_desc.hip's store form (A/B, tests)
+    bool fuse_apply = true;         // option detect_unfused: sdm_detect_batch through the feature matrix + apply GEMM (A/B)
     bool fuse_wide = false;         // sdm_debug_set_detect_path(fused = 2): fuse also when 2L > 64 (tests of the wide launch)
-    bool packing = true;            // sdm_debug_set_hog_packing / SDM_HOG_NO_PACK=1: run the one-patch-per-wave kernel instead
-    // A/B switches of the environment, all read ONCE in sdm_create (no getenv inside a launch path)
-    bool env_fuse_wide = false;     // SDM_DETECT_FUSE_WIDE=1: fuse descriptor + apply also when 2L > 64
-    bool env_apply_f32 = false;     // SDM_APPLY_F32=1: sdm_apply always on the f32 matrix-core kernel
-    bool env_gram_f32 = false;      // SDM_GRAM_F32=1: Gram matrix on the f32 matrix-core kernel of rounds 1-2
-    bool env_gram_bf16 = false;     // SDM_GRAM_BF16X3=1: Gram matrix always in the three-bf16-piece form
-    int env_shard_emulate = 0;      // SDM_SOLVE_SHARD_EMULATE: timing harness of the sharded factorisation (scripts/sharded_solve_timing.py)
+    bool packing = true;            // sdm_debug_set_hog_packing / option hog_no_pack: run the one-patch-per-wave kernel instead
+    // development switches, set by sdm_debug_set_option (the library reads no environment variable; names in sdm_capi_debug.hip)
+    bool env_fuse_wide = false;     // option detect_fuse_wide: fuse descriptor + apply also when 2L > 64
+    bool env_apply_f32 = false;     // option apply_f32: sdm_apply always on the f32 matrix-core kernel
+    bool env_gram_f32 = false;      // option gram_f32: Gram matrix on the f32 matrix-core kernel of rounds 1-2
+    bool env_gram_bf16 = false;     // option gram_bf16x3: Gram matrix always in the three-bf16-piece form
+    int env_shard_emulate = 0;      // option solve_shard_emulate: timing harness of the sharded factorisation (scripts/sharded_solve_timing.py)
     int hog_mode = SDM_HOG_COLUMNS;
     int Fmax = 0;
     long long ldf = 0;      // feature row stride: round_up(Fmax,128) + 128*rhs_tiles (tail tiles = training targets)
@@ -175,7 +175,7 @@ struct sdm_ctx {
     hipEvent_t gram_ev[XBLOCKS_MAX] = {}; hipEvent_t gram_xdone = nullptr;
     int gram_blocks = 0;                 // ranges of the Gram matrix in G (0: one launch, no events recorded)
     int gram_block_c[XBLOCKS_MAX + 1] = {};      // their boundaries in OWNED column numbers (tile column = rank + world * number)
-    int env_xblocks = -1;                // SDM_GRAM_XBLOCKS: -1 = automatic (4 from 128 tile columns on), 1 = never, n = always n
+    int env_xblocks = -1;                // option gram_xblocks: -1 = automatic (4 from 128 tile columns on), 1 = never, n = always n
     int gram_fallbacks = 0;              // launches repeated with three bf16 pieces (sdm_debug_gram_fallbacks)
     int update_range_fallbacks = 0;      // factorisations that ran their trailing updates in f32 because the diagonal spanned > 2^20
     int gram_f32_fallbacks = 0;          // launches that ran on the f32 matrix-core kernel because the planes could not be allocated

@@ -19,6 +19,7 @@ built library or without a gfx950 device the constructors raise.
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Sequence
 
@@ -55,6 +56,10 @@ def _ip(a: np.ndarray):
     return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
 
 
+_DEV_OPTIONS = ("hog_no_pack", "hog_split_store", "detect_unfused", "detect_fuse_wide", "apply_f32", "gram_f32", "gram_bf16x3", "update_f32",
+                "gram_xblocks", "solve_upd_min_tiles", "solve_fine_head", "solve_bs_cap", "solve_shard_emulate")
+
+
 class Context:
     """Owner of one ``sdm_ctx`` (one GPU, one stream).  Thin, 1:1 with the C-ABI."""
 
@@ -65,6 +70,11 @@ class Context:
             raise SdmError(_lib.SDM_ERR_NO_DEVICE, self._lib.sdm_last_error().decode())
         self.device = device
         self._keep = []  # keeps ctypes callbacks alive
+        # development switches: the library reads no environment variable; this mirror -- what tests, bench legs and A/B scripts
+        # drive -- forwards SDM_<NAME>=<int> of the process environment to sdm_debug_set_option (names: csrc/sdm_capi_debug.hip)
+        for key, val in os.environ.items():
+            if key.startswith("SDM_") and key[4:].lower() in _DEV_OPTIONS:
+                self.set_option(key[4:].lower(), int(val))
         if stream is not None:
             check(self._lib.sdm_set_stream(self._h, ctypes.c_void_p(stream)))
         self.L = 0
@@ -72,6 +82,10 @@ class Context:
         # level -> token of the regressor the DEVICE holds (None: unknown).  Kept here, next to the device copy, so that
         # two optimisers sharing this context cannot mistake each other's upload for their own.
         self._resident = {}
+
+    def set_option(self, name: str, value: int):
+        """A development switch by name (sdm_debug_set_option)."""
+        check(self._lib.sdm_debug_set_option(self._h, name.encode(), int(value)))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -435,6 +449,13 @@ class Context:
         check(self._lib.sdm_debug_patch(self._h, level, sample, landmark, rsz.ctypes.data_as(u8),
                                         bins.ctypes.data_as(u8), _fp(hist), _fp(desc)))
         return rsz, bins, hist, desc
+
+    def debug_update_f16(self, P: np.ndarray, C: np.ndarray, wcols_factor: int, factor_bound: float) -> np.ndarray:
+        """C - P^T P on the float16 matrix cores (the Cholesky's trailing update by itself; sdm_debug_update_f16)."""
+        P = np.ascontiguousarray(P, np.float32)
+        out = np.ascontiguousarray(C, np.float32).copy()
+        check(self._lib.sdm_debug_update_f16(self._h, _fp(P), P.shape[0], P.shape[1], int(wcols_factor), float(factor_bound), _fp(out)))
+        return out
 
     def debug_hog_profile(self, level: int):
         out = (ctypes.c_ulonglong * 8)()
