@@ -375,7 +375,7 @@ def generate(update):
     e.op("s_waitcnt vmcnt(0) lgkmcnt(0)", "every load has landed (the LDS-direct ones past the end too) before the LDS is given back")
     for _ in range(3):
         e.op("s_nop 7", "(the last products' accumulators are read back below)")
-    e.op("s_cmp_eq_u32 %[writes], 0")
+    e.op("s_cmp_ge_i32 %[row0], %[rowend]", "this wave's 64 rows are written iff they lie above the tile column's diagonal and inside the rows that exist")
     e.op("s_cbranch_scc1 L_end_%=")
     if update:
         e.note("---- eight slabs only (s77 = slabs done): the half of C the loop has not requested")

@@ -246,14 +246,6 @@ syrk_tn_bf16x3_w_kernel(const bf16x8* __restrict__ planes, int NG, int ncols2, i
 // power limit holds at 1.35 GHz under this load.
 #include "sdm_gram_w4_asm.inc"
 
-// (an "s" operand the compiler keeps in a vector register is printed as one: values compared on the vector unit go through this)
-__device__ __forceinline__ unsigned gram_w4_to_sgpr(unsigned v)
-{
-    unsigned r;
-    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(r) : "v"(v));
-    return r;
-}
-
 struct GramW4Operands {
     const unsigned char *ua0, *ua1, *ub0, *ub1;      // (uniform) the wave's rows / its two pieces of the column operand, pieces 0 and 1, slab 0
     unsigned long long step;                         // bytes per slab
@@ -277,12 +269,12 @@ __device__ __forceinline__ GramW4Operands gram_w4_operands(const bf16x8* planes,
     o.lds = __builtin_amdgcn_readfirstlane(l0 + 16u * (unsigned)((wave >> 1) * 128 + (wave & 1) * 64));
     return o;
 }
-#define SDM_GRAM_W4_RUN(TEXT, O, NSLABS, CP, LDC, VC, UNSCALE, WRITES)                                                              \
+#define SDM_GRAM_W4_RUN(TEXT, O, NSLABS, CP, LDC, VC, UNSCALE, ROW0, ROWEND)                                                              \
     asm volatile(TEXT                                                                                                                \
                  :                                                                                                                   \
                  : [ua0] "s"(O.ua0), [ua1] "s"(O.ua1), [ub0] "s"(O.ub0), [ub1] "s"(O.ub1), [step] "s"(O.step), [nslabs] "s"(NSLABS), \
                    [lds] "s"(O.lds), [cp] "s"(CP), [ldc1] "s"((unsigned long long)(LDC) * 4), [ldc5] "s"((unsigned long long)(LDC) * 20), \
-                   [unscale] "s"(UNSCALE), [writes] "s"(WRITES), [va] "v"(O.va), [vb] "v"(O.vb), [baddr] "v"(O.baddr), [vc] "v"(VC) \
+                   [unscale] "s"(UNSCALE), [row0] "s"(ROW0), [rowend] "s"(ROWEND), [va] "v"(O.va), [vb] "v"(O.vb), [baddr] "v"(O.baddr), [vc] "v"(VC) \
                  : SDM_GRAM_W4_CLOBBERS)
 
 __global__ void __launch_bounds__(256)
@@ -297,14 +289,15 @@ syrk_tn_split_w4_kernel(const bf16x8* __restrict__ planes, int NG, int ncols2, i
     const GramW4Operands o = gram_w4_operands(planes, NG, ncols2, I, j, gb_raw);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long gi0 = (long long)I * 256 + wave * 64;
-    // only the 128 x 128 tiles on or above the tile diagonal, inside the matrix
-    const int gi0i = I * 256 + wave * 64;                     // (32-bit: the comparisons stay on the scalar unit)
-    const unsigned writes = gram_w4_to_sgpr(((gi0i >> 7) > j || gi0i >= ncols) ? 0u : 1u);
+    // only the 128 x 128 tiles on or above the tile diagonal, inside the matrix: the wave's rows gi0i .. gi0i + 63 are written iff
+    // gi0i < min((j + 1) * 128, ncols) -- compared on the scalar unit inside the stream
+    const int gi0i = I * 256 + wave * 64;
+    const int rowend = (j + 1) * 128 < ncols ? (j + 1) * 128 : ncols;
     const unsigned char* cp = (const unsigned char*)(C + gi0 * ldc + (long long)j * 128);
     const unsigned vc = 4u * (unsigned)(4 * (lane >> 5) * (int)ldc + (lane & 31));
     const unsigned unscale = __builtin_bit_cast(unsigned, GH_UNSCALE);
     const int nslabs = NG / 2;                                    // (a multiple of 4)
-    SDM_GRAM_W4_RUN(SDM_GRAM_W4_ASM, o, nslabs, cp, ldc, vc, unscale, writes);
+    SDM_GRAM_W4_RUN(SDM_GRAM_W4_ASM, o, nslabs, cp, ldc, vc, unscale, gi0i, rowend);
 }
 
 // ---- the Cholesky's trailing update C -= P^T P on the float16 matrix cores (round 3): P = the 512 rows of a panel group
@@ -407,14 +400,15 @@ syrk_update_f16_w4_kernel(const bf16x8* __restrict__ planes, int NG, int ncols2,
     const GramW4Operands o = gram_w4_operands(planes, NG, ncols2, I, j, gb_raw);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long gi0 = (long long)I * 256 + wave * 64;
-    const int gi0i = I * 256 + wave * 64;                     // (32-bit: the comparisons stay on the scalar unit)
-    const unsigned writes = gram_w4_to_sgpr(((gi0i >> 7) > j || gi0i >= TlocF * 128) ? 0u : 1u);      // (rows below the factor: right-hand sides x right-hand sides, never read)
+    const int gi0i = I * 256 + wave * 64;
+    const int rowend = (j + 1) * 128 < TlocF * 128 ? (j + 1) * 128 : TlocF * 128;      // (rows below the factor: right-hand sides x right-hand sides, never read)
     const unsigned char* cp = (const unsigned char*)(C + gi0 * ldc + (long long)j * 128);
     const unsigned vc = 4u * (unsigned)(4 * (lane >> 5) * (int)ldc + (lane & 31));
+    // 2^e as float bits by integer arithmetic (e = -60 ... 40: a normal number): the scalar unit's, no vector register on the way into the stream
     const int ef = f16_factor_exponent(scales);
-    const unsigned unscale = gram_w4_to_sgpr(__builtin_bit_cast(unsigned, __builtin_ldexpf(1.0f, (ef - 14) + ((j >= TlocF ? f16_rhs_exponent(scales, slot) : ef) - 14))));
+    const unsigned unscale = (unsigned)(127 + (ef - 14) + ((j >= TlocF ? f16_rhs_exponent(scales, slot) : ef) - 14)) << 23;
     const int nslabs = NG / 2;                                    // (whole 128-row panels: a multiple of 8)
-    SDM_GRAM_W4_RUN(SDM_UPDATE_W4_ASM, o, nslabs, cp, ldc, vc, unscale, writes);
+    SDM_GRAM_W4_RUN(SDM_UPDATE_W4_ASM, o, nslabs, cp, ldc, vc, unscale, gi0i, rowend);
 }
 
 // The same update for the HEAD of the look-ahead (the next group's four tile rows, on the factorisation's serial chain) while the

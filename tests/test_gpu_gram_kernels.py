@@ -102,3 +102,37 @@ def test_trailing_update_stream_by_itself(built, rows, factor_tiles, rhs_tiles):
     scale = np.abs(P).max() ** 2 * rows
     assert np.abs(got[written] - want[written]).max() <= 2e-6 * scale
     assert np.abs(got[written] - want[written]).max() > 0                 # (the update did run)
+
+
+def test_gram_leaves_the_tiles_below_the_diagonal_alone(some_faces):
+    """sdm_gram_rhs writes the 128 x 128 tiles with tile row <= tile column only (what the exchange packs and the factorisation reads);
+    a workgroup covers two tile rows of one tile column, and on the diagonal its lower two waves have nothing to write.  Round 6 found
+    them writing anyway (their write flag had gone through a hand-written v_readfirstlane): the flag is compared on the scalar unit now."""
+    import torch
+    images, boxes, gt = some_faces
+    x_star, x0, idx = synth.make_samples(boxes, gt, IDS, n_perturb=3, seed=608)
+    ctx = Context(0)
+    ctx.set_model_geometry(len(IDS), RE, LE, [HoGParam(1, 3, 8, 4, 0.6)])
+    ctx.upload_images(images)
+    ctx.set_sample_image_index(idx)
+    ctx.set_x(x0)
+    ctx.set_targets(x_star)
+    ctx.hog_features(0)
+    ctx.gram_rhs(0)
+    ctx.synchronize()
+    ptr, count = ctx.gram_device_ptr()
+
+    class Span:
+        __cuda_array_interface__ = {"shape": (count,), "typestr": "<f4", "data": (ptr, False), "version": 3, "strides": None}
+    G = torch.as_tensor(Span(), device="cuda:0")
+    ncols = int(round(count ** 0.5))
+    G = G.reshape(ncols, ncols)
+    marker = -12345.0
+    lower = torch.tril(torch.ones(ncols // 128, ncols // 128, device="cuda:0"), diagonal=-1).bool()
+    mask = lower.repeat_interleave(128, 0).repeat_interleave(128, 1)
+    G[mask] = marker                         # paint every tile below the diagonal, then form the Gram matrix again
+    torch.cuda.synchronize()
+    ctx.gram_rhs(0)
+    ctx.synchronize()
+    assert bool((G[mask] == marker).all())
+    ctx.close()
