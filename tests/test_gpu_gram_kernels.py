@@ -125,10 +125,12 @@ def test_gram_leaves_the_tiles_below_the_diagonal_alone(some_faces):
     class Span:
         __cuda_array_interface__ = {"shape": (count,), "typestr": "<f4", "data": (ptr, False), "version": 3, "strides": None}
     G = torch.as_tensor(Span(), device="cuda:0")
-    ncols = int(round(count ** 0.5))
-    G = G.reshape(ncols, ncols)
+    F = ctx.feature_dim(0)
+    Fp = -(-F // 128) * 128
+    ncols = count // Fp                      # (the buffer holds the Fp factor rows x all tile columns)
+    G = G.reshape(Fp, ncols)
     marker = -12345.0
-    lower = torch.tril(torch.ones(ncols // 128, ncols // 128, device="cuda:0"), diagonal=-1).bool()
+    lower = torch.tril(torch.ones(Fp // 128, ncols // 128, device="cuda:0"), diagonal=-1).bool()
     mask = lower.repeat_interleave(128, 0).repeat_interleave(128, 1)
     G[mask] = marker                         # paint every tile below the diagonal, then form the Gram matrix again
     torch.cuda.synchronize()
