@@ -428,9 +428,10 @@ def main():
     parts.append("")
     parts.append("#define SDM_GRAM_W4_CLOBBERS " + ", ".join(clob))
     parts.append("")
-    with open(OUT, "w") as f:
+    out = sys.argv[1] if len(sys.argv) > 1 else OUT      # (tests/test_gram_stream_generator.py writes to a scratch path and compares)
+    with open(out, "w") as f:
         f.write("\n".join(parts))
-    print("wrote", os.path.normpath(OUT), sum(len(p.splitlines()) for p in parts), "lines")
+    print("wrote", os.path.normpath(out), sum(len(p.splitlines()) for p in parts), "lines")
 
 
 if __name__ == "__main__":
