@@ -1,18 +1,21 @@
 #!/usr/bin/env python3
 """Writes superviseddescent_amd/csrc/sdm_gram_w4_asm.inc: the instruction streams of the four-wave float16-piece product kernels
-(sdm_gram_bf16.hip: syrk_tn_split_w4_kernel = A^T A / A^T b of regressors.hpp:208,225; syrk_update_f16_w4_kernel = the
-Cholesky's trailing update), one wave per SIMD, every register and every wait placed by hand.
+(sdm_gram_bf16.hip: syrk_tn_split_w4_kernel = A^T A / A^T b of regressors.hpp:208,225, one wave per SIMD; syrk_update_f16_w4_kernel =
+the Cholesky's trailing update, two waves per SIMD), every register and every wait placed by hand.
 
 Why a generator and not C++: the compiler-scheduled form of this loop (kept in scripts/experiments/gram_w4_cxx.patch) needs 498 of
 the wave's 512 registers for 352 live ones (sixteen unrolled steps fragment the tuple allocation), copies accumulator tiles around
-the fold, spills, and drains the load queue at the loop header.  Here the register map is fixed:
+the fold, spills, and drains the load queue at the loop header.  Here the register maps are fixed (MAPS below).  The Gram kernel's:
 
     a[0:127]    acc    eight 32 x 32 accumulator tiles (tile t = 4 m + n: rows 32 m.., columns 32 n.. of the wave's 64 x 128)
-    v[0:127]    tot    second accumulator level (Gram) / the tile of C read ahead (update)
+    v[0:127]    tot    second accumulator level
     v[128:191]  fa     the wave's own rows: [stage 0..3][piece 0..1][row tile 0..1] x 4 registers, straight from the planes
     v[192:223]  fb     the column operand from LDS: [column tile 0..3][piece 0..1] x 4 registers (ONE set, see below)
     v[224:231]  temporaries;  v232 va  v233 vb  v234 baddr  v235 vc (lane offsets: rows, columns, LDS fragment, C)
     s[64:..]    pointers and counters (copied from the operands: they are advanced)
+
+The trailing update's (one accumulator level at K <= 512, C read behind the loop): fa in v[0:63], fb in v[64:95], temporaries and lane
+offsets in v[96:107], sixteen landing registers for C in v[108:123] -- 124 + 128 registers, two waves per SIMD.
 
 One step = one 16-row slab S = 24 matrix instructions (per accumulator tile: low x high, high x low, high x high -- the
 eight-wave kernel's order).  The wave issues in order and has its SIMD to itself, so whatever is not a matrix instruction is
@@ -27,12 +30,11 @@ placed BEHIND one -- a load or an LDS read and a few scalar instructions at a ti
     products 8-15   acc[t] += fa[S][1][m] x fb[n][0]      behind them: LDS-direct loads of slab S+3 -> slot (S-1)&3,
                                                           ds_read_b128 low column pieces of S+1
     products 16-23  acc[t] += fa[S][0][m] x fb[n][0]      behind them: global_load_dwordx4 rows of slab S+4, piece 1 -> stage S&3
-                                                          (update: this wave's part of C, eight loads per step of the first 16)
 Loads beyond the last slab read on into the planes' padding (sdm_gram_bf16x3_plane_bytes) and are never multiplied: the number
 of loads per step is static.  The waits are COMPUTED: the generator keeps the order in which vector-memory loads and LDS reads
 were issued (both return in order) and writes "at most n outstanding" with n = what was issued behind the operation waited for
 (class Stream); the loop body is emitted for two consecutive trips and the second's text (the steady state) must equal the
-first's -- or the first trip is peeled, as in the update, whose first sixteen slabs carry the loads of C.
+first's.
 
 The second accumulator level is staggered: tile t is folded at the step behind slab 2 t + 1 of every 16 (256-row chunks as in
 rounds 2-5; a tile's first chunk is shorter), one tile every other step.  The tile order of a step's three product groups is
@@ -53,8 +55,22 @@ import sys
 
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "superviseddescent_amd", "csrc", "sdm_gram_w4_asm.inc")
 
-ACC, TOT, FA, FB, TMP = 0, 0, 128, 192, 224
-VA, VB, VBADDR, VC = 232, 233, 234, 235
+# register maps (vector registers; the accumulators are a[0:127] in both).  "wide": the map of the header, 236 + 128 registers = one
+# wave per SIMD.  "slim" (the trailing update, round 6): no second level and no tile of C held through the loop -- the rows' fragments,
+# the column fragments, temporaries and lane offsets in v[0:107], sixteen landing registers for C in v[108:123]: 124 + 128 registers,
+# TWO waves per SIMD, i.e. two workgroups per compute unit -- one's prologue (first operands) and epilogue (read C, subtract, store:
+# nothing a lone wave can overlap with products) run under the other's products.
+MAPS = {"wide": dict(TOT=0, FA=128, FB=192, TMP=224, VA=232, VB=233, VBADDR=234, VC=235, CT=None, NV=236),
+        "slim": dict(TOT=None, FA=0, FB=64, TMP=96, VA=104, VB=105, VBADDR=106, VC=107, CT=108, NV=124)}
+ACC = 0
+TOT = FA = FB = TMP = VA = VB = VBADDR = VC = CT = NV = None
+
+
+def use_map(name):
+    globals().update(MAPS[name])
+
+
+use_map("wide")
 S_UA0, S_UA1, S_UB0, S_UB1, S_STEP, S_NSLABS, S_S, S_LDS, S_T = 64, 66, 68, 70, 72, 74, 75, 76, 77
 S_CP, S_LDC1, S_LDC5, S_UNSCALE, S_CP0 = 78, 80, 82, 84, 86
 SLOT_BYTES = 8192
@@ -185,7 +201,7 @@ def step(s, S, cfg):
     """One slab (S: its number counted from the start of the emitted stream; only S mod 16 enters the text)."""
     q = S & 15
     st = S & 3
-    nt, idle, fold, cspread = cfg["ntiles"], cfg["idle"], cfg["fold"], cfg.get("cspread")
+    nt, idle, fold = cfg["ntiles"], cfg["idle"], cfg["fold"]
     live = [] if idle else [t for t in range(8) if (t & 3) < nt]
     tf = fold_at(q, fold)
     if tf is not None and tf not in live:
@@ -240,8 +256,6 @@ def step(s, S, cfg):
     f3 = []
     if not idle:
         f3 += [[lambda: load_a(s, S + 4, 1, 0)], [lambda: load_a(s, S + 4, 1, 1)]]      # rows of slab S + 4, piece 1 -> this stage (its piece 1 is consumed)
-    if cspread is not None and S < 16:
-        f3 += [[lambda i=i: cspread(i), lambda i=i: cspread(i + 1)] for i in range(8 * S, 8 * S + 8, 2)]
     place(len(order), lambda k: s.mfma(order[k], fa(st, 0, order[k] >> 2), fb(order[k] & 3, 0)), f3)
 
 
@@ -254,19 +268,6 @@ def advance_cp(s, inc):
     if inc is not None:
         s.op(f"s_add_u32 s{S_CP}, s{S_CP}, s{inc}")
         s.op(f"s_addc_u32 s{S_CP + 1}, s{S_CP + 1}, s{inc + 1}")
-
-
-def c_load(s, i, tracked):
-    """load i of the 128 of this wave's part of C (row i / 4 of c_rows(), column tile i % 4) into the second level's registers"""
-    m, e, inc = c_rows()[i // 4]
-    n = i % 4
-    text = f"global_load_dword {tot(4 * m + n, e)}, v{VC}, s[{S_CP}:{S_CP + 1}] offset:{128 * n}"
-    if tracked:
-        s.vmem(text, ("C", i))
-    else:
-        s.op(text)
-    if n == 3:
-        advance_cp(s, inc)
 
 
 def emit_variant(s, cfg):
@@ -295,10 +296,9 @@ def emit_variant(s, cfg):
     if not idle:
         for n in range(nt):
             read_b(s, 0, 1, n)
-    peel = cfg.get("cspread") is not None
     n_before = len(s.mfma_tiles)
 
-    def trip(base, peeled):
+    def trip(base):
         for q in range(16):
             step(s, base + q, cfg)
             if q & 3 == 3:
@@ -308,28 +308,18 @@ def emit_variant(s, cfg):
                     s.op(f"s_cbranch_scc1 {s.ref('done')}")
                 else:
                     s.op(f"s_mov_b32 s{S_S}, s{S_T}")
-                    s.op(f"s_cbranch_scc1 {s.ref('done')}" if peeled else f"s_cbranch_scc0 {s.ref('loop')}")
-    base = 0
-    if peel:
-        trip(0, True)                      # the first sixteen slabs carry the loads of C: code of their own
-        # The loop's text is the STEADY state's (third trip on).  Its first execution, slabs 16-31, still has loads of C in the
-        # queue: they are younger than anything a wait of those slabs is for, so the exact counts there are larger than the
-        # steady ones -- the steady text waits for a little more than it must (loads issued two slabs ago), never for less.
-        m0 = len(s.lines)
-        trip(16, False)
-        del s.lines[m0:]
-        base = 32
+                    s.op(f"s_cbranch_scc0 {s.ref('loop')}")
     s.label("loop")
     m1 = len(s.lines)
-    trip(base, False)
+    trip(0)
     m2 = len(s.lines)
-    trip(base + 16, False)                 # the steady state: must read the same
+    trip(16)                               # the steady state: must read the same
     assert [t for t, _ in s.lines[m1:m2]] == [t for t, _ in s.lines[m2:]], (cfg["ntiles"], cfg["idle"], "the loop's waits are not stationary")
     del s.lines[m2:]
     s.label("done")
     # spacing of two products into one accumulator tile, cyclically over the loop body
     per_trip = 3 * len([t for t in range(8) if (t & 3) < nt]) * 16 if not idle else 0
-    seq = s.mfma_tiles[n_before + (2 * per_trip if peel else 0):][:per_trip]
+    seq = s.mfma_tiles[n_before:][:per_trip]
     last = {}
     for i, t in enumerate(seq + seq):
         if t in last:
@@ -338,11 +328,67 @@ def emit_variant(s, cfg):
     s.op("s_branch L_epilogue_%=")
 
 
-def generate(update):
+def c_dst_slim(i):
+    """landing register of load i (of 128) of the wave's part of C in the slim map: the first 112 in one round (the fragment registers
+    are dead behind the loop), the last 16 in a second"""
+    if i < 96:
+        return f"v{i}"
+    if i < 112:
+        return f"v{CT + i - 96}"
+    return f"v{i - 112}"
+
+
+def generate_update():
+    """the trailing update on the slim register map (two waves per SIMD): the Gram loop without the second level, C read behind the loop"""
+    use_map("slim")
     parts = []
     s0 = Stream("x")
-    s0.note(f"{'trailing update C -= P^T P' if update else 'Gram tile'}")
-    # operands -> the fixed registers
+    s0.note("trailing update C -= P^T P, 124 + 128 registers")
+    entry(s0, False)
+    parts.append(s0)
+    s = Stream("n4")
+    emit_variant(s, {"ntiles": 4, "idle": False, "fold": False})
+    parts.append(s)
+    e = Stream("e")
+    epilogue_head(e, "every load has landed (the ones past the last slab too: their registers are reused below)")
+    rows = c_rows()
+
+    def loads(i0, i1):
+        for i in range(i0, i1):
+            m, ee, inc = rows[i // 4]
+            n = i % 4
+            e.op(f"global_load_dword {c_dst_slim(i)}, v{VC}, s[{S_CP}:{S_CP + 1}] offset:{128 * n}")
+            if n == 3:
+                advance_cp(e, inc)
+
+    def finish(i0, i1):
+        for i in range(i0, i1):
+            m, ee, inc = rows[i // 4]
+            n = i % 4
+            tmp = f"v{TMP + i % N_TMP}"
+            e.op(f"v_accvgpr_read_b32 {tmp}, {acc(4 * m + n, ee)}")
+            e.op(f"v_fma_f32 {tmp}, -{tmp}, s{S_UNSCALE}, {c_dst_slim(i)}", "(the scale is a power of two: the product is exact)" if i == 0 else None)
+            e.op(f"global_store_dword v{VC}, {tmp}, s[{S_CP0}:{S_CP0 + 1}] offset:{128 * n}")
+            if n == 3 and inc is not None:
+                e.op(f"s_add_u32 s{S_CP0}, s{S_CP0}, s{inc}")
+                e.op(f"s_addc_u32 s{S_CP0 + 1}, s{S_CP0 + 1}, s{inc + 1}")
+    e.note("---- C: rows 0-27 of this wave's 32 (x 4 per lane half) into the dead fragment registers + the landing registers")
+    loads(0, 112)
+    e.op("s_waitcnt vmcnt(0)")
+    finish(0, 16)
+    e.note("---- the last four rows into the registers just consumed; they land while the other 96 values are finished")
+    loads(112, 128)
+    finish(16, 112)
+    e.op("s_waitcnt vmcnt(0)")
+    finish(112, 128)
+    e.op("L_end_%=:")
+    parts.append(e)
+    use_map("wide")
+    return parts
+
+
+def entry(s0, zero_tot):
+    """operands -> the fixed registers, accumulators cleared"""
     for dst, name in ((S_UA0, "ua0"), (S_UA1, "ua1"), (S_UB0, "ub0"), (S_UB1, "ub1"), (S_STEP, "step"), (S_CP, "cp"), (S_LDC1, "ldc1"), (S_LDC5, "ldc5")):
         s0.op(f"s_mov_b64 s[{dst}:{dst + 1}], %[{name}]")
     for dst, name in ((S_NSLABS, "nslabs"), (S_LDS, "lds"), (S_UNSCALE, "unscale")):
@@ -351,10 +397,29 @@ def generate(update):
         s0.op(f"v_mov_b32 v{dst}, %[{name}]")
     s0.op(f"s_mov_b32 s{S_S}, 0")
     s0.op(f"s_mov_b64 s[{S_CP0}:{S_CP0 + 1}], s[{S_CP}:{S_CP + 1}]", "(the row pointer of the store walk)")
-    for i in range(128):
-        s0.op(f"v_mov_b32 v{TOT + i}, 0")
+    if zero_tot:
+        for i in range(128):
+            s0.op(f"v_mov_b32 v{TOT + i}, 0")
     for i in range(128):
         s0.op(f"v_accvgpr_write_b32 a{i}, 0")
+
+
+def epilogue_head(e, why):
+    e.op("L_epilogue_%=:")
+    e.op("s_waitcnt vmcnt(0) lgkmcnt(0)", why)
+    for _ in range(3):
+        e.op("s_nop 7", "(the last products' accumulators are read back below)")
+    e.op("s_cmp_ge_i32 %[row0], %[rowend]", "this wave's 64 rows are written iff they lie above the tile column's diagonal and inside the rows that exist")
+    e.op("s_cbranch_scc1 L_end_%=")
+
+
+def generate_gram():
+    """the Gram tile on the wide register map: two accumulator levels, (tot + acc) * unscale stored"""
+    use_map("wide")
+    parts = []
+    s0 = Stream("x")
+    s0.note("Gram tile")
+    entry(s0, True)
     for name, v, _ntiles, _idle in VARIANTS[1:]:
         s0.op(f"s_cmp_eq_u32 %[variant], {v}")
         s0.op(f"s_cbranch_scc1 L_entry_{name}_%=")
@@ -363,39 +428,17 @@ def generate(update):
         s = Stream(name)
         s.op(f"L_entry_{name}_%=:")
         s.note(f"==== variant {name}")
-        cfg = {"ntiles": ntiles, "idle": idle, "fold": (not update) and not idle}
-        if update and not idle:
-            # this wave's part of C, requested behind the third product group of the first sixteen slabs (8 loads each) into the
-            # registers of the second accumulator level; with eight slabs (a 128-row panel group) the other half behind the loop
-            cfg["cspread"] = lambda i, s=s: c_load(s, i, True)
-        emit_variant(s, cfg)
+        emit_variant(s, {"ntiles": ntiles, "idle": idle, "fold": not idle})
         parts.append(s)
     e = Stream("e")
-    e.op("L_epilogue_%=:")
-    e.op("s_waitcnt vmcnt(0) lgkmcnt(0)", "every load has landed (the LDS-direct ones past the end too) before the LDS is given back")
-    for _ in range(3):
-        e.op("s_nop 7", "(the last products' accumulators are read back below)")
-    e.op("s_cmp_ge_i32 %[row0], %[rowend]", "this wave's 64 rows are written iff they lie above the tile column's diagonal and inside the rows that exist")
-    e.op("s_cbranch_scc1 L_end_%=")
-    if update:
-        e.note("---- eight slabs only (s77 = slabs done): the half of C the loop has not requested")
-        e.op(f"s_cmp_ge_i32 s{S_T}, 16")
-        e.op("s_cbranch_scc1 L_cdone_%=")
-        for i in range(64, 128):
-            c_load(e, i, False)
-        e.op("s_waitcnt vmcnt(0)")
-        e.op("L_cdone_%=:")
-    e.op(f"s_mov_b64 s[{S_CP}:{S_CP + 1}], s[{S_CP0}:{S_CP0 + 1}]")
+    epilogue_head(e, "every load has landed (the LDS-direct ones past the end too) before the LDS is given back")
     for m, ee, inc in c_rows():
         for n in range(4):
             t = 4 * m + n
             tmp = f"v{TMP + (4 * ee + n) % N_TMP}"
             e.op(f"v_accvgpr_read_b32 {tmp}, {acc(t, ee)}")
-            if update:
-                e.op(f"v_fma_f32 {tmp}, -{tmp}, s{S_UNSCALE}, {tot(t, ee)}", "(the scale is a power of two: the product is exact)" if (m, ee, n) == (0, 0, 0) else None)
-            else:
-                e.op(f"v_add_f32 {tmp}, {tot(t, ee)}, {tmp}")
-                e.op(f"v_mul_f32 {tmp}, s{S_UNSCALE}, {tmp}")
+            e.op(f"v_add_f32 {tmp}, {tot(t, ee)}, {tmp}")
+            e.op(f"v_mul_f32 {tmp}, s{S_UNSCALE}, {tmp}")
             e.op(f"global_store_dword v{VC}, {tmp}, s[{S_CP}:{S_CP + 1}] offset:{128 * n}")
         advance_cp(e, inc)
     e.op("L_end_%=:")
@@ -417,16 +460,19 @@ def render(name, parts):
 
 
 def main():
-    clob = [f'"v{i}"' for i in range(236)] + [f'"a{i}"' for i in range(128)] + [f'"s{i}"' for i in range(64, 90)] + ['"scc"', '"vcc"', '"memory"']
+    def clobbers(nv):
+        return [f'"v{i}"' for i in range(nv)] + [f'"a{i}"' for i in range(128)] + [f'"s{i}"' for i in range(64, 90)] + ['"scc"', '"vcc"', '"memory"']
+    clob = clobbers(MAPS["wide"]["NV"])
     parts = ["// GENERATED by scripts/gen_gram_w4_asm.py -- edit the generator, not this file.  The instruction streams of the four-wave",
              "// float16-piece product kernels of sdm_gram_bf16.hip (register map, step layout, variants and how the waits are counted: see",
              "// the generator's header).",
              "// clang-format off", ""]
-    parts.append(render("SDM_GRAM_W4_ASM", generate(False)))
+    parts.append(render("SDM_GRAM_W4_ASM", generate_gram()))
     parts.append("")
-    parts.append(render("SDM_UPDATE_W4_ASM", generate(True)))
+    parts.append(render("SDM_UPDATE_W4_ASM", generate_update()))
     parts.append("")
     parts.append("#define SDM_GRAM_W4_CLOBBERS " + ", ".join(clob))
+    parts.append("#define SDM_UPDATE_W4_CLOBBERS " + ", ".join(clobbers(MAPS["slim"]["NV"])))
     parts.append("")
     out = sys.argv[1] if len(sys.argv) > 1 else OUT      # (tests/test_gram_stream_generator.py writes to a scratch path and compares)
     with open(out, "w") as f:

@@ -269,13 +269,13 @@ __device__ __forceinline__ GramW4Operands gram_w4_operands(const bf16x8* planes,
     o.lds = __builtin_amdgcn_readfirstlane(l0 + 16u * (unsigned)((wave >> 1) * 128 + (wave & 1) * 64));
     return o;
 }
-#define SDM_GRAM_W4_RUN(TEXT, O, NSLABS, CP, LDC, VC, UNSCALE, ROW0, ROWEND)                                                              \
+#define SDM_GRAM_W4_RUN(TEXT, CLOBBERS, O, NSLABS, CP, LDC, VC, UNSCALE, ROW0, ROWEND)                                                    \
     asm volatile(TEXT                                                                                                                \
                  :                                                                                                                   \
                  : [ua0] "s"(O.ua0), [ua1] "s"(O.ua1), [ub0] "s"(O.ub0), [ub1] "s"(O.ub1), [step] "s"(O.step), [nslabs] "s"(NSLABS), \
                    [lds] "s"(O.lds), [cp] "s"(CP), [ldc1] "s"((unsigned long long)(LDC) * 4), [ldc5] "s"((unsigned long long)(LDC) * 20), \
                    [unscale] "s"(UNSCALE), [row0] "s"(ROW0), [rowend] "s"(ROWEND), [va] "v"(O.va), [vb] "v"(O.vb), [baddr] "v"(O.baddr), [vc] "v"(VC) \
-                 : SDM_GRAM_W4_CLOBBERS)
+                 : CLOBBERS)
 
 __global__ void __launch_bounds__(256)
 syrk_tn_split_w4_kernel(const bf16x8* __restrict__ planes, int NG, int ncols2, int ncols, float* __restrict__ C, long long ldc,
@@ -297,7 +297,7 @@ syrk_tn_split_w4_kernel(const bf16x8* __restrict__ planes, int NG, int ncols2, i
     const unsigned vc = 4u * (unsigned)(4 * (lane >> 5) * (int)ldc + (lane & 31));
     const unsigned unscale = __builtin_bit_cast(unsigned, GH_UNSCALE);
     const int nslabs = NG / 2;                                    // (a multiple of 4)
-    SDM_GRAM_W4_RUN(SDM_GRAM_W4_ASM, o, nslabs, cp, ldc, vc, unscale, gi0i, rowend);
+    SDM_GRAM_W4_RUN(SDM_GRAM_W4_ASM, SDM_GRAM_W4_CLOBBERS, o, nslabs, cp, ldc, vc, unscale, gi0i, rowend);
 }
 
 // ---- the Cholesky's trailing update C -= P^T P on the float16 matrix cores (round 3): P = the 512 rows of a panel group
@@ -369,6 +369,13 @@ split_planes_f16_scaled_kernel(const float* __restrict__ A, long long lda, int N
 // The same update on the four-wave instruction stream (round 6, SDM_UPDATE_W4_ASM): the wave's 64 x 128 of C is requested before
 // anything else into the registers that hold the Gram kernel's second accumulator level (K <= 512 rows: one level), the products
 // run as in the Gram kernel, the epilogue writes C - acc * unscale.
+// Round 6: the stream runs on 124 + 128 registers (the rows' and columns' fragments, temporaries and offsets in v[0:123]; no second
+// accumulator level at K <= 512, and C is read behind the loop into the then dead fragment registers), i.e. TWO workgroups per compute
+// unit: a tile of 32 slabs is prologue (first operands: latency) and epilogue (read C, subtract, store) for almost as long as it
+// multiplies, which a wave alone on its SIMD cannot overlap with products; two waves per SIMD do it for each other.  Same products in
+// the same order as the one-wave stream it replaces (C requested during the first sixteen slabs into the Gram kernel's second-level
+// registers): bit-identical factors; the largest tail of F = 27 201 by itself 1 144 -> 973 us, matrix pipe busy 0.43 -> 0.58 at a
+// clock that settles at 1.83 instead of 2.12 GHz (profiles/r06_update_two_waves.txt).
 __global__ void __launch_bounds__(256)
 syrk_update_f16_w4_kernel(const bf16x8* __restrict__ planes, int NG, int ncols2, int Tloc, int TlocF, float* __restrict__ C, long long ldc,
                           const unsigned* __restrict__ scales, int slot, int I_lo, int I_hi, int own_first, int own_stride, int chunk)
@@ -408,7 +415,7 @@ syrk_update_f16_w4_kernel(const bf16x8* __restrict__ planes, int NG, int ncols2,
     const int ef = f16_factor_exponent(scales);
     const unsigned unscale = (unsigned)(127 + (ef - 14) + ((j >= TlocF ? f16_rhs_exponent(scales, slot) : ef) - 14)) << 23;
     const int nslabs = NG / 2;                                    // (whole 128-row panels: a multiple of 8)
-    SDM_GRAM_W4_RUN(SDM_UPDATE_W4_ASM, o, nslabs, cp, ldc, vc, unscale, gi0i, rowend);
+    SDM_GRAM_W4_RUN(SDM_UPDATE_W4_ASM, SDM_UPDATE_W4_CLOBBERS, o, nslabs, cp, ldc, vc, unscale, gi0i, rowend);
 }
 
 // The same update for the HEAD of the look-ahead (the next group's four tile rows, on the factorisation's serial chain) while the

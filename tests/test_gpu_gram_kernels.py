@@ -80,9 +80,9 @@ def test_trailing_update_for_every_panel_group_height(built, monkeypatch, tiles)
 @pytest.mark.parametrize("rows", [128, 256, 384, 512])
 @pytest.mark.parametrize("factor_tiles,rhs_tiles", [(5, 1), (18, 2)])
 def test_trailing_update_stream_by_itself(built, rows, factor_tiles, rhs_tiles):
-    """C -= P^T P through sdm_debug_update_f16: the four-wave update stream alone, 8 / 16 / 24 / 32 slabs (the first sixteen carry the
-    loads of C; with eight the second half of C is requested behind the loop), super-rows on and off the diagonal, right-hand-side
-    tile columns with their own scale.  Against float64: the operands are two float16 pieces (22 significant bits)."""
+    """C -= P^T P through sdm_debug_update_f16: the four-wave update stream alone (124 + 128 registers, two workgroups per compute
+    unit, its part of C read behind the loop in two rounds), 8 / 16 / 24 / 32 slabs, super-rows on and off the diagonal,
+    right-hand-side tile columns with their own scale.  Against float64: the operands are two float16 pieces (22 significant bits)."""
     rng = np.random.default_rng(rows + factor_tiles)
     wf, w = 128 * factor_tiles, 128 * (factor_tiles + rhs_tiles)
     P = rng.standard_normal((rows, w)).astype(np.float32)
