@@ -414,7 +414,11 @@ __host__ __device__ constexpr int trsm_blk(int jb, int rb) { return jb * (17 - j
 // solve needs is picked by uniform selects): unrolled, step (a) exists eight times, each copy executed once by one wave.
 // =====================================================================================================
 #define POTRF2_LDS_FLOATS (IB * POTRF_PLD + NIB * IB * IB + 4)
-__global__ void __launch_bounds__(TILE * PQ)
+// (128 vector registers, not the 129 the compiler would take: the kernel's eight waves are two per SIMD, and beside the trailing
+//  update -- two workgroups of 256 registers per compute unit -- they fit into what ONE retiring workgroup leaves; with 136 they
+//  waited for both to retire at once: 26 of RCR-68's 213 factor steps waited 60 - 620 us.  Gone with this line -- the factor + solve
+//  time is the same, the other chain kernels take up the slack: profiles/r06_update_two_waves.txt, 5.)
+__global__ void __launch_bounds__(TILE * PQ) __attribute__((amdgpu_waves_per_eu(4, 4)))
 potrf_tile2_kernel(float* __restrict__ G, long long ldg, int k0, int* __restrict__ status)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
