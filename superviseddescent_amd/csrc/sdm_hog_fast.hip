@@ -1749,7 +1749,7 @@ __global__ void verify_fast_bins_kernel(HogLevelDev lv, int* __restrict__ mismat
 namespace {
 struct PlanLane { int slot, col, active, seg; };
 // greedy packing of `npatch` patches of S columns into passes of 64 lanes (see HogPlanDev)
-int plan_pack(int S, int npatch, std::vector<std::vector<PlanLane>>& passes)
+int plan_pack_cut(int S, int npatch, std::vector<std::vector<PlanLane>>& passes, bool allow_cut)
 {
     passes.clear();
     std::vector<PlanLane> cur;
@@ -1767,7 +1767,7 @@ int plan_pack(int S, int npatch, std::vector<std::vector<PlanLane>>& passes)
                 ++segs;
                 break;
             }
-            if (free_l >= 3) {
+            if (free_l >= 3 && allow_cut) {
                 // cut: the last placed column is only the right neighbour of the one before it; the next pass starts one
                 // column earlier, which there is only the left neighbour
                 const int e = c + free_l - 1;
@@ -1784,6 +1784,14 @@ int plan_pack(int S, int npatch, std::vector<std::vector<PlanLane>>& passes)
     flush();
     return (int)passes.size();
 }
+// ... with cuts only if they save a pass (a cut patch's raw cells arrive in two parts, which the descriptor kernel adds)
+int plan_pack(int S, int npatch, std::vector<std::vector<PlanLane>>& passes)
+{
+    std::vector<std::vector<PlanLane>> whole;
+    const int pw = plan_pack_cut(S, npatch, whole, false), pc = plan_pack_cut(S, npatch, passes, true);
+    if (pw <= pc) { passes.swap(whole); return pw; }
+    return pc;
+}
 }  // namespace
 
 bool sdm_hog_plan_build(const HogLevelDev& lv, int L, HogPlanHost& out)
@@ -1797,9 +1805,10 @@ bool sdm_hog_plan_build(const HogLevelDev& lv, int L, HogPlanHost& out)
     }
     std::vector<std::vector<PlanLane>> tmp;
     // group size: fewest passes per sample; among equals at least two passes per wave (the per-group set-up is then shared),
-    // then the smaller group
+    // then the smaller group.  Up to 12 patches (round 6; 8 before): nine 55-column patches of the first shipped level share eight
+    // passes (495 columns + 2 per cut in 512 lanes) -- 20 passes per RCR-22 face instead of 22, 61 instead of 68 at RCR-68.
     int bestG = 1; long long bestCost = -1; bool bestMulti = false;
-    for (int G = 1; G <= 8 && G <= L; ++G) {
+    for (int G = 1; G <= 12 && G <= L; ++G) {
         const int P = plan_pack(S, G, tmp);
         const int nm = L / G, Gt = L - nm * G;
         const long long cost = (long long)nm * P + (Gt ? plan_pack(S, Gt, tmp) : 0);

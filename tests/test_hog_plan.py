@@ -120,7 +120,8 @@ def test_plan_fold_weights(built, C, cell, O, L):
 def test_plan_packs_the_shipped_levels(built):
     # S = (55, 50, 40, 30) for the shipped parameters; 22 landmarks
     got = {cell: hog_plan(5, cell, 4, 22) for cell in (11, 10, 8, 6)}
-    assert (got[11]["G"], got[11]["P"]) == (1, 1)           # 55 columns: nothing to pack
+    assert (got[11]["G"], got[11]["P"]) == (9, 8)           # nine 55-column patches in eight passes (round 6: groups of up to 12); 22 landmarks = 2 x 9 + 4 whole ones: 20 passes
+    assert (got[11]["Gt"], got[11]["Pt"]) == (4, 4)         # ... the tail group's four patches one per pass: cuts that save no pass are not made
     assert (got[10]["G"], got[10]["P"]) == (5, 4)           # five 50-column patches in four passes
     assert (got[8]["G"], got[8]["P"]) == (3, 2)             # three 40-column patches in two passes
     assert (got[6]["G"], got[6]["P"]) == (2, 1)             # 30 columns: two patches per pass
