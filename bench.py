@@ -49,7 +49,8 @@ def gram_report(exec_flops, useful_flops, ms):
             "useful_tflops": useful_flops / (ms * 1e-3) / 1e12, "times_f32_mfma_peak": tf / MFMA_F32_PEAK_TF,
             "stage_ms": ms,
             "matrix_pipe": "profiles/r06_gram_pmc.txt: SQ_VALU_MFMA_BUSY_CYCLES / (1 024 SIMDs x GRBM_GUI_ACTIVE / 8) = 0.93 of the clocks, which "
-                           "the power limit holds at ~1.35 GHz under this load (2.4 GHz nominal = the clock `peak` is quoted at)",
+                           "the power limit holds at ~1.35 GHz under this load (2.4 GHz nominal = the clock `peak` is quoted at); "
+                           "profiles/r06_gram_power_check.txt: the same launch on rows of zeros takes 25 % less time than on the feature rows",
             "note": "every f32 operand = two float16 pieces (x 2^12), three piece products per product (low x low is below float32's "
                     "rounding), float32 accumulation; measured against a float64 product: 1.1e-7 ... 2.9e-7 relative (the f32 "
                     "matrix-core kernel it replaces: 2.4e-7 ... 3.5e-7)"}
